@@ -1,0 +1,86 @@
+/* TEST INFRASTRUCTURE ONLY -- C API shared by the two CPU checkers:
+ *
+ *   ho_*  oracle/hector_oracle.cpp   plain-C++ restatement of the reference path
+ *   hr_*  oracle/ref_shim.cpp        the UNMODIFIED reference headers from
+ *                                    /root/reference compiled through the private
+ *                                    Eigen/tf stand-in (oracle/stubs/) -> oracle/_ref/
+ *
+ * Both export the same entry points (prefix differs) so tests can drive either.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * these libraries; the product (libhector_mi355.so) never links or calls them.
+ *
+ * Conventions (all follow the reference):
+ *   poses    float[3] = x, y, theta      world: metres/rad, map: cells/rad
+ *   pts      float[2*n] AoS endpoints, robot frame, LEVEL-0 cell units
+ *            (DataPointContainer.h:92-96); *_level entry points take points
+ *            already scaled for that level (what DataContainer::setFrom produced)
+ *   cov/H    float[9] column-major 3x3 (Eigen default)
+ *   planes   row-major, index = y*sizeX + x (GridMapBase.h:141-144)
+ */
+#ifndef HECTOR_ORACLE_API_H
+#define HECTOR_ORACLE_API_H
+
+#ifndef ORACLE_PREFIX
+#error "define ORACLE_PREFIX (ho_ or hr_) before including oracle_api.h"
+#endif
+#define OR_CAT2(a, b) a##b
+#define OR_CAT(a, b) OR_CAT2(a, b)
+#define ORF(name) OR_CAT(ORACLE_PREFIX, name)
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HectorSlamProcessor ctor (HectorSlamProcessor.h:54-64) -> MapRepMultiMap ctor
+ * (MapRepMultiMap.h:48-72). */
+void* ORF(create)(float map_resolution, int size_x, int size_y, unsigned levels,
+                  float start_x, float start_y);
+void ORF(destroy)(void* h);
+void ORF(reset)(void* h);                                   /* HectorSlamProcessor::reset :115-124 */
+int ORF(levels)(void* h);                                   /* getMapLevels */
+float ORF(scale_to_map)(void* h);                           /* getScaleToMap (level 0) */
+void ORF(set_update_factor_free)(void* h, float f);         /* MapRepMultiMap.h:149-157 */
+void ORF(set_update_factor_occupied)(void* h, float f);     /* MapRepMultiMap.h:159-167 */
+void ORF(level_info)(void* h, int level, int* sx, int* sy, float* cell_length, float* scale_to_map);
+void ORF(download_level)(void* h, int level, float* logodds, int* update_index);
+/* overwrite cells, then invalidate the probability cache (like onMapUpdated) */
+void ORF(upload_level)(void* h, int level, const float* logodds, const int* update_index);
+
+void ORF(map_coords_pose)(void* h, int level, const float world[3], float map[3]);   /* GridMapBase.h:235-239 */
+void ORF(world_coords_pose)(void* h, int level, const float map[3], float world[3]); /* GridMapBase.h:226-230 */
+
+/* a1: OccGridMapUtil::interpMapValueWithDerivatives (OccGridMapUtil.h:287-347), n coords */
+void ORF(interp)(void* h, int level, const float* coords_xy, int n, float* out_mgxgy);
+/* a2: OccGridMapUtil::getCompleteHessianDerivs (OccGridMapUtil.h:64-104) */
+void ORF(hessian_derivs)(void* h, int level, const float pose_map[3], const float* pts_level,
+                         int n, float H[9], float dTr[3]);
+/* a5: ScanMatcher::matchData (ScanMatcher.h:54-190) on one level */
+void ORF(match_level)(void* h, int level, const float begin_world[3], const float* pts_level,
+                      int n, int max_iterations, float out_pose_world[3], float cov[9]);
+/* a7: MapRepMultiMap::matchData (MapRepMultiMap.h:116-132); a DataContainer is (pts, n, origo);
+ * cov is in/out (untouched for n==0).  Retains the per-level scaled copies like the reference. */
+void ORF(match)(void* h, const float begin_world[3], const float* pts, int n, const float origo[2],
+                float out_pose_world[3], float cov[9]);
+/* a11: MapRepMultiMap::updateByScan (MapRepMultiMap.h:134-147): level 0 from pts,
+ * coarse levels from the containers retained by the last match() call */
+void ORF(update_by_scan)(void* h, const float pose_world[3], const float* pts, int n,
+                         const float origo[2]);
+/* one level only, explicit points (OccGridMapBase.h:121-168) */
+void ORF(update_by_scan_level)(void* h, int level, const float pose_world[3],
+                               const float* pts_level, int n, const float origo_level[2]);
+void ORF(on_map_updated)(void* h);                          /* MapRepMultiMap.h:107-114 */
+
+/* a12: HectorSlamProcessor::update (HectorSlamProcessor.h:71-113) */
+void ORF(proc_set_thresholds)(void* h, float min_dist, float min_angle);
+void ORF(proc_update)(void* h, const float* pts, int n, const float origo[2],
+                      const float pose_hint_world[3], int map_without_matching);
+void ORF(proc_last_pose)(void* h, float pose[3], float cov[9]);
+
+/* a8 helpers (UtilFunctions.h:37-92) */
+float ORF(normalize_angle)(float a);
+int ORF(pose_difference_larger_than)(const float p1[3], const float p2[3], float dist, float ang);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

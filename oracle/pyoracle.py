@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end for the two CPU checkers.
+
+``Oracle("ho")`` drives oracle/build/libhector_oracle.so (plain-C++ restatement),
+``Oracle("hr")`` drives oracle/_ref/libhector_ref.so (the unmodified reference
+headers compiled through the private Eigen/tf stand-in).  Same API, see
+oracle/oracle_api.h.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {"ho": os.path.join(_HERE, "build", "libhector_oracle.so"),
+         "hr": os.path.join(_HERE, "_ref", "libhector_ref.so")}
+_loaded: dict = {}
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(quiet: bool = True) -> None:
+    """make -C oracle: restatement always; _ref only where /root/reference exists."""
+    subprocess.run(["make", "-C", _HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def available(kind: str) -> bool:
+    return os.path.exists(_LIBS[kind])
+
+
+def _load(kind: str):
+    if kind in _loaded:
+        return _loaded[kind]
+    if not os.path.exists(_LIBS[kind]):
+        if kind == "ho":
+            build()
+        else:
+            raise FileNotFoundError(f"{_LIBS[kind]} missing (built only where /root/reference exists)")
+    lib = C.CDLL(_LIBS[kind])
+    p = kind + "_"
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    sig = {
+        "create": (vp, [f, i, i, C.c_uint, f, f]),
+        "destroy": (None, [vp]), "reset": (None, [vp]), "levels": (i, [vp]),
+        "scale_to_map": (f, [vp]),
+        "set_update_factor_free": (None, [vp, f]), "set_update_factor_occupied": (None, [vp, f]),
+        "level_info": (None, [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(f), C.POINTER(f)]),
+        "download_level": (None, [vp, i, _f32p, _i32p]),
+        "upload_level": (None, [vp, i, _f32p, _i32p]),
+        "map_coords_pose": (None, [vp, i, _f32p, _f32p]),
+        "world_coords_pose": (None, [vp, i, _f32p, _f32p]),
+        "interp": (None, [vp, i, _f32p, i, _f32p]),
+        "hessian_derivs": (None, [vp, i, _f32p, _f32p, i, _f32p, _f32p]),
+        "match_level": (None, [vp, i, _f32p, _f32p, i, i, _f32p, _f32p]),
+        "match": (None, [vp, _f32p, _f32p, i, _f32p, _f32p, _f32p]),
+        "update_by_scan": (None, [vp, _f32p, _f32p, i, _f32p]),
+        "update_by_scan_level": (None, [vp, i, _f32p, _f32p, i, _f32p]),
+        "on_map_updated": (None, [vp]),
+        "proc_set_thresholds": (None, [vp, f, f]),
+        "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
+        "proc_last_pose": (None, [vp, _f32p, _f32p]),
+        "normalize_angle": (f, [f]),
+        "pose_difference_larger_than": (i, [_f32p, _f32p, f, f]),
+    }
+    ns = {}
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, p + name)
+        fn.restype, fn.argtypes = res, args
+        ns[name] = fn
+    _loaded[kind] = ns
+    return ns
+
+
+def _pts(pts) -> np.ndarray:
+    a = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    return a if a.size else np.zeros((1, 2), np.float32)[:0].reshape(0, 2).copy()
+
+
+def _v(x, n) -> np.ndarray:
+    a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    assert a.size == n
+    return a
+
+
+_ZERO2 = np.zeros(2, np.float32)
+
+
+class Oracle:
+    """One HectorSlamProcessor-equivalent on the CPU (kind 'ho' = restatement, 'hr' = reference)."""
+
+    def __init__(self, kind: str, resolution: float, size_x: int, size_y: int, levels: int,
+                 start=(0.5, 0.5)):
+        self.kind = kind
+        self.f = _load(kind)
+        self.h = self.f["create"](resolution, size_x, size_y, levels, start[0], start[1])
+        self.n_levels = levels
+
+    def close(self):
+        if self.h:
+            self.f["destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- map representation interface -------------------------------------
+    def reset(self): self.f["reset"](self.h)
+    def levels(self) -> int: return self.f["levels"](self.h)
+    def scale_to_map(self) -> float: return self.f["scale_to_map"](self.h)
+    def set_update_factor_free(self, v): self.f["set_update_factor_free"](self.h, v)
+    def set_update_factor_occupied(self, v): self.f["set_update_factor_occupied"](self.h, v)
+    def on_map_updated(self): self.f["on_map_updated"](self.h)
+
+    def level_info(self, level):
+        sx, sy, cell, scale = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+        self.f["level_info"](self.h, level, C.byref(sx), C.byref(sy), C.byref(cell), C.byref(scale))
+        return sx.value, sy.value, cell.value, scale.value
+
+    def download_level(self, level):
+        sx, sy, _, _ = self.level_info(level)
+        lo = np.empty(sx * sy, np.float32)
+        ui = np.empty(sx * sy, np.int32)
+        self.f["download_level"](self.h, level, lo, ui)
+        return lo.reshape(sy, sx), ui.reshape(sy, sx)
+
+    def upload_level(self, level, logodds, update_index):
+        self.f["upload_level"](self.h, level, np.ascontiguousarray(logodds, np.float32).reshape(-1),
+                               np.ascontiguousarray(update_index, np.int32).reshape(-1))
+
+    def map_coords_pose(self, level, world):
+        out = np.empty(3, np.float32)
+        self.f["map_coords_pose"](self.h, level, _v(world, 3), out)
+        return out
+
+    def world_coords_pose(self, level, mp):
+        out = np.empty(3, np.float32)
+        self.f["world_coords_pose"](self.h, level, _v(mp, 3), out)
+        return out
+
+    def interp(self, level, coords):
+        c = _pts(coords)
+        out = np.empty((c.shape[0], 3), np.float32)
+        self.f["interp"](self.h, level, c.reshape(-1), c.shape[0], out.reshape(-1))
+        return out
+
+    def hessian_derivs(self, level, pose_map, pts_level):
+        p = _pts(pts_level)
+        H = np.empty(9, np.float32)
+        d = np.empty(3, np.float32)
+        self.f["hessian_derivs"](self.h, level, _v(pose_map, 3), p.reshape(-1), p.shape[0], H, d)
+        return H.reshape(3, 3).T.copy(), d  # column-major -> numpy [r, c]
+
+    def match_level(self, level, begin_world, pts_level, max_iter, cov=None):
+        p = _pts(pts_level)
+        out = np.empty(3, np.float32)
+        c = np.zeros(9, np.float32) if cov is None else _v(cov, 9).copy()
+        self.f["match_level"](self.h, level, _v(begin_world, 3), p.reshape(-1), p.shape[0], max_iter, out, c)
+        return out, c
+
+    def match(self, begin_world, pts, origo=_ZERO2, cov=None):
+        p = _pts(pts)
+        out = np.empty(3, np.float32)
+        c = np.zeros(9, np.float32) if cov is None else _v(cov, 9).copy()
+        self.f["match"](self.h, _v(begin_world, 3), p.reshape(-1), p.shape[0], _v(origo, 2), out, c)
+        return out, c
+
+    def update_by_scan(self, pose_world, pts, origo=_ZERO2):
+        p = _pts(pts)
+        self.f["update_by_scan"](self.h, _v(pose_world, 3), p.reshape(-1), p.shape[0], _v(origo, 2))
+
+    def update_by_scan_level(self, level, pose_world, pts_level, origo_level=_ZERO2):
+        p = _pts(pts_level)
+        self.f["update_by_scan_level"](self.h, level, _v(pose_world, 3), p.reshape(-1), p.shape[0],
+                                       _v(origo_level, 2))
+
+    # ---- processor ------------------------------------------------------------
+    def proc_set_thresholds(self, d, a): self.f["proc_set_thresholds"](self.h, d, a)
+
+    def proc_update(self, pts, hint_world, origo=_ZERO2, map_without_matching=False):
+        p = _pts(pts)
+        self.f["proc_update"](self.h, p.reshape(-1), p.shape[0], _v(origo, 2), _v(hint_world, 3),
+                              1 if map_without_matching else 0)
+
+    def proc_last_pose(self):
+        pose = np.empty(3, np.float32)
+        cov = np.empty(9, np.float32)
+        self.f["proc_last_pose"](self.h, pose, cov)
+        return pose, cov
+
+    def normalize_angle(self, a) -> float:
+        return self.f["normalize_angle"](float(a))
+
+    def pose_difference_larger_than(self, p1, p2, d, a) -> bool:
+        return bool(self.f["pose_difference_larger_than"](_v(p1, 3), _v(p2, 3), d, a))
+
+    # ---- convenience ----------------------------------------------------------
+    def build_map(self, poses, scans, origo=_ZERO2):
+        """Map from ground-truth poses: match-free updates on every level (the retained
+        coarse containers are refreshed through match's setFrom, as in the processor)."""
+        for pose, pts in zip(poses, scans):
+            # proc_update(map_without_matching) would leave coarse levels stale (row a12);
+            # drive each level explicitly with the level-scaled container instead.
+            for lvl in range(self.n_levels):
+                f = np.float32(1.0 / 2.0 ** lvl)
+                self.update_by_scan_level(lvl, pose, (np.asarray(pts, np.float32) * f),
+                                          np.asarray(origo, np.float32) * f)
+            self.on_map_updated()

@@ -1,0 +1,196 @@
+// TEST INFRASTRUCTURE ONLY -- the reference itself behind the oracle C API.
+//
+// This translation unit #includes the UNMODIFIED hector_slam_lib headers
+// straight from /root/reference (via -I, nothing is copied into the repo) and
+// instantiates the reference's own classes: HectorSlamProcessor ->
+// MapRepMultiMap -> MapProcContainer{GridMap, OccGridMapUtilConfig, ScanMatcher}.
+// Eigen3 and tf (third-party, absent from /root/reference and from this image)
+// are provided by the private stand-ins in oracle/stubs/.  Built by
+// oracle/Makefile into oracle/_ref/libhector_ref.so (git-ignored, travels to the
+// GPU box with the snapshot).  Used to pin oracle/hector_oracle.cpp bit-for-bit
+// and as the "reference" CPU baseline in bench.py.
+#include "slam_main/HectorSlamProcessor.h"
+
+#include <sstream>
+#include <vector>
+
+#define ORACLE_PREFIX hr_
+#include "oracle_api.h"
+
+namespace {
+
+
+typedef hectorslam::GridMap RefGridMap;
+using hectorslam::HectorSlamProcessor;
+using hectorslam::MapProcContainer;
+using hectorslam::MapRepMultiMap;
+using hectorslam::MapRepresentationInterface;
+
+// reach protected members without touching the reference sources
+struct ProcAccess : HectorSlamProcessor {
+  static MapRepresentationInterface* get(HectorSlamProcessor& p) { return p.*(&ProcAccess::mapRep); }
+};
+struct MapAccess : MapRepMultiMap {
+  static std::vector<MapProcContainer>& get(MapRepMultiMap& m) { return m.*(&MapAccess::mapContainer); }
+};
+
+struct Ref {
+  HectorSlamProcessor* proc;
+  MapRepMultiMap* map;
+  Ref() : proc(0), map(0) {}
+  MapProcContainer& level(int l) { return MapAccess::get(*map)[l]; }
+};
+
+// the reference prints a banner (MapRepMultiMap.h:60) and a clamp message
+// (ScanMatcher.h:211,214) on std::cout; keep test output clean
+struct CoutMute {
+  std::streambuf* old;
+  std::ostringstream sink;
+  CoutMute() : old(std::cout.rdbuf(sink.rdbuf())) {}
+  ~CoutMute() { std::cout.rdbuf(old); }
+};
+
+static hectorslam::DataContainer make_container(const float* pts, int n, const float origo[2]) {
+  hectorslam::DataContainer dc(n > 0 ? n : 1);
+  for (int i = 0; i < n; ++i) dc.add(Eigen::Vector2f(pts[2 * i], pts[2 * i + 1]));
+  dc.setOrigo(origo ? Eigen::Vector2f(origo[0], origo[1]) : Eigen::Vector2f(0.0f, 0.0f));
+  return dc;
+}
+static inline Eigen::Vector3f v3(const float p[3]) { return Eigen::Vector3f(p[0], p[1], p[2]); }
+static inline void store3(const Eigen::Vector3f& v, float out[3]) {
+  out[0] = v[0];
+  out[1] = v[1];
+  out[2] = v[2];
+}
+static inline Eigen::Matrix3f m3(const float c[9]) {
+  Eigen::Matrix3f m;
+  for (int i = 0; i < 9; ++i) m.data()[i] = c[i];
+  return m;
+}
+static inline void store9(const Eigen::Matrix3f& m, float out[9]) {
+  for (int i = 0; i < 9; ++i) out[i] = m.data()[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+void* hr_create(float res, int sx, int sy, unsigned levels, float start_x, float start_y) {
+  CoutMute mute;
+  Ref* r = new Ref();
+  r->proc = new HectorSlamProcessor(res, sx, sy, Eigen::Vector2f(start_x, start_y), (int)levels, 0, 0);
+  r->map = static_cast<MapRepMultiMap*>(ProcAccess::get(*r->proc));
+  return r;
+}
+void hr_destroy(void* h) {
+  Ref* r = (Ref*)h;
+  delete r->proc;
+  delete r;
+}
+void hr_reset(void* h) { ((Ref*)h)->proc->reset(); }
+int hr_levels(void* h) { return ((Ref*)h)->proc->getMapLevels(); }
+float hr_scale_to_map(void* h) { return ((Ref*)h)->proc->getScaleToMap(); }
+void hr_set_update_factor_free(void* h, float f) { ((Ref*)h)->proc->setUpdateFactorFree(f); }
+void hr_set_update_factor_occupied(void* h, float f) { ((Ref*)h)->proc->setUpdateFactorOccupied(f); }
+void hr_level_info(void* h, int level, int* sx, int* sy, float* cell, float* scale) {
+  const RefGridMap& g = ((Ref*)h)->proc->getGridMap(level);
+  *sx = g.getSizeX();
+  *sy = g.getSizeY();
+  *cell = g.getCellLength();
+  *scale = g.getScaleToMap();
+}
+void hr_download_level(void* h, int level, float* lo, int* ui) {
+  const RefGridMap& g = ((Ref*)h)->proc->getGridMap(level);
+  const int n = g.getSizeX() * g.getSizeY();
+  for (int i = 0; i < n; ++i) {
+    if (lo) lo[i] = g.getCell(i).logOddsVal;
+    if (ui) ui[i] = g.getCell(i).updateIndex;
+  }
+}
+void hr_upload_level(void* h, int level, const float* lo, const int* ui) {
+  Ref* r = (Ref*)h;
+  RefGridMap& g = r->level(level).getGridMap();
+  const int n = g.getSizeX() * g.getSizeY();
+  for (int i = 0; i < n; ++i) {
+    if (lo) g.getCell(i).logOddsVal = lo[i];
+    if (ui) g.getCell(i).updateIndex = ui[i];
+  }
+  r->level(level).resetCachedData();
+}
+void hr_map_coords_pose(void* h, int level, const float w[3], float m[3]) {
+  store3(((Ref*)h)->proc->getGridMap(level).getMapCoordsPose(v3(w)), m);
+}
+void hr_world_coords_pose(void* h, int level, const float m[3], float w[3]) {
+  store3(((Ref*)h)->proc->getGridMap(level).getWorldCoordsPose(v3(m)), w);
+}
+void hr_interp(void* h, int level, const float* xy, int n, float* out) {
+  Ref* r = (Ref*)h;
+  for (int i = 0; i < n; ++i) {
+    Eigen::Vector3f v = r->level(level).gridMapUtil->interpMapValueWithDerivatives(
+        Eigen::Vector2f(xy[2 * i], xy[2 * i + 1]));
+    store3(v, out + 3 * i);
+  }
+}
+void hr_hessian_derivs(void* h, int level, const float pose[3], const float* pts, int n, float H[9],
+                       float dTr[3]) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, 0);
+  Eigen::Matrix3f Hm;
+  Eigen::Vector3f d;
+  r->level(level).gridMapUtil->getCompleteHessianDerivs(v3(pose), dc, Hm, d);
+  store9(Hm, H);
+  store3(d, dTr);
+}
+void hr_match_level(void* h, int level, const float begin[3], const float* pts, int n, int maxIter,
+                    float out[3], float cov[9]) {
+  CoutMute mute;
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, 0);
+  Eigen::Matrix3f c = m3(cov);
+  store3(r->level(level).matchData(v3(begin), dc, c, maxIter), out);
+  store9(c, cov);
+}
+void hr_match(void* h, const float begin[3], const float* pts, int n, const float origo[2],
+              float out[3], float cov[9]) {
+  CoutMute mute;
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, origo);
+  Eigen::Matrix3f c = m3(cov);
+  store3(r->map->matchData(v3(begin), dc, c), out);
+  store9(c, cov);
+}
+void hr_update_by_scan(void* h, const float pose[3], const float* pts, int n, const float origo[2]) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, origo);
+  r->map->updateByScan(dc, v3(pose));
+}
+void hr_update_by_scan_level(void* h, int level, const float pose[3], const float* pts, int n,
+                             const float origo[2]) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, origo);
+  r->level(level).updateByScan(dc, v3(pose));
+}
+void hr_on_map_updated(void* h) { ((Ref*)h)->map->onMapUpdated(); }
+
+void hr_proc_set_thresholds(void* h, float d, float a) {
+  ((Ref*)h)->proc->setMapUpdateMinDistDiff(d);
+  ((Ref*)h)->proc->setMapUpdateMinAngleDiff(a);
+}
+void hr_proc_update(void* h, const float* pts, int n, const float origo[2], const float hint[3],
+                    int mapWithoutMatching) {
+  CoutMute mute;
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, origo);
+  r->proc->update(dc, v3(hint), mapWithoutMatching != 0);
+}
+void hr_proc_last_pose(void* h, float pose[3], float cov[9]) {
+  Ref* r = (Ref*)h;
+  store3(r->proc->getLastScanMatchPose(), pose);
+  store9(r->proc->getLastScanMatchCovariance(), cov);
+}
+float hr_normalize_angle(float a) { return util::normalize_angle(a); }
+int hr_pose_difference_larger_than(const float p1[3], const float p2[3], float d, float a) {
+  return util::poseDifferenceLargerThan(v3(p1), v3(p2), d, a) ? 1 : 0;
+}
+
+}  // extern "C"
