@@ -1,0 +1,337 @@
+"""ctypes binding of the C ABI (include/hector_mi355/capi.h) + a thin Python mirror of the
+reference's map-representation interface.
+
+``MapRepMultiMap`` keeps the reference's method names and argument meaning
+(hector_slam_lib/slam_main/MapRepMultiMap.h, MapRepresentationInterface.h:38-62) so the
+parity tests read like calls into the reference.  Everything computes on the GPU through
+``libhector_mi355.so``; if the library is missing, or no HIP device is present, construction
+raises -- there is no CPU fallback in this package.
+
+torch is imported first on purpose: PyTorch-ROCm bundles its own ``libamdhip64.so`` with the
+same SONAME as /opt/rocm's; loading torch first makes the dynamic loader bind this library
+to that single HIP runtime, so torch device pointers / streams and ours interoperate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # plumbing only (device memory, streams, torch.distributed); see module docstring
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is always present in the target image
+    torch = None
+
+from . import build as _build
+
+HSM_OK = 0
+LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class HsmOpts(C.Structure):
+    _fields_ = [("device", C.c_int), ("layout", C.c_int), ("waves_per_scan", C.c_int)]
+
+
+class HsmError(RuntimeError):
+    pass
+
+
+# every symbol include/hector_mi355/capi.h declares: name -> (restype, argtypes)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "hsm_create": (_i, [_f, _i, _i, C.c_uint, _f, _f, C.POINTER(HsmOpts), C.POINTER(_vp)]),
+    "hsm_destroy": (None, [_vp]),
+    "hsm_reset": (_i, [_vp]),
+    "hsm_levels": (_i, [_vp]),
+    "hsm_scale_to_map": (_f, [_vp]),
+    "hsm_set_update_factor_free": (_i, [_vp, _f]),
+    "hsm_set_update_factor_occupied": (_i, [_vp, _f]),
+    "hsm_on_map_updated": (_i, [_vp]),
+    "hsm_match": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
+    "hsm_match_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "hsm_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
+    "hsm_update_by_scan": (_i, [_vp, _f32p, _vp, _i, _f32p]),
+    "hsm_update_by_scan_level": (_i, [_vp, _i, _f32p, _vp, _i, _f32p]),
+    "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
+    "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
+    "hsm_world_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
+    "hsm_update_index": (_i, [_vp, _i]),
+    "hsm_download_level": (_i, [_vp, _i, _vp, _vp]),
+    "hsm_upload_level": (_i, [_vp, _i, _vp, _vp]),
+    "hsm_download_rows": (_i, [_vp, _i, _i, _i, _f32p]),
+    "hsm_last_update_bbox": (_i, [_vp, _i, _i32p]),
+    "hsm_download_prob": (_i, [_vp, _i, _f32p]),
+    "hsm_hessian_derivs": (_i, [_vp, _i, _f32p, _vp, _i, _f32p, _f32p]),
+    "hsm_eval_beams": (_i, [_vp, _i, _f32p, _vp, _i, _vp]),
+    "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
+    "hsm_gn_iterations_per_match": (_i, [_vp]),
+    "hsm_last_launch_config": (_i, [_vp, _i32p]),
+    "hsm_last_error": (C.c_char_p, []),
+    "hsm_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen libhector_mi355.so (building it with hipcc when stale) and type every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build_native() if build_if_missing else _build.LIB
+    if not os.path.exists(path):
+        raise HsmError(f"{path} not found and could not be built; hector_slam_amd has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != HSM_OK:
+        raise HsmError(f"{what} failed ({rc}): {load_library().hsm_last_error().decode()}")
+
+
+def _pts(pts):
+    a = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    return a, (a.ctypes.data if a.size else None), a.shape[0]
+
+
+def _v(x, n):
+    a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} floats")
+    return a
+
+
+_ZERO2 = np.zeros(2, np.float32)
+
+
+class MapRepMultiMap:
+    """GPU-resident multi-resolution map representation (reference: MapRepMultiMap.h:45-173)."""
+
+    def __init__(self, mapResolution: float, mapSizeX: int, mapSizeY: int, numDepth: int,
+                 startCoords=(0.5, 0.5), device: int = -1, layout: int = LAYOUT_AUTO,
+                 waves_per_scan: int = 0):
+        self._lib = load_library()
+        self._h = _vp()
+        opts = HsmOpts(device, layout, waves_per_scan)
+        _check(self._lib.hsm_create(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords[0],
+                                    startCoords[1], C.byref(opts), C.byref(self._h)), "hsm_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- MapRepresentationInterface -------------------------------------------------
+    def reset(self): _check(self._lib.hsm_reset(self._h), "hsm_reset")
+    def getScaleToMap(self) -> float: return self._lib.hsm_scale_to_map(self._h)
+    def getMapLevels(self) -> int: return self._lib.hsm_levels(self._h)
+    def onMapUpdated(self): _check(self._lib.hsm_on_map_updated(self._h), "hsm_on_map_updated")
+
+    def setUpdateFactorFree(self, v: float):
+        _check(self._lib.hsm_set_update_factor_free(self._h, v), "hsm_set_update_factor_free")
+
+    def setUpdateFactorOccupied(self, v: float):
+        _check(self._lib.hsm_set_update_factor_occupied(self._h, v), "hsm_set_update_factor_occupied")
+
+    def matchData(self, beginEstimateWorld, dataContainer, covMatrix=None, origo=_ZERO2):
+        """-> (newEstimateWorld[3], covMatrix[9] column-major); cov is in/out like the reference."""
+        a, p, n = _pts(dataContainer)
+        out = np.empty(3, np.float32)
+        cov = np.zeros(9, np.float32) if covMatrix is None else _v(covMatrix, 9).copy()
+        _check(self._lib.hsm_match(self._h, _v(beginEstimateWorld, 3), p, n, _v(origo, 2), out, cov), "hsm_match")
+        return out, cov
+
+    def updateByScan(self, dataContainer, robotPoseWorld, origo=_ZERO2):
+        a, p, n = _pts(dataContainer)
+        _check(self._lib.hsm_update_by_scan(self._h, _v(robotPoseWorld, 3), p, n, _v(origo, 2)),
+               "hsm_update_by_scan")
+
+    # ---- GridMap accessors (host mirror support) ---------------------------------------
+    def level_info(self, level: int):
+        sx, sy, cell, scale = _i(), _i(), _f(), _f()
+        _check(self._lib.hsm_level_info(self._h, level, C.byref(sx), C.byref(sy), C.byref(cell),
+                                        C.byref(scale)), "hsm_level_info")
+        return sx.value, sy.value, cell.value, scale.value
+
+    def getMapCoordsPose(self, level, world):
+        out = np.empty(3, np.float32)
+        _check(self._lib.hsm_map_coords_pose(self._h, level, _v(world, 3), out), "hsm_map_coords_pose")
+        return out
+
+    def getWorldCoordsPose(self, level, mp):
+        out = np.empty(3, np.float32)
+        _check(self._lib.hsm_world_coords_pose(self._h, level, _v(mp, 3), out), "hsm_world_coords_pose")
+        return out
+
+    def getUpdateIndex(self, level=0) -> int:
+        return self._lib.hsm_update_index(self._h, level)
+
+    def download_level(self, level):
+        sx, sy, _, _ = self.level_info(level)
+        lo = np.empty((sy, sx), np.float32)
+        ui = np.empty((sy, sx), np.int32)
+        _check(self._lib.hsm_download_level(self._h, level, lo.ctypes.data, ui.ctypes.data), "hsm_download_level")
+        return lo, ui
+
+    def upload_level(self, level, logodds, update_index=None):
+        lo = np.ascontiguousarray(logodds, np.float32)
+        ui = None if update_index is None else np.ascontiguousarray(update_index, np.int32)
+        _check(self._lib.hsm_upload_level(self._h, level, lo.ctypes.data, None if ui is None else ui.ctypes.data),
+               "hsm_upload_level")
+
+    def download_rows(self, level, y0, y1):
+        sx, _, _, _ = self.level_info(level)
+        out = np.empty((max(y1 - y0, 0), sx), np.float32)
+        _check(self._lib.hsm_download_rows(self._h, level, y0, y1, out.reshape(-1) if out.size else
+                                           np.zeros(1, np.float32)), "hsm_download_rows")
+        return out
+
+    def last_update_bbox(self, level):
+        bb = np.empty(4, np.int32)
+        _check(self._lib.hsm_last_update_bbox(self._h, level, bb), "hsm_last_update_bbox")
+        return bb
+
+    def download_prob(self, level):
+        sx, sy, _, _ = self.level_info(level)
+        out = np.empty((sy, sx), np.float32)
+        _check(self._lib.hsm_download_prob(self._h, level, out.reshape(-1)), "hsm_download_prob")
+        return out
+
+    # ---- batched extension ---------------------------------------------------------------
+    def match_batch(self, begin_world, pts, offsets=None, want_cov=True):
+        """Host arrays in/out.  ``offsets`` None = every hypothesis uses the same scan ``pts``."""
+        b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 3)
+        a, p, n = _pts(pts)
+        out = np.empty_like(b)
+        cov = np.zeros((b.shape[0], 9), np.float32) if want_cov else None
+        offs = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        _check(self._lib.hsm_match_batch(self._h, b.shape[0], b.reshape(-1), p,
+                                         None if offs is None else offs.ctypes.data,
+                                         n if offs is None else 0, out.reshape(-1),
+                                         None if cov is None else cov.ctypes.data), "hsm_match_batch")
+        return out, cov
+
+    def match_batch_device(self, batch, d_begin, d_pts, d_offsets, shared_n, d_out_pose, d_out_cov, stream=0):
+        """Raw device pointers (ints), asynchronous on ``stream`` (a hipStream_t value)."""
+        _check(self._lib.hsm_match_batch_device(self._h, batch, d_begin, d_pts, d_offsets or None, shared_n,
+                                                d_out_pose, d_out_cov or None, stream or None),
+               "hsm_match_batch_device")
+
+    def gn_iterations_per_match(self) -> int:
+        return self._lib.hsm_gn_iterations_per_match(self._h)
+
+    def last_launch_config(self):
+        cfg = np.empty(4, np.int32)
+        _check(self._lib.hsm_last_launch_config(self._h, cfg), "hsm_last_launch_config")
+        return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
+                "block": int(cfg[2]), "grid": int(cfg[3])}
+
+    # ---- parity / debug ---------------------------------------------------------------------
+    def hessian_derivs(self, level, pose_map, pts_level):
+        a, p, n = _pts(pts_level)
+        H = np.empty(9, np.float32)
+        d = np.empty(3, np.float32)
+        _check(self._lib.hsm_hessian_derivs(self._h, level, _v(pose_map, 3), p, n, H, d), "hsm_hessian_derivs")
+        return H.reshape(3, 3).T.copy(), d
+
+    def eval_beams(self, level, pose_map, pts_level):
+        a, p, n = _pts(pts_level)
+        out = np.empty((n, 4), np.float32)
+        _check(self._lib.hsm_eval_beams(self._h, level, _v(pose_map, 3), p, n, out.ctypes.data if n else None),
+               "hsm_eval_beams")
+        return out
+
+    def match_level(self, level, begin_world, pts_level, max_iter, cov=None):
+        a, p, n = _pts(pts_level)
+        out = np.empty(3, np.float32)
+        c = np.zeros(9, np.float32) if cov is None else _v(cov, 9).copy()
+        _check(self._lib.hsm_match_level(self._h, level, _v(begin_world, 3), p, n, max_iter, out, c),
+               "hsm_match_level")
+        return out, c
+
+    def update_by_scan_level(self, level, pose_world, pts_level, origo_level=_ZERO2):
+        a, p, n = _pts(pts_level)
+        _check(self._lib.hsm_update_by_scan_level(self._h, level, _v(pose_world, 3), p, n, _v(origo_level, 2)),
+               "hsm_update_by_scan_level")
+
+    def build_map(self, poses, scans, origo=_ZERO2):
+        """Ground-truth-posed map building on every level (same recipe as the oracle's build_map)."""
+        for pose, pts in zip(poses, scans):
+            for lvl in range(self.getMapLevels()):
+                f = np.float32(1.0 / 2.0 ** lvl)
+                self.update_by_scan_level(lvl, pose, np.asarray(pts, np.float32) * f,
+                                          np.asarray(origo, np.float32) * f)
+            self.onMapUpdated()
+
+
+def pose_difference_larger_than(p1, p2, dist_thresh, ang_thresh) -> bool:
+    """util::poseDifferenceLargerThan (hector_slam_lib/util/UtilFunctions.h:73-92), fp32."""
+    p1 = np.asarray(p1, np.float32)
+    p2 = np.asarray(p2, np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        d = p1[:2] - p2[:2]
+        if np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1])) > np.float32(dist_thresh):
+            return True
+        ang = np.float32(p1[2] - p2[2])
+        if ang > np.pi:
+            ang = np.float32(np.float64(ang) - np.pi * 2.0)
+        elif ang < -np.pi:
+            ang = np.float32(np.float64(ang) + np.pi * 2.0)
+        return bool(abs(ang) > np.float32(ang_thresh))
+
+
+class HectorSlamProcessor:
+    """Glue of HectorSlamProcessor::update (slam_main/HectorSlamProcessor.h:71-124) over the
+    GPU map representation: match -> threshold test -> updateByScan -> onMapUpdated."""
+
+    def __init__(self, mapResolution, mapSizeX, mapSizeY, startCoords, multi_res_size, **kw):
+        self.mapRep = MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, multi_res_size, startCoords, **kw)
+        self.lastScanMatchCov = np.zeros(9, np.float32)
+        self.reset()
+        self.paramMinDistanceDiffForMapUpdate = np.float32(0.4)
+        self.paramMinAngleDiffForMapUpdate = np.float32(0.13)
+
+    def reset(self):
+        fmax = np.finfo(np.float32).max
+        self.lastMapUpdatePose = np.array([fmax, fmax, fmax], np.float32)
+        self.lastScanMatchPose = np.zeros(3, np.float32)
+        self.mapRep.reset()
+
+    def setMapUpdateMinDistDiff(self, v): self.paramMinDistanceDiffForMapUpdate = np.float32(v)
+    def setMapUpdateMinAngleDiff(self, v): self.paramMinAngleDiffForMapUpdate = np.float32(v)
+    def setUpdateFactorFree(self, v): self.mapRep.setUpdateFactorFree(v)
+    def setUpdateFactorOccupied(self, v): self.mapRep.setUpdateFactorOccupied(v)
+    def getLastScanMatchPose(self): return self.lastScanMatchPose
+    def getLastScanMatchCovariance(self): return self.lastScanMatchCov
+
+    def update(self, dataContainer, poseHintWorld, map_without_matching=False, origo=_ZERO2):
+        if not map_without_matching:
+            new_pose, self.lastScanMatchCov = self.mapRep.matchData(poseHintWorld, dataContainer,
+                                                                    self.lastScanMatchCov, origo)
+        else:
+            new_pose = np.asarray(poseHintWorld, np.float32).copy()
+        self.lastScanMatchPose = new_pose
+        if pose_difference_larger_than(new_pose, self.lastMapUpdatePose, self.paramMinDistanceDiffForMapUpdate,
+                                       self.paramMinAngleDiffForMapUpdate) or map_without_matching:
+            self.mapRep.updateByScan(dataContainer, new_pose, origo)
+            self.mapRep.onMapUpdated()
+            self.lastMapUpdatePose = new_pose.copy()

@@ -1,0 +1,371 @@
+// gn_match.h -- the scan-to-map Gauss-Newton matcher as CDNA4 (gfx950) HIP kernels.
+//
+// What it computes (reference, HSL/ = hector_mapping/include/hector_slam_lib/):
+//   per beam   OccGridMapUtil::interpMapValueWithDerivatives   HSL/map/OccGridMapUtil.h:287-347
+//   per scan   OccGridMapUtil::getCompleteHessianDerivs        HSL/map/OccGridMapUtil.h:64-104
+//   per step   ScanMatcher::estimateTransformationLogLh        HSL/matcher/ScanMatcher.h:194-221
+//   per level  ScanMatcher::matchData                          HSL/matcher/ScanMatcher.h:54-190
+//   per match  MapRepMultiMap::matchData                       HSL/slam_main/MapRepMultiMap.h:116-132
+//
+// How it is mapped onto the machine:
+//   * one TEAM of WPS wavefronts (64 lanes each) owns one (pose hypothesis, scan)
+//     pair for the WHOLE coarse-to-fine schedule (all levels, all GN steps) -- the
+//     14-step dependent chain never leaves the CU, no host round trips;
+//   * beams are dealt round-robin to lanes (beam i -> lane i mod 64*WPS), so the
+//     float2 endpoint loads of a wavefront are one contiguous 512-byte segment and
+//     neighbouring lanes sample neighbouring map cells;
+//   * the occupancy pyramid is sampled from a texture-like "quad" plane: texel
+//     (x,y) = float4{P(x,y), P(x+1,y), P(x,y+1), P(x+1,y+1)} -> ONE 16-byte gather
+//     per beam instead of four 4-byte gathers on two rows (HSM_LAYOUT_PLANE keeps
+//     the 4-gather form for A/B measurements);
+//   * the 6 unique H terms + 3 dTr terms are lane-local fp32 partial sums, reduced
+//     with a wavefront butterfly (__shfl_xor), then -- when WPS > 1 -- staged
+//     through LDS (double buffered, one barrier per GN step);
+//   * every lane ends up with bit-identical totals and solves the 3x3 system
+//     redundantly: no broadcast, no divergence.
+//   No MFMA: this is a bilinear gather plus a 9-term reduction, not a contraction.
+//
+// Numerics: built with -ffp-contract=off.  Every per-beam value (M, dM/dx, dM/dy,
+// rotDeriv and the nine products) is the same IEEE fp32 expression, in the same
+// order, as the reference; only the ORDER of the beam summation differs (strided
+// partial sums + tree instead of one sequential chain).  sin/cos/exp are evaluated
+// in fp64 and rounded once to fp32 (within 1 ulp of glibc's sinf/cosf/expf, which
+// the reference calls through the float overloads).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hsm {
+
+constexpr int kMaxLevels = 8;
+constexpr int kLayoutQuad = 1;
+constexpr int kLayoutPlane = 2;
+
+// Eigen::Affine2f as the reference builds it: 2x2 linear (column major) + translation.
+struct Affine2 {
+  float l00, l10, l01, l11, t0, t1;
+};
+
+// read-only view of one pyramid level for the matcher
+struct LevelView {
+  const float4* quad;  // [sy*sx] texels {P00,P10,P01,P11}
+  const float* prob;   // [sy*sx] plain probability plane
+  int sx, sy;
+  float limx, limy;    // dims - 2  (MapDimensionProperties.h:70-74)
+  Affine2 mapTworld;   // GridMapBase.h:272
+  Affine2 worldTmap;   // GridMapBase.h:279
+  float pt_scale;      // 2^-level applied to the level-0 endpoints (DataPointContainer.h:46-58)
+  int gn_steps;        // 1 + maxIterations (ScanMatcher.h:74,94-97)
+};
+
+struct MatchParams {
+  LevelView lv[kMaxLevels];
+  int first_level;         // coarsest level to run (levels first_level .. last_level, descending)
+  int last_level;
+  int batch;
+  const float* begin_world;  // [B*3]
+  const float2* pts;         // packed endpoints
+  const int* offsets;        // [B+1] or nullptr (shared scan)
+  int shared_n;
+  float* out_pose;           // [B*3]
+  float* out_cov;            // [B*9] or nullptr
+};
+
+// Transform<Affine> * Vector2f = t + (l(i,0)*x + l(i,1)*y)   (Eigen Transform.h)
+__device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y, float& ox, float& oy) {
+  ox = a.t0 + (a.l00 * x + a.l01 * y);
+  oy = a.t1 + (a.l10 * x + a.l11 * y);
+}
+
+// sinf/cosf of the reference (float overloads): fp64 then one rounding.
+__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) {
+  double sd, cd;
+  sincos((double)th, &sd, &cd);
+  s = (float)sd;
+  c = (float)cd;
+}
+
+// util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
+__device__ __forceinline__ float normalize_angle(float angle) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  float a = (float)fmod(fmod((double)angle, two_pi) + two_pi, two_pi);
+  if ((double)a > 3.14159265358979323846) {
+    a = (float)((double)a - two_pi);
+  }
+  return a;
+}
+
+struct BeamTerms {
+  float M, gx, gy;
+};
+
+// a1: interpMapValueWithDerivatives at map coords (cx, cy)
+template <int LAYOUT>
+__device__ __forceinline__ BeamTerms interp_with_derivs(const LevelView& L, float cx, float cy) {
+  // MapDimensionProperties::pointOutOfMapBounds (MapDimensionProperties.h:65-68)
+  const bool oob = (cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy);
+  // out-of-map lanes sample texel 0 and are zeroed below (the reference returns (0,0,0))
+  const float sx_ = oob ? 0.0f : cx;
+  const float sy_ = oob ? 0.0f : cy;
+  const int ix = (int)sx_;  // truncation, :295
+  const int iy = (int)sy_;
+  const float fx = sx_ - (float)ix;  // :298
+  const float fy = sy_ - (float)iy;
+  const int index = iy * L.sx + ix;  // :302
+  float i0, i1, i2, i3;
+  if (LAYOUT == kLayoutQuad) {
+    const float4 q = L.quad[index];
+    i0 = q.x;
+    i1 = q.y;
+    i2 = q.z;
+    i3 = q.w;
+  } else {
+    // indices index, index+1, index+sizeX, index+sizeX+1 (:306-330).  A NaN coordinate
+    // passes the bounds test like in the reference; v_cvt_i32_f32(NaN) = 0 keeps the
+    // address inside the plane and the NaN fraction poisons the result as it should.
+    const float* p = L.prob + index;
+    i0 = p[0];
+    i1 = p[1];
+    i2 = p[L.sx];
+    i3 = p[L.sx + 1];
+  }
+  const float dx1 = i0 - i1;  // :332-336
+  const float dx2 = i2 - i3;
+  const float dy1 = i0 - i2;
+  const float dy2 = i1 - i3;
+  const float xFacInv = (1.0f - fx);  // :338-339
+  const float yFacInv = (1.0f - fy);
+  BeamTerms r;
+  // :341-346, source-literal (x-differences blended with the x fractions)
+  r.M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
+  r.gx = -((dx1 * xFacInv) + (dx2 * fx));
+  r.gy = -((dy1 * yFacInv) + (dy2 * fy));
+  if (oob) {
+    r.M = 0.0f;
+    r.gx = 0.0f;
+    r.gy = 0.0f;
+  }
+  return r;
+}
+
+// per-beam contribution to (dTr, H) -- OccGridMapUtil.h:76-98
+struct Acc9 {
+  float d0, d1, d2, h00, h11, h22, h01, h02, h12;
+  __device__ __forceinline__ void zero() { d0 = d1 = d2 = h00 = h11 = h22 = h01 = h02 = h12 = 0.0f; }
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ float beam_accumulate(const LevelView& L, float ex, float ey, float sinRot,
+                                                 float cosRot, float px, float py, Acc9& a,
+                                                 BeamTerms* terms_out = nullptr) {
+  // transform * currPoint with transform = Translation(ex,ey) * Rotation(theta): linear [c -s; s c]
+  const float tx = ex + (cosRot * px + (-sinRot) * py);
+  const float ty = ey + (sinRot * px + cosRot * py);
+  const BeamTerms t = interp_with_derivs<LAYOUT>(L, tx, ty);
+  const float funVal = 1.0f - t.M;
+  a.d0 += t.gx * funVal;
+  a.d1 += t.gy * funVal;
+  const float rotDeriv = ((-sinRot * px - cosRot * py) * t.gx + (cosRot * px - sinRot * py) * t.gy);  // :87
+  a.d2 += rotDeriv * funVal;
+  a.h00 += t.gx * t.gx;
+  a.h11 += t.gy * t.gy;
+  a.h22 += rotDeriv * rotDeriv;
+  a.h01 += t.gx * t.gy;
+  a.h02 += t.gx * rotDeriv;
+  a.h12 += t.gy * rotDeriv;
+  if (terms_out) *terms_out = t;
+  return rotDeriv;
+}
+
+__device__ __forceinline__ float wave_allreduce(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ void wave_allreduce9(Acc9& a) {
+  a.d0 = wave_allreduce(a.d0);
+  a.d1 = wave_allreduce(a.d1);
+  a.d2 = wave_allreduce(a.d2);
+  a.h00 = wave_allreduce(a.h00);
+  a.h11 = wave_allreduce(a.h11);
+  a.h22 = wave_allreduce(a.h22);
+  a.h01 = wave_allreduce(a.h01);
+  a.h02 = wave_allreduce(a.h02);
+  a.h12 = wave_allreduce(a.h12);
+}
+
+// team-wide totals: wave butterfly, then (WPS > 1) LDS staging of the per-wave
+// partials; every thread of the team returns with identical bits.
+template <int WPS>
+__device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[WPS][9], int buf, int wave_in_team,
+                                                int lane) {
+  wave_allreduce9(a);
+  if (WPS > 1) {
+    if (lane == 0) {
+      float* r = red[buf][wave_in_team];
+      r[0] = a.d0; r[1] = a.d1; r[2] = a.d2;
+      r[3] = a.h00; r[4] = a.h11; r[5] = a.h22;
+      r[6] = a.h01; r[7] = a.h02; r[8] = a.h12;
+    }
+    __syncthreads();
+    float t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = red[buf][0][k];
+#pragma unroll
+    for (int w = 1; w < WPS; ++w) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) t[k] += red[buf][w][k];
+    }
+    a.d0 = t[0]; a.d1 = t[1]; a.d2 = t[2];
+    a.h00 = t[3]; a.h11 = t[4]; a.h22 = t[5];
+    a.h01 = t[6]; a.h02 = t[7]; a.h12 = t[8];
+  }
+}
+
+// H.inverse() * dTr as Eigen evaluates it (LU/InverseImpl.h cofactors * invdet, then a
+// coefficient-based product; 3-term sums are x0 + (x1 + x2)), ScanMatcher.h:201-217.
+__device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, float& ey, float& eth) {
+  if ((a.h00 != 0.0f) && (a.h11 != 0.0f)) {
+    // symmetric H: m(r,c)
+    const float m00 = a.h00, m01 = a.h01, m02 = a.h02;
+    const float m10 = a.h01, m11 = a.h11, m12 = a.h12;
+    const float m20 = a.h02, m21 = a.h12, m22 = a.h22;
+    // cofactor_3x3<i,j> = m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1), i1=(i+1)%3 ...
+    const float c00 = m11 * m22 - m12 * m21;
+    const float c10 = m21 * m02 - m22 * m01;
+    const float c20 = m01 * m12 - m02 * m11;
+    const float det = c00 * m00 + (c10 * m10 + c20 * m20);
+    const float invdet = 1.0f / det;
+    const float i00 = c00 * invdet, i01 = c10 * invdet, i02 = c20 * invdet;
+    const float i10 = (m12 * m20 - m10 * m22) * invdet;  // cofactor<0,1>
+    const float i11 = (m22 * m00 - m20 * m02) * invdet;  // cofactor<1,1>
+    const float i12 = (m02 * m10 - m00 * m12) * invdet;  // cofactor<2,1>
+    const float i20 = (m10 * m21 - m11 * m20) * invdet;  // cofactor<0,2>
+    const float i21 = (m20 * m01 - m21 * m00) * invdet;  // cofactor<1,2>
+    const float i22 = (m00 * m11 - m01 * m10) * invdet;  // cofactor<2,2>
+    const float s0 = i00 * a.d0 + (i01 * a.d1 + i02 * a.d2);
+    const float s1 = i10 * a.d0 + (i11 * a.d1 + i12 * a.d2);
+    float s2 = i20 * a.d0 + (i21 * a.d1 + i22 * a.d2);
+    if (s2 > 0.2f) {
+      s2 = 0.2f;
+    } else if (s2 < -0.2f) {
+      s2 = -0.2f;
+    }
+    ex += s0;
+    ey += s1;
+    eth += s2;
+  }
+}
+
+// One team (WPS wavefronts) per scan; SPB scans per workgroup (SPB > 1 only when WPS == 1,
+// where no barrier is ever executed so the wavefronts of a block are fully independent).
+template <int WPS, int SPB, int LAYOUT>
+__global__ void __launch_bounds__(64 * WPS * SPB) gn_match_kernel(const MatchParams P) {
+  static_assert(WPS == 1 || SPB == 1, "barrier-synchronised teams own their workgroup");
+  __shared__ float red[2][WPS][9];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int team = wave / WPS;
+  const int wit = wave - team * WPS;
+  const int scan = blockIdx.x * SPB + team;
+  if (scan >= P.batch) return;  // whole team exits together
+
+  int beg = 0, n = P.shared_n;
+  if (P.offsets) {
+    beg = P.offsets[scan];
+    n = P.offsets[scan + 1] - beg;
+  }
+  float pw0 = P.begin_world[3 * scan + 0];
+  float pw1 = P.begin_world[3 * scan + 1];
+  float pw2 = P.begin_world[3 * scan + 2];
+  if (n == 0) {  // ScanMatcher.h:68,189: pose passes through, cov untouched
+    if (lane == 0 && wit == 0) {
+      P.out_pose[3 * scan + 0] = pw0;
+      P.out_pose[3 * scan + 1] = pw1;
+      P.out_pose[3 * scan + 2] = pw2;
+    }
+    return;
+  }
+  const float2* __restrict__ pts = P.pts + beg;
+  const int tid_in_team = wit * 64 + lane;
+  Acc9 acc;
+  acc.zero();
+  int buf = 0;
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);  // getMapCoordsPose, GridMapBase.h:235-239
+    eth = pw2;
+    const float ps = L.pt_scale;
+    for (int it = 0; it < L.gn_steps; ++it) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      acc.zero();
+      for (int i = tid_in_team; i < n; i += 64 * WPS) {
+        const float2 p = pts[i];
+        beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x * ps, p.y * ps, acc);
+      }
+      team_allreduce9<WPS>(acc, red, buf, wit, lane);
+      buf ^= 1;
+      gn_solve_and_step(acc, ex, ey, eth);
+    }
+    eth = normalize_angle(eth);                     // ScanMatcher.h:170
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);    // getWorldCoordsPose, :186
+    pw2 = eth;
+  }
+  if (lane == 0 && wit == 0) {
+    P.out_pose[3 * scan + 0] = pw0;
+    P.out_pose[3 * scan + 1] = pw1;
+    P.out_pose[3 * scan + 2] = pw2;
+    if (P.out_cov) {  // covMatrix = H of the last evaluation (ScanMatcher.h:184), column major
+      float* c = P.out_cov + 9 * scan;
+      c[0] = acc.h00; c[1] = acc.h01; c[2] = acc.h02;
+      c[3] = acc.h01; c[4] = acc.h11; c[5] = acc.h12;
+      c[6] = acc.h02; c[7] = acc.h12; c[8] = acc.h22;
+    }
+  }
+}
+
+// ---- parity / debug kernels: one evaluation at a given map-frame pose ------------
+// H, dTr of one getCompleteHessianDerivs call (same device functions as the matcher)
+template <int LAYOUT>
+__global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const float2* __restrict__ pts,
+                                                      int n, float ex, float ey, float eth,
+                                                      float* out12 /* H[9] col-major, dTr[3] */) {
+  __shared__ float red[2][16][9];
+  const int lane = threadIdx.x & 63;
+  const int wit = threadIdx.x >> 6;
+  float sinRot, cosRot;
+  sincos_f32(eth, sinRot, cosRot);
+  Acc9 acc;
+  acc.zero();
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float2 p = pts[i];
+    beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x, p.y, acc);
+  }
+  team_allreduce9<16>(acc, red, 0, wit, lane);
+  if (threadIdx.x == 0) {
+    out12[0] = acc.h00; out12[1] = acc.h01; out12[2] = acc.h02;
+    out12[3] = acc.h01; out12[4] = acc.h11; out12[5] = acc.h12;
+    out12[6] = acc.h02; out12[7] = acc.h12; out12[8] = acc.h22;
+    out12[9] = acc.d0; out12[10] = acc.d1; out12[11] = acc.d2;
+  }
+}
+
+// per-beam M, dM/dx, dM/dy, rotDeriv
+template <int LAYOUT>
+__global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict__ pts, int n, float ex,
+                                     float ey, float eth, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sinRot, cosRot;
+  sincos_f32(eth, sinRot, cosRot);
+  Acc9 acc;
+  acc.zero();
+  BeamTerms t;
+  const float2 p = pts[i];
+  const float rd = beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x, p.y, acc, &t);
+  out[i] = make_float4(t.M, t.gx, t.gy, rd);
+}
+
+}  // namespace hsm

@@ -1,0 +1,817 @@
+// hector_mi355.hip -- host runtime + C ABI (include/hector_mi355/capi.h) of the
+// MI355X-native hector_mapping scan matcher.  Kernels: gn_match.h, map_update.h.
+//
+// The context mirrors hectorslam::MapRepMultiMap (HSL/slam_main/MapRepMultiMap.h): a
+// pyramid of levels, each with its grid (log-odds + update stamps), its world<->map
+// transforms (HSL/map/GridMapBase.h:265-280) and the update counters of
+// OccGridMapBase (HSL/map/OccGridMapBase.h:264-266).  All planes live in HBM; the
+// host keeps only scalars.  There is no CPU compute path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gn_match.h"
+#include "hector_mi355/capi.h"
+#include "map_update.h"
+
+namespace {
+
+using namespace hsm;
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess)
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(buf, sizeof buf, "%s", what);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                         \
+  do {                                                        \
+    hipError_t e__ = (expr);                                  \
+    if (e__ != hipSuccess) return fail(HSM_ERR_HIP, #expr, e__); \
+  } while (0)
+
+struct Level {
+  int sx = 0, sy = 0;
+  float cell_length = 0.f, scale_to_map = 0.f;
+  float limx = 0.f, limy = 0.f;
+  Affine2 mapTworld{}, worldTmap{};
+  // device planes
+  float* d_logodds = nullptr;
+  int* d_update_index = nullptr;
+  float* d_prob = nullptr;
+  float4* d_quad = nullptr;
+  unsigned int* d_key_free = nullptr;
+  unsigned int* d_key_occ = nullptr;
+  // GridMapLogOddsFunctions (GridMapLogOdds.h:200-203)
+  float log_odds_free = 0.f, log_odds_occ = 0.f;
+  // OccGridMapBase counters / GridMapBase::lastUpdateIndex
+  int curr_update_index = 0, curr_mark_occ = -1, curr_mark_free = -1, last_update_index = -1;
+  unsigned int serial = 0;  // key-plane generation (map_update.h)
+  int bbox[4] = {0, 0, -1, -1};
+  size_t cells() const { return (size_t)sx * sy; }
+};
+
+}  // namespace
+
+struct hsm_ctx {
+  int device = 0;
+  int layout = kLayoutQuad;
+  int wps_override = 0;
+  std::vector<Level> levels;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  // single-scan staging (device) + pinned result
+  float2* d_scan = nullptr;
+  size_t d_scan_cap = 0;
+  float* d_small = nullptr;   // begin pose[3] | out pose[3] | out cov[9] | eval[12]
+  float* h_small = nullptr;   // pinned mirror of d_small
+  // retained scan = MapRepMultiMap::dataContainers (level-0 units; scaled by 2^-l on use)
+  std::vector<float> retained_pts;
+  float retained_origo[2] = {0.f, 0.f};
+  bool retained_valid = false;  // false until the first match (reference: empty containers)
+  float2* d_retained = nullptr;
+  size_t d_retained_cap = 0;
+  bool d_retained_current = false;
+  // batch staging for the host-pointer convenience entry
+  void* d_batch = nullptr;
+  size_t d_batch_cap = 0;
+  int last_cfg[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+float prob_to_log_odds(float prob) {  // GridMapLogOdds.h:196-200 (float log overload)
+  float odds = prob / (1.0f - prob);
+  return logf(odds);
+}
+
+// GridMapBase::setMapTransformation (GridMapBase.h:265-280) with Eigen's evaluation
+// order: mapTworld = Scaling(s,s) * Translation(off); worldTmap = mapTworld.inverse()
+void set_map_transformation(Level& L, float offx, float offy, float cell_length) {
+  L.cell_length = cell_length;
+  L.scale_to_map = 1.0f / cell_length;
+  const float s = L.scale_to_map;
+  Affine2 m;
+  m.l00 = s;
+  m.l10 = 0.0f;
+  m.l01 = 0.0f;
+  m.l11 = s;
+  m.t0 = s * offx;
+  m.t1 = s * offy;
+  L.mapTworld = m;
+  const float det = m.l00 * m.l11 - m.l10 * m.l01;
+  const float invdet = 1.0f / det;
+  Affine2 w;
+  w.l00 = m.l11 * invdet;
+  w.l10 = -m.l10 * invdet;
+  w.l01 = -m.l01 * invdet;
+  w.l11 = m.l00 * invdet;
+  w.t0 = (-w.l00) * m.t0 + (-w.l01) * m.t1;
+  w.t1 = (-w.l10) * m.t0 + (-w.l11) * m.t1;
+  L.worldTmap = w;
+}
+
+inline void affine_apply_host(const Affine2& a, float x, float y, float& ox, float& oy) {
+  ox = a.t0 + (a.l00 * x + a.l01 * y);
+  oy = a.t1 + (a.l10 * x + a.l11 * y);
+}
+
+LevelRW level_rw(const Level& L) {
+  LevelRW v;
+  v.logodds = L.d_logodds;
+  v.update_index = L.d_update_index;
+  v.prob = L.d_prob;
+  v.quad = L.d_quad;
+  v.key_free = L.d_key_free;
+  v.key_occ = L.d_key_occ;
+  v.sx = L.sx;
+  v.sy = L.sy;
+  return v;
+}
+
+LevelView level_view(const Level& L, float pt_scale, int gn_steps) {
+  LevelView v;
+  v.quad = L.d_quad;
+  v.prob = L.d_prob;
+  v.sx = L.sx;
+  v.sy = L.sy;
+  v.limx = L.limx;
+  v.limy = L.limy;
+  v.mapTworld = L.mapTworld;
+  v.worldTmap = L.worldTmap;
+  v.pt_scale = pt_scale;
+  v.gn_steps = gn_steps;
+  return v;
+}
+
+int grid_for(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;  // grid-stride the rest (guide, Guideline 11)
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int fill_level(hsm_ctx* h, Level& L) {  // GridMapBase::clear + LogOddsCell::resetGridCell
+  hipLaunchKernelGGL(fill_level_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L),
+                     0.0f, -1);
+  HIP_TRY(hipGetLastError());
+  return HSM_OK;
+}
+
+int rebuild_probability(hsm_ctx* h, Level& L) {
+  hipLaunchKernelGGL(rebuild_prob_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L));
+  hipLaunchKernelGGL(rebuild_quad_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L));
+  HIP_TRY(hipGetLastError());
+  return HSM_OK;
+}
+
+void free_level(Level& L) {
+  (void)hipFree(L.d_logodds);
+  (void)hipFree(L.d_update_index);
+  (void)hipFree(L.d_prob);
+  (void)hipFree(L.d_quad);
+  (void)hipFree(L.d_key_free);
+  (void)hipFree(L.d_key_occ);
+  L = Level();
+}
+
+int ensure_scan_capacity(float2*& buf, size_t& cap, size_t n) {
+  if (n <= cap) return HSM_OK;
+  if (buf) HIP_TRY(hipFree(buf));
+  buf = nullptr;
+  cap = 0;
+  size_t want = n < 4096 ? 4096 : n + n / 2;
+  HIP_TRY(hipMalloc((void**)&buf, want * sizeof(float2)));
+  cap = want;
+  return HSM_OK;
+}
+
+template <int WPS, int SPB>
+int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+  const int block = 64 * WPS * SPB;
+  const int grid = (P.batch + SPB - 1) / SPB;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
+  else
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = WPS;
+  h->last_cfg[2] = block;
+  h->last_cfg[3] = grid;
+  return HSM_OK;
+}
+
+// waves per scan: enough wavefronts to fill 256 CUs x 4 SIMDs x several waves, but never
+// more lanes than beams
+int choose_wps(const hsm_ctx* h, int batch, int max_n) {
+  if (h->wps_override > 0) return h->wps_override;
+  int wps = 1;
+  const long target_waves = 256L * 4 * 4;  // 4 waves per SIMD
+  while (wps < 16 && (long)batch * wps < target_waves && 64 * wps < max_n) wps *= 2;
+  return wps;
+}
+
+int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  switch (choose_wps(h, P.batch, max_n)) {
+    case 1: return launch_match_t<1, 4>(h, P, stream);
+    case 2: return launch_match_t<2, 1>(h, P, stream);
+    case 4: return launch_match_t<4, 1>(h, P, stream);
+    case 8: return launch_match_t<8, 1>(h, P, stream);
+    default: return launch_match_t<16, 1>(h, P, stream);
+  }
+}
+
+// the schedule of MapRepMultiMap::matchData (MapRepMultiMap.h:116-132): coarse levels
+// maxIterations = 3, level 0 maxIterations = 5, each plus the unconditional first step
+void fill_schedule(const hsm_ctx* h, MatchParams& P) {
+  const int nl = (int)h->levels.size();
+  for (int l = 0; l < nl; ++l) {
+    // static_cast<float>(1.0 / pow(2.0, level)) -- a power of two, exact in fp32
+    const float factor = (float)(1.0 / pow(2.0, (double)l));
+    P.lv[l] = level_view(h->levels[l], factor, l == 0 ? 6 : 4);
+  }
+  P.first_level = nl - 1;
+  P.last_level = 0;
+}
+
+int valid_level(const hsm_ctx* h, int level) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (level < 0 || level >= (int)h->levels.size()) return fail(HSM_ERR_INVALID, "level out of range");
+  return HSM_OK;
+}
+
+// OccGridMapBase::updateByScan on one level (OccGridMapBase.h:121-168).  pts are LEVEL-0
+// endpoints on the device; pt_scale/origo bring them to this level.  h_pts (host copy of
+// the same points) is only used for the touched bounding box.
+int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2* d_pts,
+                 const float* h_pts, int n, float pt_scale, const float origo_level[2]) {
+  Level& L = h->levels[level];
+  L.curr_mark_free = L.curr_update_index + 1;
+  L.curr_mark_occ = L.curr_update_index + 2;
+  float mx, my;
+  affine_apply_host(L.mapTworld, pose_world[0], pose_world[1], mx, my);  // getMapCoordsPose
+  const float mth = pose_world[2];
+  // Translation2f(mapPose.xy) * Rotation2Df(mapPose.theta): host float sin/cos like the reference
+  Affine2 T;
+  const float sinA = sinf(mth), cosA = cosf(mth);
+  T.l00 = cosA;
+  T.l01 = -sinA;
+  T.l10 = sinA;
+  T.l11 = cosA;
+  T.t0 = mx;
+  T.t1 = my;
+  float bx, by;
+  affine_apply_host(T, origo_level[0], origo_level[1], bx, by);
+  const int bxi = (int)(bx + 0.5f);
+  const int byi = (int)(by + 0.5f);
+  L.bbox[0] = L.bbox[1] = 0;
+  L.bbox[2] = L.bbox[3] = -1;
+  if (n > 0) {
+    if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than 65535 beams");
+    if (++L.serial > 0xFFFFu) {  // key generation wrapped: clear the key planes once
+      HIP_TRY(hipMemsetAsync(L.d_key_free, 0, L.cells() * sizeof(unsigned int), h->stream));
+      HIP_TRY(hipMemsetAsync(L.d_key_occ, 0, L.cells() * sizeof(unsigned int), h->stream));
+      L.serial = 1;
+    }
+    UpdateParams P;
+    P.lv = level_rw(L);
+    P.pose = T;
+    P.pts = d_pts;
+    P.n = n;
+    P.pt_scale = pt_scale;
+    P.bx = bxi;
+    P.by = byi;
+    P.serial = L.serial;
+    P.log_odds_free = L.log_odds_free;
+    P.log_odds_occ = L.log_odds_occ;
+    P.mark_free = L.curr_mark_free;
+    P.mark_occ = L.curr_mark_occ;
+    const int grid = (n + 3) / 4;  // 4 beams (wavefronts) per 256-thread workgroup
+    hipLaunchKernelGGL(update_mark_kernel, dim3(grid), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(update_apply_kernel, dim3(grid), dim3(256), 0, h->stream, P);
+    HIP_TRY(hipGetLastError());
+    // touched bounding box (host, same fp32 expressions as the kernels)
+    if (h_pts && bxi >= 0 && bxi < L.sx && byi >= 0 && byi < L.sy) {
+      int x0 = L.sx, y0 = L.sy, x1 = -1, y1 = -1;
+      for (int i = 0; i < n; ++i) {
+        float ex, ey;
+        affine_apply_host(T, h_pts[2 * i] * pt_scale, h_pts[2 * i + 1] * pt_scale, ex, ey);
+        ex += 0.5f;
+        ey += 0.5f;
+        if (!(ex > -2.0f && ex < (float)L.sx + 2.0f && ey > -2.0f && ey < (float)L.sy + 2.0f)) continue;
+        const int exi = (int)ex, eyi = (int)ey;
+        if (exi < 0 || exi >= L.sx || eyi < 0 || eyi >= L.sy) continue;
+        if (exi == bxi && eyi == byi) continue;
+        if (exi < x0) x0 = exi;
+        if (exi > x1) x1 = exi;
+        if (eyi < y0) y0 = eyi;
+        if (eyi > y1) y1 = eyi;
+      }
+      if (x1 >= 0) {
+        L.bbox[0] = x0 < bxi ? x0 : bxi;
+        L.bbox[1] = y0 < byi ? y0 : byi;
+        L.bbox[2] = x1 > bxi ? x1 : bxi;
+        L.bbox[3] = y1 > byi ? y1 : byi;
+      }
+    }
+  }
+  L.last_update_index++;     // setUpdated(), GridMapBase.h:343
+  L.curr_update_index += 3;  // OccGridMapBase.h:167
+  return HSM_OK;
+}
+
+int select_device(const hsm_ctx* h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return HSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hsm_last_error(void) { return g_last_error.c_str(); }
+const char* hsm_version(void) { return "hector_mi355 0.1 (gfx950)"; }
+
+int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
+               const hsm_opts* opts, hsm_ctx** out) {
+  if (!out) return fail(HSM_ERR_INVALID, "hsm_create: out is null");
+  *out = nullptr;
+  if (levels < 1 || levels > HSM_MAX_LEVELS || size_x < 2 || size_y < 2 || !(map_resolution > 0.0f))
+    return fail(HSM_ERR_INVALID, "hsm_create: bad map geometry");
+  if ((size_x >> (levels - 1)) < 2 || (size_y >> (levels - 1)) < 2)
+    return fail(HSM_ERR_INVALID, "hsm_create: too many levels for this map size");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(HSM_ERR_NO_DEVICE, "hsm_create: no HIP device (this library has no CPU path)", e);
+  hsm_ctx* h = new hsm_ctx();
+  if (opts && opts->device >= 0) {
+    h->device = opts->device;
+  } else {
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  }
+  if (h->device >= ndev) {
+    delete h;
+    return fail(HSM_ERR_INVALID, "hsm_create: device ordinal out of range");
+  }
+  int layout = opts ? opts->layout : HSM_LAYOUT_AUTO;
+  if (layout == HSM_LAYOUT_AUTO) {
+    const char* env = getenv("HSM_LAYOUT");
+    layout = (env && strcmp(env, "plane") == 0) ? HSM_LAYOUT_PLANE : HSM_LAYOUT_QUAD;
+  }
+  h->layout = layout == HSM_LAYOUT_PLANE ? kLayoutPlane : kLayoutQuad;
+  int wps = opts ? opts->waves_per_scan : 0;
+  if (wps == 0) {
+    const char* env = getenv("HSM_WPS");
+    if (env) wps = atoi(env);
+  }
+  if (wps != 0 && wps != 1 && wps != 2 && wps != 4 && wps != 8 && wps != 16) {
+    delete h;
+    return fail(HSM_ERR_INVALID, "hsm_create: waves_per_scan must be 0,1,2,4,8,16");
+  }
+  h->wps_override = wps;
+
+#define CREATE_TRY(expr)                                   \
+  do {                                                     \
+    hipError_t e__ = (expr);                               \
+    if (e__ != hipSuccess) {                               \
+      int rc__ = fail(HSM_ERR_HIP, #expr, e__);            \
+      hsm_destroy(h);                                      \
+      return rc__;                                         \
+    }                                                      \
+  } while (0)
+
+  CREATE_TRY(hipSetDevice(h->device));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc((void**)&h->d_small, 64 * sizeof(float)));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_small, 64 * sizeof(float), hipHostMallocDefault));
+
+  // MapRepMultiMap ctor (MapRepMultiMap.h:48-72)
+  int rx = size_x, ry = size_y;
+  const float total_x = map_resolution * (float)size_x;
+  const float mid_offset_x = total_x * start_x;
+  const float total_y = map_resolution * (float)size_y;
+  const float mid_offset_y = total_y * start_y;
+  h->levels.resize(levels);
+  for (unsigned i = 0; i < levels; ++i) {
+    Level& L = h->levels[i];
+    L.sx = rx;
+    L.sy = ry;
+    L.limx = (float)rx - 2.0f;  // MapDimensionProperties::setMapCellDims (:70-74)
+    L.limy = (float)ry - 2.0f;
+    set_map_transformation(L, mid_offset_x, mid_offset_y, map_resolution);
+    L.log_odds_free = prob_to_log_odds(0.4f);  // GridMapLogOdds.h:117-118
+    L.log_odds_occ = prob_to_log_odds(0.6f);
+    const size_t n = L.cells();
+    CREATE_TRY(hipMalloc((void**)&L.d_logodds, n * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&L.d_update_index, n * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&L.d_prob, n * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&L.d_quad, n * sizeof(float4)));
+    CREATE_TRY(hipMalloc((void**)&L.d_key_free, n * sizeof(unsigned int)));
+    CREATE_TRY(hipMalloc((void**)&L.d_key_occ, n * sizeof(unsigned int)));
+    CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, n * sizeof(unsigned int), h->stream));
+    CREATE_TRY(hipMemsetAsync(L.d_key_occ, 0, n * sizeof(unsigned int), h->stream));
+    if (fill_level(h, L) != HSM_OK) {
+      hsm_destroy(h);
+      return HSM_ERR_HIP;
+    }
+    rx /= 2;
+    ry /= 2;
+    map_resolution *= 2.0f;
+  }
+  CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+  *out = h;
+  return HSM_OK;
+}
+
+void hsm_destroy(hsm_ctx* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (Level& L : h->levels) free_level(L);
+  (void)hipFree(h->d_scan);
+  (void)hipFree(h->d_retained);
+  (void)hipFree(h->d_small);
+  (void)hipFree(h->d_batch);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int hsm_reset(hsm_ctx* h) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  for (Level& L : h->levels)
+    if (int rc = fill_level(h, L)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_levels(const hsm_ctx* h) { return h ? (int)h->levels.size() : 0; }
+float hsm_scale_to_map(const hsm_ctx* h) { return h ? h->levels[0].scale_to_map : 0.0f; }
+
+int hsm_set_update_factor_free(hsm_ctx* h, float f) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  for (Level& L : h->levels) L.log_odds_free = prob_to_log_odds(f);
+  return HSM_OK;
+}
+int hsm_set_update_factor_occupied(hsm_ctx* h, float f) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  for (Level& L : h->levels) L.log_odds_occ = prob_to_log_odds(f);
+  return HSM_OK;
+}
+int hsm_on_map_updated(hsm_ctx* h) { return h ? HSM_OK : fail(HSM_ERR_INVALID, "null context"); }
+
+int hsm_gn_iterations_per_match(const hsm_ctx* h) {
+  return h ? 6 + 4 * ((int)h->levels.size() - 1) : 0;
+}
+int hsm_last_launch_config(const hsm_ctx* h, int cfg[4]) {
+  if (!h || !cfg) return fail(HSM_ERR_INVALID, "null argument");
+  for (int i = 0; i < 4; ++i) cfg[i] = h->last_cfg[i];
+  return HSM_OK;
+}
+
+static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
+                                     const int* d_scan_offsets, int shared_n, float* d_out_pose,
+                                     float* d_out_cov, void* stream) {
+  if (batch < 0 || !d_begin_world || !d_out_pose || (!d_scan_offsets && shared_n < 0))
+    return fail(HSM_ERR_INVALID, "hsm_match_batch_device: bad argument");
+  if (batch == 0) return HSM_OK;
+  if (int rc = select_device(h)) return rc;
+  MatchParams P;
+  memset(&P, 0, sizeof P);
+  fill_schedule(h, P);
+  P.batch = batch;
+  P.begin_world = d_begin_world;
+  P.pts = reinterpret_cast<const float2*>(d_pts_xy);
+  P.offsets = d_scan_offsets;
+  P.shared_n = shared_n;
+  P.out_pose = d_out_pose;
+  P.out_cov = d_out_cov;
+  // per-scan length is only known on the device for CSR input; shared_n doubles as the
+  // sizing hint there (callers pass the typical beams per scan, 0 = unknown)
+  const int hint = shared_n > 0 ? shared_n : 1081;
+  return launch_match(h, P, hint, (hipStream_t)stream);
+}
+
+int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
+                           const int* d_scan_offsets, int shared_n, float* d_out_pose, float* d_out_cov,
+                           void* stream) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  return match_batch_device_nolock(h, batch, d_begin_world, d_pts_xy, d_scan_offsets, shared_n, d_out_pose,
+                                   d_out_cov, stream);
+}
+
+int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float* pts_xy,
+                    const int* scan_offsets, int shared_n, float* out_pose, float* out_cov) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (batch < 0 || !begin_world || !out_pose) return fail(HSM_ERR_INVALID, "hsm_match_batch: bad argument");
+  if (batch == 0) return HSM_OK;
+  const size_t total = scan_offsets ? (size_t)scan_offsets[batch] : (size_t)(shared_n > 0 ? shared_n : 0);
+  if (total > 0 && !pts_xy) return fail(HSM_ERR_INVALID, "hsm_match_batch: pts_xy is null");
+  const size_t b_begin = (size_t)batch * 3 * sizeof(float);
+  const size_t b_pts = total * 2 * sizeof(float);
+  const size_t b_offs = scan_offsets ? ((size_t)batch + 1) * sizeof(int) : 0;
+  const size_t b_pose = b_begin, b_cov = (size_t)batch * 9 * sizeof(float);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t need = al(b_begin) + al(b_pts) + al(b_offs) + al(b_pose) + al(b_cov);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (need > h->d_batch_cap) {
+    if (h->d_batch) HIP_TRY(hipFree(h->d_batch));
+    h->d_batch = nullptr;
+    h->d_batch_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_batch, need));
+    h->d_batch_cap = need;
+  }
+  char* base = (char*)h->d_batch;
+  float* d_begin = (float*)base;
+  float* d_pts = (float*)(base + al(b_begin));
+  int* d_offs = scan_offsets ? (int*)(base + al(b_begin) + al(b_pts)) : nullptr;
+  float* d_pose = (float*)(base + al(b_begin) + al(b_pts) + al(b_offs));
+  float* d_cov = (float*)(base + al(b_begin) + al(b_pts) + al(b_offs) + al(b_pose));
+  HIP_TRY(hipMemcpyAsync(d_begin, begin_world, b_begin, hipMemcpyHostToDevice, h->stream));
+  if (b_pts) HIP_TRY(hipMemcpyAsync(d_pts, pts_xy, b_pts, hipMemcpyHostToDevice, h->stream));
+  if (d_offs) HIP_TRY(hipMemcpyAsync(d_offs, scan_offsets, b_offs, hipMemcpyHostToDevice, h->stream));
+  if (out_cov) HIP_TRY(hipMemcpyAsync(d_cov, out_cov, b_cov, hipMemcpyHostToDevice, h->stream));  // in/out
+  int hint = shared_n;
+  if (scan_offsets) {
+    hint = 0;
+    for (int i = 0; i < batch; ++i) {
+      const int ni = scan_offsets[i + 1] - scan_offsets[i];
+      if (ni > hint) hint = ni;
+    }
+  }
+  if (int rc = match_batch_device_nolock(h, batch, d_begin, d_pts, d_offs, hint, d_pose,
+                                         out_cov ? d_cov : nullptr, h->stream))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out_pose, d_pose, b_pose, hipMemcpyDeviceToHost, h->stream));
+  if (out_cov) HIP_TRY(hipMemcpyAsync(out_cov, d_cov, b_cov, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+// one scan on the first..last levels; pts are host, level-0 units (pt_scale applied per level)
+static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], const float2* d_pts, int n,
+                        float out_pose_world[3], float cov[9]) {
+  float* hs = h->h_small;
+  hs[0] = begin_world[0];
+  hs[1] = begin_world[1];
+  hs[2] = begin_world[2];
+  HIP_TRY(hipMemcpyAsync(h->d_small, hs, 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  P.batch = 1;
+  P.begin_world = h->d_small;
+  P.pts = d_pts;
+  P.offsets = nullptr;
+  P.shared_n = n;
+  P.out_pose = h->d_small + 3;
+  P.out_cov = h->d_small + 6;
+  if (int rc = launch_match(h, P, n, h->stream)) return rc;
+  HIP_TRY(hipMemcpyAsync(hs + 3, h->d_small + 3, 12 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  out_pose_world[0] = hs[3];
+  out_pose_world[1] = hs[4];
+  out_pose_world[2] = hs[5];
+  if (n != 0 && cov)
+    for (int i = 0; i < 9; ++i) cov[i] = hs[6 + i];
+  return HSM_OK;
+}
+
+int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
+              float out_pose_world[3], float cov[9]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (!begin_world || !out_pose_world || n < 0 || (n > 0 && !pts_xy))
+    return fail(HSM_ERR_INVALID, "hsm_match: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  // DataContainer::setFrom keeps scaled copies for the coarse levels (MapRepMultiMap.h:127);
+  // here: one level-0 copy, scaled by 2^-level on use
+  if (h->levels.size() > 1) {
+    h->retained_pts.assign(pts_xy, pts_xy + 2 * (size_t)n);
+    h->retained_origo[0] = origo ? origo[0] : 0.0f;
+    h->retained_origo[1] = origo ? origo[1] : 0.0f;
+    h->retained_valid = true;
+  }
+  if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)n)) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->d_retained, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  h->d_retained_current = h->levels.size() > 1;
+  MatchParams P;
+  memset(&P, 0, sizeof P);
+  fill_schedule(h, P);
+  return match_single(h, P, begin_world, h->d_retained, n, out_pose_world, cov);
+}
+
+int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy, int n,
+                    int max_iterations, float out_pose_world[3], float cov[9]) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!begin_world || !out_pose_world || n < 0 || max_iterations < 0 || (n > 0 && !pts_level_xy))
+    return fail(HSM_ERR_INVALID, "hsm_match_level: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->d_scan, pts_level_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  MatchParams P;
+  memset(&P, 0, sizeof P);
+  P.lv[level] = level_view(h->levels[level], 1.0f, 1 + max_iterations);
+  P.first_level = level;
+  P.last_level = level;
+  return match_single(h, P, begin_world, h->d_scan, n, out_pose_world, cov);
+}
+
+int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (!pose_world || n < 0 || (n > 0 && !pts_xy)) return fail(HSM_ERR_INVALID, "hsm_update_by_scan: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  const float zero[2] = {0.0f, 0.0f};
+  const float* o = origo ? origo : zero;
+  // level 0: the caller's container
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (int rc = update_level(h, 0, pose_world, h->d_scan, pts_xy, n, 1.0f, o)) return rc;
+  // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
+  const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
+  if (h->levels.size() > 1) {
+    if (rn > 0 && !h->d_retained_current) {
+      if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)rn)) return rc;
+      HIP_TRY(hipMemcpyAsync(h->d_retained, h->retained_pts.data(), (size_t)rn * sizeof(float2),
+                             hipMemcpyHostToDevice, h->stream));
+      h->d_retained_current = true;
+    }
+    for (size_t l = 1; l < h->levels.size(); ++l) {
+      const float factor = (float)(1.0 / pow(2.0, (double)l));
+      const float ol[2] = {h->retained_origo[0] * factor, h->retained_origo[1] * factor};  // setFrom :48
+      if (int rc = update_level(h, (int)l, pose_world, h->d_retained, h->retained_pts.data(), rn, factor, ol))
+        return rc;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], const float* pts_level_xy, int n,
+                             const float origo_level[2]) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!pose_world || n < 0 || (n > 0 && !pts_level_xy))
+    return fail(HSM_ERR_INVALID, "hsm_update_by_scan_level: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  const float zero[2] = {0.0f, 0.0f};
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->d_scan, pts_level_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (int rc = update_level(h, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
+                            origo_level ? origo_level : zero))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_level_info(const hsm_ctx* h, int level, int* sx, int* sy, float* cell, float* scale) {
+  if (int rc = valid_level(h, level)) return rc;
+  const Level& L = h->levels[level];
+  if (sx) *sx = L.sx;
+  if (sy) *sy = L.sy;
+  if (cell) *cell = L.cell_length;
+  if (scale) *scale = L.scale_to_map;
+  return HSM_OK;
+}
+int hsm_map_coords_pose(const hsm_ctx* h, int level, const float w[3], float m[3]) {
+  if (int rc = valid_level(h, level)) return rc;
+  affine_apply_host(h->levels[level].mapTworld, w[0], w[1], m[0], m[1]);
+  m[2] = w[2];
+  return HSM_OK;
+}
+int hsm_world_coords_pose(const hsm_ctx* h, int level, const float m[3], float w[3]) {
+  if (int rc = valid_level(h, level)) return rc;
+  affine_apply_host(h->levels[level].worldTmap, m[0], m[1], w[0], w[1]);
+  w[2] = m[2];
+  return HSM_OK;
+}
+int hsm_update_index(const hsm_ctx* h, int level) {
+  if (valid_level(h, level)) return -1;
+  return h->levels[level].last_update_index;
+}
+
+int hsm_download_level(hsm_ctx* h, int level, float* logodds, int* update_index) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (logodds) HIP_TRY(hipMemcpy(logodds, L.d_logodds, L.cells() * sizeof(float), hipMemcpyDeviceToHost));
+  if (update_index)
+    HIP_TRY(hipMemcpy(update_index, L.d_update_index, L.cells() * sizeof(int), hipMemcpyDeviceToHost));
+  return HSM_OK;
+}
+int hsm_upload_level(hsm_ctx* h, int level, const float* logodds, const int* update_index) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (logodds) HIP_TRY(hipMemcpy(L.d_logodds, logodds, L.cells() * sizeof(float), hipMemcpyHostToDevice));
+  if (update_index)
+    HIP_TRY(hipMemcpy(L.d_update_index, update_index, L.cells() * sizeof(int), hipMemcpyHostToDevice));
+  if (int rc = rebuild_probability(h, L)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+int hsm_download_rows(hsm_ctx* h, int level, int y0, int y1, float* rows) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  if (y0 < 0 || y1 > L.sy || y0 > y1 || !rows) return fail(HSM_ERR_INVALID, "hsm_download_rows: bad row range");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (y1 > y0)
+    HIP_TRY(hipMemcpy(rows, L.d_logodds + (size_t)y0 * L.sx, (size_t)(y1 - y0) * L.sx * sizeof(float),
+                      hipMemcpyDeviceToHost));
+  return HSM_OK;
+}
+int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]) {
+  if (int rc = valid_level(h, level)) return rc;
+  for (int i = 0; i < 4; ++i) bbox[i] = h->levels[level].bbox[i];
+  return HSM_OK;
+}
+int hsm_download_prob(hsm_ctx* h, int level, float* prob) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(prob, L.d_prob, L.cells() * sizeof(float), hipMemcpyDeviceToHost));
+  return HSM_OK;
+}
+
+int hsm_hessian_derivs(hsm_ctx* h, int level, const float pose_map[3], const float* pts, int n, float H[9],
+                       float dTr[3]) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!pose_map || n < 0 || (n > 0 && !pts) || !H || !dTr) return fail(HSM_ERR_INVALID, "bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  const LevelView v = level_view(h->levels[level], 1.0f, 1);
+  float* d_out = h->d_small + 16;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_eval_kernel<kLayoutPlane>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
+                       pose_map[0], pose_map[1], pose_map[2], d_out);
+  else
+    hipLaunchKernelGGL((gn_eval_kernel<kLayoutQuad>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
+                       pose_map[0], pose_map[1], pose_map[2], d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->h_small + 16, d_out, 12 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 9; ++i) H[i] = h->h_small[16 + i];
+  for (int i = 0; i < 3; ++i) dTr[i] = h->h_small[25 + i];
+  return HSM_OK;
+}
+
+int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* pts, int n, float* out4) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!pose_map || n < 0 || (n > 0 && (!pts || !out4))) return fail(HSM_ERR_INVALID, "bad argument");
+  if (n == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n * 3)) return rc;  // pts + float4 out
+  HIP_TRY(hipMemcpyAsync(h->d_scan, pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  float4* d_out = reinterpret_cast<float4*>(h->d_scan + (((size_t)n + 1) & ~(size_t)1));
+  const LevelView v = level_view(h->levels[level], 1.0f, 1);
+  const int grid = (n + 255) / 256;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_beam_terms_kernel<kLayoutPlane>), dim3(grid), dim3(256), 0, h->stream, v, h->d_scan, n,
+                       pose_map[0], pose_map[1], pose_map[2], d_out);
+  else
+    hipLaunchKernelGGL((gn_beam_terms_kernel<kLayoutQuad>), dim3(grid), dim3(256), 0, h->stream, v, h->d_scan, n,
+                       pose_map[0], pose_map[1], pose_map[2], d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+}  // extern "C"

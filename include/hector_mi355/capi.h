@@ -1,0 +1,158 @@
+/* hector_mi355 -- C ABI of the MI355X-native scan-to-map Gauss-Newton matcher.
+ *
+ * This is the drop-in boundary for hector_mapping's L1 map representation
+ * (SURVEY.md section 8(b)).  Every entry point names the reference interface it
+ * replaces; paths are relative to
+ *   /root/reference/hector_mapping/include/hector_slam_lib/        (HSL/)
+ * The header facade include/hector_slam_lib/slam_main/MapRepMultiMap.h forwards
+ * the reference's C++ virtuals to these functions.
+ *
+ * Conventions (identical to the reference):
+ *   poses   float[3] = x, y, theta; world frame = metres / rad
+ *   scans   a DataContainer (HSL/scan/DataPointContainer.h:36-96) is the triple
+ *           (pts, n, origo): n endpoints as AoS float[2*n] in the robot frame,
+ *           already multiplied by the level-0 scaleToMap (cell units), plus the
+ *           laser origin `origo` in the same units
+ *   cov/H   float[9], column-major 3x3 (Eigen::Matrix3f default layout)
+ *   planes  row-major, index = y*sizeX + x (HSL/map/GridMapBase.h:141-144)
+ *
+ * Return value: 0 = HSM_OK, negative = error (hsm_last_error() has the text).
+ * The reference itself has no error channel (SURVEY.md 8(b) "error conventions");
+ * the facade ignores the status to stay behaviour-compatible.
+ *
+ * All compute runs on the GPU.  There is NO CPU fallback: without a HIP device
+ * hsm_create fails with HSM_ERR_NO_DEVICE.
+ */
+#ifndef HECTOR_MI355_CAPI_H
+#define HECTOR_MI355_CAPI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hsm_ctx hsm_ctx;
+
+enum {
+  HSM_OK = 0,
+  HSM_ERR_INVALID = -1,    /* bad argument */
+  HSM_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at init */
+  HSM_ERR_HIP = -3,        /* HIP runtime error (text in hsm_last_error) */
+  HSM_ERR_TOO_LARGE = -4   /* scan longer than HSM_MAX_UPDATE_BEAMS in update_by_scan */
+};
+
+#define HSM_MAX_LEVELS 8
+#define HSM_MAX_UPDATE_BEAMS 65535
+
+/* probability sampling layout used by the GN kernel (DESIGN.md "data layout") */
+enum { HSM_LAYOUT_AUTO = 0, HSM_LAYOUT_QUAD = 1, HSM_LAYOUT_PLANE = 2 };
+
+typedef struct hsm_opts {
+  int device;          /* HIP device ordinal; -1 = current device */
+  int layout;          /* HSM_LAYOUT_*; AUTO honours env HSM_LAYOUT=quad|plane, default quad */
+  int waves_per_scan;  /* 0 = auto (env HSM_WPS overrides), else 1,2,4,8,16 */
+} hsm_opts;
+
+/* ---- construction ---------------------------------------------------------
+ * replaces: MapRepMultiMap::MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, numDepth,
+ *           startCoords, draw, debug)                    HSL/slam_main/MapRepMultiMap.h:48-72
+ * Level l has size (sx>>l, sy>>l) and cell length res*2^l; all levels share the
+ * offset (res*sx*start_x, res*sy*start_y).  Update factors start at the library
+ * defaults 0.4 / 0.6 (HSL/map/GridMapLogOdds.h:117-118). */
+int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x,
+               float start_y, const hsm_opts* opts /* may be NULL */, hsm_ctx** out);
+/* replaces: MapRepMultiMap::~MapRepMultiMap                   MapRepMultiMap.h:74-81 */
+void hsm_destroy(hsm_ctx* h);
+
+/* replaces: MapRepMultiMap::reset -> MapProcContainer::reset  MapRepMultiMap.h:83-90, MapProcContainer.h:67-71 */
+int hsm_reset(hsm_ctx* h);
+/* replaces: getMapLevels / getScaleToMap                      MapRepMultiMap.h:92-94 */
+int hsm_levels(const hsm_ctx* h);
+float hsm_scale_to_map(const hsm_ctx* h);
+/* replaces: setUpdateFactorFree / setUpdateFactorOccupied     MapRepMultiMap.h:149-167 */
+int hsm_set_update_factor_free(hsm_ctx* h, float free_factor);
+int hsm_set_update_factor_occupied(hsm_ctx* h, float occupied_factor);
+/* replaces: onMapUpdated (cache generation bump)              MapRepMultiMap.h:107-114.
+ * The device probability texels are refreshed eagerly by update_by_scan, so this
+ * only has to exist; it returns HSM_OK. */
+int hsm_on_map_updated(hsm_ctx* h);
+
+/* ---- the hot path -----------------------------------------------------------
+ * replaces: MapRepMultiMap::matchData(beginEstimateWorld, dataContainer, covMatrix)
+ *           HSL/slam_main/MapRepMultiMap.h:116-132  (-> ScanMatcher::matchData,
+ *           HSL/matcher/ScanMatcher.h:54-190, 4 GN steps per coarse level, 6 on level 0).
+ * Host pointers.  n == 0: out_pose = begin, cov untouched (ScanMatcher.h:68,189).
+ * Like the reference it retains the scan for the coarse levels of the next
+ * hsm_update_by_scan (MapRepMultiMap.h:127,143). */
+int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n,
+              const float origo[2], float out_pose_world[3], float cov[9]);
+
+/* Batched extension (not in the reference): B independent (pose hypothesis, scan)
+ * pairs against the read-only pyramid in ONE launch.  DEVICE pointers:
+ *   d_begin_world  [B*3]       d_pts_xy [total*2]
+ *   d_scan_offsets [B+1] CSR offsets into d_pts_xy in points, or NULL = every
+ *                  hypothesis uses the same scan d_pts_xy[0 .. shared_n)
+ *   d_out_pose     [B*3]       d_out_cov [B*9] or NULL
+ * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous.
+ * Does not touch the retained-scan state. */
+int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world,
+                           const float* d_pts_xy, const int* d_scan_offsets, int shared_n,
+                           float* d_out_pose, float* d_out_cov, void* stream);
+/* same with host pointers (copies in, runs, copies out, synchronous) */
+int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float* pts_xy,
+                    const int* scan_offsets, int shared_n, float* out_pose, float* out_cov);
+
+/* replaces: MapRepMultiMap::updateByScan(dataContainer, robotPoseWorld)
+ *           HSL/slam_main/MapRepMultiMap.h:134-147 -> OccGridMapBase::updateByScan,
+ *           HSL/map/OccGridMapBase.h:121-260.  Level 0 uses (pts, n, origo); coarse
+ *           levels use the scan retained by the last hsm_match, scaled by 2^-level,
+ *           exactly as the reference does. */
+int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n,
+                       const float origo[2]);
+/* one level, explicit level-scaled container (OccGridMapBase::updateByScan itself) */
+int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
+                             const float* pts_level_xy, int n, const float origo_level[2]);
+
+/* ---- host mirror support: replaces getGridMap(level) cell access --------------
+ * HSL/slam_main/MapRepMultiMap.h:95, HSL/map/GridMapBase.h:141-159 */
+int hsm_level_info(const hsm_ctx* h, int level, int* size_x, int* size_y, float* cell_length,
+                   float* scale_to_map);
+/* GridMapBase::getMapCoordsPose / getWorldCoordsPose         GridMapBase.h:226-239 */
+int hsm_map_coords_pose(const hsm_ctx* h, int level, const float world[3], float map[3]);
+int hsm_world_coords_pose(const hsm_ctx* h, int level, const float map[3], float world[3]);
+/* GridMapBase::getUpdateIndex (bumped by every update, GridMapBase.h:343-344) */
+int hsm_update_index(const hsm_ctx* h, int level);
+/* whole level; either pointer may be NULL */
+int hsm_download_level(hsm_ctx* h, int level, float* logodds, int* update_index);
+int hsm_upload_level(hsm_ctx* h, int level, const float* logodds, const int* update_index);
+/* rows [y0, y1) of the log-odds plane only (cheap mirror refresh after an update) */
+int hsm_download_rows(hsm_ctx* h, int level, int y0, int y1, float* logodds_rows);
+/* cell bounding box {x0, y0, x1, y1} (inclusive) touched by the last update of `level`;
+ * x1 < x0 when nothing was touched */
+int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]);
+
+/* ---- parity / debug entry points (used by tests, not by the facade) ------------ */
+/* device probability plane p = e^l/(e^l+1) (GridMapLogOdds.h:163-166) */
+int hsm_download_prob(hsm_ctx* h, int level, float* prob);
+/* one evaluation of OccGridMapUtil::getCompleteHessianDerivs (OccGridMapUtil.h:64-104)
+ * at a MAP-frame pose with level-scaled points */
+int hsm_hessian_derivs(hsm_ctx* h, int level, const float pose_map[3], const float* pts_level_xy,
+                       int n, float H[9], float dTr[3]);
+/* per-beam terms of the same evaluation: out[4*i] = M, dM/dx, dM/dy, rotDeriv */
+int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* pts_level_xy,
+                   int n, float* out4);
+/* ScanMatcher::matchData on one level with explicit max_iterations (ScanMatcher.h:54) */
+int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy,
+                    int n, int max_iterations, float out_pose_world[3], float cov[9]);
+
+/* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
+int hsm_gn_iterations_per_match(const hsm_ctx* h);
+/* effective kernel configuration of the last match launch: {layout, waves_per_scan, block, grid} */
+int hsm_last_launch_config(const hsm_ctx* h, int cfg[4]);
+
+const char* hsm_last_error(void);
+const char* hsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HECTOR_MI355_CAPI_H */

@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def bits(a):
+    """uint32 view for bit-exact float comparisons."""
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def ang_diff(a, b):
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def small_scene():
+    """config-1 shaped: 181 beams, 256x256 single-resolution map, 20 m x 15 m room."""
+    from hector_slam_amd import synth
+    return synth.make_scene(n_beams=181, map_size=256, levels=1, resolution=0.1, n_build=60, n_query=12,
+                            room=(20.0, 15.0), seed=4321, range_max=30.0)
+
+
+@pytest.fixture(scope="session")
+def pyramid_scene():
+    """config-2 shaped but smaller: 1081 beams, 3-level 512/256/128 pyramid, 20 m x 15 m room."""
+    from hector_slam_amd import synth
+    return synth.make_scene(n_beams=1081, map_size=512, levels=3, resolution=0.05, n_build=80, n_query=16,
+                            room=(20.0, 15.0), seed=99)
+
+
+def make_oracle(pyoracle, kind, scene, free=0.4, occ=0.9, build=True):
+    o = pyoracle.Oracle(kind, scene.resolution, scene.map_size, scene.map_size, scene.levels)
+    o.set_update_factor_free(free)
+    o.set_update_factor_occupied(occ)
+    if build:
+        o.build_map(scene.build_poses, scene.build_scans)
+    return o

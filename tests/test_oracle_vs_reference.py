@@ -1,0 +1,149 @@
+"""Pin the plain-C++ restatement (oracle/hector_oracle.cpp, "ho") against the reference's own
+code (oracle/_ref/libhector_ref.so, "hr" = unmodified hector_slam_lib headers compiled through
+the private Eigen/tf stand-in).  Every comparison is BIT-EXACT (integer/index work and fp32)."""
+import numpy as np
+import pytest
+
+from conftest import bits, make_oracle
+
+pytestmark = pytest.mark.skipif(False, reason="")
+
+
+@pytest.fixture(scope="module")
+def pair(oracle_mod, pyramid_scene):
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref/libhector_ref.so not built (needs /root/reference)")
+    ho = make_oracle(oracle_mod, "ho", pyramid_scene)
+    hr = make_oracle(oracle_mod, "hr", pyramid_scene)
+    return ho, hr
+
+
+def test_level_geometry_and_transforms(pair, pyramid_scene):
+    ho, hr = pair
+    rng = np.random.default_rng(5)
+    for lvl in range(pyramid_scene.levels):
+        assert ho.level_info(lvl) == hr.level_info(lvl)
+        for _ in range(50):
+            w = rng.uniform(-12, 12, 3).astype(np.float32)
+            m_o, m_r = ho.map_coords_pose(lvl, w), hr.map_coords_pose(lvl, w)
+            assert np.array_equal(bits(m_o), bits(m_r))
+            assert np.array_equal(bits(ho.world_coords_pose(lvl, m_o)), bits(hr.world_coords_pose(lvl, m_r)))
+
+
+def test_map_built_by_update_by_scan_is_identical(pair, pyramid_scene):
+    ho, hr = pair
+    for lvl in range(pyramid_scene.levels):
+        lo_o, ui_o = ho.download_level(lvl)
+        lo_r, ui_r = hr.download_level(lvl)
+        assert np.array_equal(bits(lo_o), bits(lo_r))
+        assert np.array_equal(ui_o, ui_r)
+        assert (lo_o > 0).sum() > 100 and (lo_o < 0).sum() > 1000  # the map is not trivial
+
+
+def test_interp_with_derivatives(pair, pyramid_scene):
+    ho, hr = pair
+    rng = np.random.default_rng(6)
+    for lvl in range(pyramid_scene.levels):
+        s = pyramid_scene.map_size >> lvl
+        c = rng.uniform(-3, s + 3, size=(4000, 2)).astype(np.float32)
+        c[:8] = [[0, 0], [s - 2, s - 2], [s - 2, 0], [0, s - 2], [s - 1.999, 5], [-0.0, 3], [5, s - 2.0001], [s - 1, s - 1]]
+        assert np.array_equal(bits(ho.interp(lvl, c)), bits(hr.interp(lvl, c)))
+
+
+def test_hessian_derivs_and_match_level(pair, pyramid_scene):
+    ho, hr = pair
+    sc = pyramid_scene
+    for q in range(6):
+        for lvl in range(sc.levels):
+            pts = sc.query_scans[q] * np.float32(1.0 / 2 ** lvl)
+            pm = ho.map_coords_pose(lvl, sc.query_init[q])
+            H_o, d_o = ho.hessian_derivs(lvl, pm, pts)
+            H_r, d_r = hr.hessian_derivs(lvl, pm, pts)
+            assert np.array_equal(bits(H_o), bits(H_r)) and np.array_equal(bits(d_o), bits(d_r))
+            for it in (0, 3, 5):
+                p_o, c_o = ho.match_level(lvl, sc.query_init[q], pts, it)
+                p_r, c_r = hr.match_level(lvl, sc.query_init[q], pts, it)
+                assert np.array_equal(bits(p_o), bits(p_r)) and np.array_equal(bits(c_o), bits(c_r))
+
+
+def test_full_match_and_empty_scan(pair, pyramid_scene):
+    ho, hr = pair
+    sc = pyramid_scene
+    for q in range(len(sc.query_scans)):
+        p_o, c_o = ho.match(sc.query_init[q], sc.query_scans[q])
+        p_r, c_r = hr.match(sc.query_init[q], sc.query_scans[q])
+        assert np.array_equal(bits(p_o), bits(p_r)) and np.array_equal(bits(c_o), bits(c_r))
+    cov_in = np.arange(9, dtype=np.float32)
+    empty = np.zeros((0, 2), np.float32)
+    for o in (ho, hr):  # ScanMatcher.h:68,189: pose passes through, cov untouched
+        p, c = o.match(sc.query_init[0], empty, cov=cov_in)
+        assert np.array_equal(bits(p), bits(sc.query_init[0])) and np.array_equal(c, cov_in)
+
+
+def test_clamp_and_far_start(pair, pyramid_scene):
+    """large initial errors: exercises the +-0.2 rad clamp and partially out-of-map scans"""
+    ho, hr = pair
+    sc = pyramid_scene
+    rng = np.random.default_rng(7)
+    for q in range(8):
+        init = sc.query_truth[q] + np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.8, 0.8)], np.float32)
+        p_o, c_o = ho.match(init, sc.query_scans[q])
+        p_r, c_r = hr.match(init, sc.query_scans[q])
+        assert np.array_equal(bits(p_o), bits(p_r)) and np.array_equal(bits(c_o), bits(c_r))
+    far = np.array([11.5, 9.0, 0.3], np.float32)  # near the map border: most beams out of bounds
+    assert np.array_equal(bits(ho.match(far, sc.query_scans[0])[0]), bits(hr.match(far, sc.query_scans[0])[0]))
+
+
+def test_processor_trajectory_from_empty_map(oracle_mod, pyramid_scene):
+    """a12: match -> threshold -> updateByScan -> onMapUpdated, incl. first-scan and stale-coarse quirks"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("no reference build")
+    sc = pyramid_scene
+    o = [make_oracle(oracle_mod, k, sc, build=False) for k in ("ho", "hr")]
+    for x in o:
+        x.proc_set_thresholds(0.05, 0.02)
+    hints = [sc.build_poses[0].copy(), sc.build_poses[0].copy()]
+    origo = np.array([0.3, -0.1], np.float32) * np.float32(sc.scale_to_map)
+    for t in range(10):
+        mwm = t in (4,)  # one map_without_matching step: coarse levels reuse stale containers
+        for k in range(2):
+            o[k].proc_update(sc.build_scans[t], hints[k], origo=origo, map_without_matching=mwm)
+        (p0, c0), (p1, c1) = o[0].proc_last_pose(), o[1].proc_last_pose()
+        assert np.array_equal(bits(p0), bits(p1)), t
+        if t > 0:
+            assert np.array_equal(bits(c0), bits(c1)), t
+        step = sc.build_poses[t + 1] - sc.build_poses[t]
+        hints = [p0 + step, p1 + step]
+    for lvl in range(sc.levels):
+        a, b = o[0].download_level(lvl), o[1].download_level(lvl)
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
+
+
+def test_reset_and_factor_setters(oracle_mod, small_scene):
+    if not oracle_mod.available("hr"):
+        pytest.skip("no reference build")
+    sc = small_scene
+    o = [make_oracle(oracle_mod, k, sc, free=0.3, occ=0.8) for k in ("ho", "hr")]
+    for x in o:
+        x.reset()
+        x.set_update_factor_free(0.45)
+        x.set_update_factor_occupied(0.7)
+        x.build_map(sc.build_poses[:5], sc.build_scans[:5])
+    a, b = o[0].download_level(0), o[1].download_level(0)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
+
+
+def test_util_helpers(oracle_mod):
+    if not oracle_mod.available("hr"):
+        pytest.skip("no reference build")
+    f_o, f_r = oracle_mod._load("ho"), oracle_mod._load("hr")
+    rng = np.random.default_rng(8)
+    for a in np.concatenate([rng.uniform(-50, 50, 500), [0.0, np.pi, -np.pi, 3.1415927, -3.1415927, 6.2831855]]):
+        x, y = f_o["normalize_angle"](float(a)), f_r["normalize_angle"](float(a))
+        assert np.float32(x).view(np.uint32) == np.float32(y).view(np.uint32)
+    for _ in range(300):
+        p1 = rng.uniform(-2, 2, 3).astype(np.float32)
+        p2 = p1 + rng.uniform(-0.5, 0.5, 3).astype(np.float32) * np.array([1, 1, 8], np.float32)
+        assert f_o["pose_difference_larger_than"](p1, p2, 0.4, 0.13) == f_r["pose_difference_larger_than"](p1, p2, 0.4, 0.13)
+    fmax = np.full(3, np.finfo(np.float32).max, np.float32)
+    assert f_o["pose_difference_larger_than"](np.zeros(3, np.float32), fmax, 0.4, 0.13) == 1
