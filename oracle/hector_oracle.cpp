@@ -572,6 +572,13 @@ void ho_match(void* h, const float begin[3], const float* pts, int n, const floa
               float out[3], float cov[9]) {
   multimap_match(*(Ctx*)h, begin, pts, n, origo, out, cov);
 }
+void ho_match_many(void* h, int batch, const float* begin, const float* pts, const int* offs, float* out) {
+  static const float zero[2] = {0.0f, 0.0f};
+  float cov[9];
+  for (int b = 0; b < batch; ++b)
+    multimap_match(*(Ctx*)h, begin + 3 * b, pts + 2 * (size_t)offs[b], offs[b + 1] - offs[b], zero,
+                   out + 3 * b, cov);
+}
 void ho_update_by_scan(void* h, const float pose[3], const float* pts, int n, const float origo[2]) {
   multimap_update(*(Ctx*)h, pts, n, origo, pose);
 }

@@ -61,6 +61,10 @@ void ORF(match_level)(void* h, int level, const float begin_world[3], const floa
  * cov is in/out (untouched for n==0).  Retains the per-level scaled copies like the reference. */
 void ORF(match)(void* h, const float begin_world[3], const float* pts, int n, const float origo[2],
                 float out_pose_world[3], float cov[9]);
+/* `batch` consecutive match() calls in one C loop (CSR offsets in points); timing helper so the
+ * CPU baseline is not charged for Python call overhead.  out_pose [batch*3]. */
+void ORF(match_many)(void* h, int batch, const float* begin_world, const float* pts,
+                     const int* offsets, float* out_pose_world);
 /* a11: MapRepMultiMap::updateByScan (MapRepMultiMap.h:134-147): level 0 from pts,
  * coarse levels from the containers retained by the last match() call */
 void ORF(update_by_scan)(void* h, const float pose_world[3], const float* pts, int n,

@@ -58,6 +58,7 @@ def _load(kind: str):
         "hessian_derivs": (None, [vp, i, _f32p, _f32p, i, _f32p, _f32p]),
         "match_level": (None, [vp, i, _f32p, _f32p, i, i, _f32p, _f32p]),
         "match": (None, [vp, _f32p, _f32p, i, _f32p, _f32p, _f32p]),
+        "match_many": (None, [vp, i, _f32p, _f32p, _i32p, _f32p]),
         "update_by_scan": (None, [vp, _f32p, _f32p, i, _f32p]),
         "update_by_scan_level": (None, [vp, i, _f32p, _f32p, i, _f32p]),
         "on_map_updated": (None, [vp]),
@@ -171,6 +172,14 @@ class Oracle:
         c = np.zeros(9, np.float32) if cov is None else _v(cov, 9).copy()
         self.f["match"](self.h, _v(begin_world, 3), p.reshape(-1), p.shape[0], _v(origo, 2), out, c)
         return out, c
+
+    def match_many(self, begin_world, pts, offsets):
+        """len(offsets)-1 matchData calls in one C loop (CPU-baseline timing helper)."""
+        b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 3)
+        out = np.empty_like(b)
+        self.f["match_many"](self.h, b.shape[0], b.reshape(-1), np.ascontiguousarray(pts, np.float32).reshape(-1),
+                             np.ascontiguousarray(offsets, np.int32), out.reshape(-1))
+        return out
 
     def update_by_scan(self, pose_world, pts, origo=_ZERO2):
         p = _pts(pts)

@@ -159,6 +159,17 @@ void hr_match(void* h, const float begin[3], const float* pts, int n, const floa
   store3(r->map->matchData(v3(begin), dc, c), out);
   store9(c, cov);
 }
+void hr_match_many(void* h, int batch, const float* begin, const float* pts, const int* offs, float* out) {
+  CoutMute mute;
+  Ref* r = (Ref*)h;
+  const float zero[2] = {0.0f, 0.0f};
+  Eigen::Matrix3f c = Eigen::Matrix3f::Zero();
+  for (int b = 0; b < batch; ++b) {
+    // container construction is part of what the ROS node does per scan too (HectorMappingRos.cpp:483-507)
+    hectorslam::DataContainer dc = make_container(pts + 2 * (size_t)offs[b], offs[b + 1] - offs[b], zero);
+    store3(r->map->matchData(v3(begin + 3 * b), dc, c), out + 3 * b);
+  }
+}
 void hr_update_by_scan(void* h, const float pose[3], const float* pts, int n, const float origo[2]) {
   Ref* r = (Ref*)h;
   hectorslam::DataContainer dc = make_container(pts, n, origo);

@@ -1,0 +1,383 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs and against the committed golden vectors.
+
+Bars (BASELINE.json north_star / SURVEY.md 8(d)):
+  * integer / index work (map update: log-odds + stamps): BIT-EXACT
+  * world<->map transforms (host fp32): BIT-EXACT
+  * per-beam terms M, dM/dx, dM/dy, rotDeriv: BIT-EXACT given the rotation's sin/cos (the device
+    evaluates them in fp64 and rounds once; within 1 ulp of any host sinf/cosf)
+  * probability texels: <= 1 ulp from the oracle's expf-based value
+  * pose estimate: |dx|, |dy| <= 1e-4 m, |dtheta| <= 1e-4 rad  (POSE_TOL below)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ang_diff, bits, make_oracle, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_pose_close(p, q, what=""):
+    p = np.asarray(p, np.float64).reshape(-1, 3)
+    q = np.asarray(q, np.float64).reshape(-1, 3)
+    dxy = np.abs(p[:, :2] - q[:, :2]).max()
+    dth = ang_diff(p[:, 2], q[:, 2]).max()
+    assert dxy <= POSE_TOL_M and dth <= POSE_TOL_RAD, f"{what}: dxy={dxy:.3e} m dth={dth:.3e} rad"
+    return dxy, dth
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a HIP device"
+    from hector_slam_amd import capi as m
+    m.load_library()  # raises if the native library is missing: no silent fallback
+    return m
+
+
+def make_gpu(capi, scene, free=0.4, occ=0.9, build=True, **kw):
+    g = capi.MapRepMultiMap(scene.resolution, scene.map_size, scene.map_size, scene.levels, **kw)
+    g.setUpdateFactorFree(free)
+    g.setUpdateFactorOccupied(occ)
+    if build:
+        g.build_map(scene.build_poses, scene.build_scans)
+    return g
+
+
+@pytest.fixture(scope="module")
+def pyr(capi, oracle_mod, pyramid_scene):
+    return make_gpu(capi, pyramid_scene), make_oracle(oracle_mod, "ho", pyramid_scene)
+
+
+@pytest.fixture(scope="module")
+def sml(capi, oracle_mod, small_scene):
+    return make_gpu(capi, small_scene), make_oracle(oracle_mod, "ho", small_scene)
+
+
+# ---------------------------------------------------------------- geometry / storage
+def test_level_geometry_and_transforms_bit_exact(pyr, pyramid_scene):
+    g, o = pyr
+    assert g.getMapLevels() == o.levels() == pyramid_scene.levels
+    assert np.float32(g.getScaleToMap()) == np.float32(o.scale_to_map())
+    rng = np.random.default_rng(11)
+    for lvl in range(pyramid_scene.levels):
+        assert g.level_info(lvl) == o.level_info(lvl)
+        for _ in range(40):
+            w = rng.uniform(-12, 12, 3).astype(np.float32)
+            m = o.map_coords_pose(lvl, w)
+            assert np.array_equal(bits(g.getMapCoordsPose(lvl, w)), bits(m))
+            assert np.array_equal(bits(g.getWorldCoordsPose(lvl, m)), bits(o.world_coords_pose(lvl, m)))
+
+
+def test_map_update_bit_exact(pyr, pyramid_scene):
+    """80 scans x 3 levels of updateByScan: log-odds planes and update stamps identical to the oracle"""
+    g, o = pyr
+    for lvl in range(pyramid_scene.levels):
+        lo_g, ui_g = g.download_level(lvl)
+        lo_o, ui_o = o.download_level(lvl)
+        assert (lo_o > 0).sum() > 100
+        assert np.array_equal(ui_g, ui_o), f"level {lvl}: {(ui_g != ui_o).sum()} stamps differ"
+        assert np.array_equal(bits(lo_g), bits(lo_o)), f"level {lvl}: {(bits(lo_g) != bits(lo_o)).sum()} cells differ"
+        assert g.getUpdateIndex(lvl) == len(pyramid_scene.build_scans) - 1
+
+
+def test_probability_plane_within_one_ulp(pyr, pyramid_scene):
+    g, o = pyr
+    for lvl in range(pyramid_scene.levels):
+        lo, _ = o.download_level(lvl)
+        odds = np.exp(lo.astype(np.float32))  # numpy float32 exp ~ expf
+        ref = odds / (odds + np.float32(1.0))
+        got = g.download_prob(lvl)
+        d = ulp_diff(got, ref)
+        assert d.max() <= 1, d.max()
+        assert (d == 0).mean() > 0.99
+
+
+def test_upload_then_download_roundtrip_and_rebuild(capi, pyr, pyramid_scene):
+    g, o = pyr
+    g2 = make_gpu(capi, pyramid_scene, build=False)
+    for lvl in range(pyramid_scene.levels):
+        lo, ui = o.download_level(lvl)
+        g2.upload_level(lvl, lo, ui)
+        lo2, ui2 = g2.download_level(lvl)
+        assert np.array_equal(bits(lo2), bits(lo)) and np.array_equal(ui2, ui)
+        # texels rebuilt from an uploaded plane == texels maintained incrementally by the updates
+        assert np.array_equal(bits(g2.download_prob(lvl)), bits(g.download_prob(lvl)))
+    sc = pyramid_scene
+    a = g.matchData(sc.query_init[0], sc.query_scans[0])
+    b = g2.matchData(sc.query_init[0], sc.query_scans[0])
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+# ---------------------------------------------------------------- per-beam / per-step
+@pytest.mark.parametrize("layout", ["quad", "plane"])
+def test_per_beam_terms_bit_exact(capi, oracle_mod, pyramid_scene, layout):
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    g = make_gpu(capi, sc, build=False, layout=capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE)
+    for lvl in range(sc.levels):
+        g.upload_level(lvl, *o.download_level(lvl))
+    checked = 0
+    for q in range(len(sc.query_scans)):
+        for lvl in range(sc.levels):
+            pts = sc.query_scans[q] * np.float32(1.0 / 2 ** lvl)
+            pm = o.map_coords_pose(lvl, sc.query_init[q])
+            got = g.eval_beams(lvl, pm, pts)
+            # oracle per-beam terms: M, gx, gy from interp at the transformed point; the transform
+            # uses the same fp32 expression t + (c*x + (-s)*y).  sin/cos as the device defines
+            # them: evaluated in fp64, rounded once to fp32 (independent of any host libm)
+            s, c = np.float32(np.sin(np.float64(pm[2]))), np.float32(np.cos(np.float64(pm[2])))
+            tx = pm[0] + (c * pts[:, 0] + (-s) * pts[:, 1])
+            ty = pm[1] + (s * pts[:, 0] + c * pts[:, 1])
+            ref = o.interp(lvl, np.stack([tx, ty], 1).astype(np.float32))
+            assert np.array_equal(bits(got[:, :3]), bits(ref)), (q, lvl)
+            rot = ((-s * pts[:, 0] - c * pts[:, 1]) * ref[:, 1] + (c * pts[:, 0] - s * pts[:, 1]) * ref[:, 2])
+            assert np.array_equal(bits(got[:, 3]), bits(rot.astype(np.float32))), (q, lvl)
+            checked += 1
+    assert checked == len(sc.query_scans) * sc.levels
+
+
+def test_hessian_derivs_match_oracle(pyr, pyramid_scene):
+    """H and dTr of one evaluation: same per-beam terms, different summation order -> ~1e-6 relative"""
+    g, o = pyr
+    sc = pyramid_scene
+    for q in range(8):
+        for lvl in range(sc.levels):
+            pts = sc.query_scans[q] * np.float32(1.0 / 2 ** lvl)
+            pm = o.map_coords_pose(lvl, sc.query_init[q])
+            Hg, dg = g.hessian_derivs(lvl, pm, pts)
+            Ho, do = o.hessian_derivs(lvl, pm, pts)
+            scale = np.abs(Ho).max()
+            assert np.abs(Hg - Ho).max() <= 2e-5 * scale
+            assert np.abs(dg - do).max() <= 2e-5 * max(np.abs(do).max(), 1e-3 * np.sqrt(scale))
+            assert np.array_equal(Hg, Hg.T)
+
+
+# ---------------------------------------------------------------- pose parity
+def test_config1_single_level_pose_parity(sml, small_scene):
+    """BASELINE configs[0]: 181 beams, 256x256 single-res map, 5 GN iterations"""
+    g, o = sml
+    sc = small_scene
+    for q in range(len(sc.query_scans)):
+        pg, cg = g.match_level(0, sc.query_init[q], sc.query_scans[q], 5)
+        po, co = o.match_level(0, sc.query_init[q], sc.query_scans[q], 5)
+        assert_pose_close(pg, po, f"q{q}")
+        assert np.abs(cg - co).max() <= 1e-4 * np.abs(co).max()
+
+
+def test_config2_pyramid_pose_parity(pyr, pyramid_scene):
+    """configs[1]-shaped: 1081 beams, 3-level pyramid, full matchData (4+4+6 GN steps)"""
+    g, o = pyr
+    sc = pyramid_scene
+    worst = (0.0, 0.0)
+    for q in range(len(sc.query_scans)):
+        pg, cg = g.matchData(sc.query_init[q], sc.query_scans[q])
+        po, co = o.match(sc.query_init[q], sc.query_scans[q])
+        d = assert_pose_close(pg, po, f"q{q}")
+        worst = (max(worst[0], d[0]), max(worst[1], d[1]))
+        assert np.abs(cg - co).max() <= 1e-4 * np.abs(co).max()
+    print(f"worst pose deviation vs oracle: {worst[0]:.2e} m, {worst[1]:.2e} rad")
+
+
+def test_empty_scan_and_degenerate_map(capi, pyr, pyramid_scene):
+    g, o = pyr
+    sc = pyramid_scene
+    cov_in = np.arange(9, dtype=np.float32)
+    p, c = g.matchData(sc.query_init[0], np.zeros((0, 2), np.float32), cov_in)
+    assert np.array_equal(bits(p), bits(sc.query_init[0])) and np.array_equal(c, cov_in)
+    # fresh map: p = 0.5 everywhere -> H(0,0) == 0 -> the pose must not move
+    fresh = make_gpu(capi, sc, build=False)
+    p, c = fresh.matchData(sc.query_init[1], sc.query_scans[1])
+    fo = o.__class__("ho", sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    po, co = fo.match(sc.query_init[1], sc.query_scans[1])
+    assert np.array_equal(bits(p), bits(po)) and np.array_equal(c, co) and not c.any()
+
+
+def test_far_starts_clamp_and_out_of_map_beams(pyr, pyramid_scene):
+    """large initial errors (angle clamp active) and a start near the map border (most beams OOB).
+    GN from far outside the basin is chaotic, so only starts the oracle itself converges are held
+    to the pose tolerance; all must stay finite and agree on the first coarse step."""
+    g, o = pyr
+    sc = pyramid_scene
+    rng = np.random.default_rng(7)
+    for q in range(8):
+        init = sc.query_truth[q] + np.array([rng.uniform(-.5, .5), rng.uniform(-.5, .5), rng.uniform(-.5, .5)], np.float32)
+        lvl = sc.levels - 1
+        pts = sc.query_scans[q] * np.float32(1.0 / 2 ** lvl)
+        pg, _ = g.match_level(lvl, init, pts, 0)  # exactly one GN step on the coarsest level
+        po, _ = o.match_level(lvl, init, pts, 0)
+        assert_pose_close(pg, po, f"first step q{q}")
+        pg, _ = g.matchData(init, sc.query_scans[q])
+        assert np.isfinite(pg).all()
+    far = np.array([11.5, 9.0, 0.3], np.float32)
+    pg, _ = g.match_level(0, far, sc.query_scans[0], 0)
+    po, _ = o.match_level(0, far, sc.query_scans[0], 0)
+    assert_pose_close(pg, po, "border start")
+
+
+# ---------------------------------------------------------------- batched path
+def test_batch_equals_singles_and_is_deterministic(capi, oracle_mod, pyramid_scene):
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    g1 = make_gpu(capi, sc, build=False, waves_per_scan=1)
+    for lvl in range(sc.levels):
+        g1.upload_level(lvl, *o.download_level(lvl))
+    pts, offs = synth.pack_scans(sc.query_scans)
+    pb, cb = g1.match_batch(sc.query_init, pts, offs)
+    pb2, cb2 = g1.match_batch(sc.query_init, pts, offs)
+    assert np.array_equal(bits(pb), bits(pb2)) and np.array_equal(bits(cb), bits(cb2))  # deterministic
+    for q in range(len(sc.query_scans)):
+        ps, cs = g1.matchData(sc.query_init[q], sc.query_scans[q])  # same WPS -> same reduction tree
+        assert np.array_equal(bits(ps), bits(pb[q])) and np.array_equal(bits(cs), bits(cb[q]))
+        po, _ = o.match(sc.query_init[q], sc.query_scans[q])
+        assert_pose_close(pb[q], po, f"batch q{q}")
+    # order independence: reversing the batch reverses the results bit-for-bit
+    rev = list(reversed(range(len(sc.query_scans))))
+    pts_r, offs_r = synth.pack_scans([sc.query_scans[i] for i in rev])
+    pr, _ = g1.match_batch(sc.query_init[rev], pts_r, offs_r)
+    assert np.array_equal(bits(pr), bits(pb[rev]))
+    # shared-scan mode (pose hypotheses of ONE scan) == CSR with the scan replicated
+    hyp = np.repeat(sc.query_init[3:4], 9, 0) + np.linspace(-0.05, 0.05, 9, dtype=np.float32)[:, None]
+    ph, _ = g1.match_batch(hyp, sc.query_scans[3], None)
+    pts_c, offs_c = synth.pack_scans([sc.query_scans[3]] * 9)
+    pc, _ = g1.match_batch(hyp, pts_c, offs_c)
+    assert np.array_equal(bits(ph), bits(pc))
+
+
+@pytest.mark.parametrize("wps", [1, 2, 4, 8, 16])
+def test_every_team_width_meets_pose_tolerance(capi, oracle_mod, pyramid_scene, wps):
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    g = make_gpu(capi, sc, build=False, waves_per_scan=wps)
+    for lvl in range(sc.levels):
+        g.upload_level(lvl, *o.download_level(lvl))
+    for q in range(6):
+        pg, _ = g.matchData(sc.query_init[q], sc.query_scans[q])
+        assert g.last_launch_config()["waves_per_scan"] == wps
+        assert_pose_close(pg, o.match(sc.query_init[q], sc.query_scans[q])[0], f"wps{wps} q{q}")
+    # ragged scan lengths around the team width (1, 63, 64, 65 beams ...)
+    for n in (1, 2, 63, 64, 65, 64 * wps - 1, 64 * wps + 1, 1000):
+        pts = sc.query_scans[2][:n]
+        pg, _ = g.matchData(sc.query_init[2], pts)
+        po, _ = o.match(sc.query_init[2], pts)
+        if np.isfinite(po).all():
+            assert np.abs(pg - po).max() <= 1e-3, n  # few-beam systems are ill conditioned
+        else:
+            assert not np.isfinite(pg).all()
+
+
+# ---------------------------------------------------------------- processor loop
+def test_slam_loop_match_update_interleaved(capi, oracle_mod, pyramid_scene):
+    """HectorSlamProcessor::update from an EMPTY map: match -> threshold -> updateByScan, 25 scans.
+    Poses stay within tolerance of the oracle's at every step; the maps agree except for the few
+    cells whose Bresenham endpoints flip because the poses differ in the last bits."""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o.proc_set_thresholds(0.05, 0.02)
+    p = capi.HectorSlamProcessor(sc.resolution, sc.map_size, sc.map_size, (0.5, 0.5), sc.levels)
+    p.setUpdateFactorFree(0.4)
+    p.setUpdateFactorOccupied(0.9)
+    p.setMapUpdateMinDistDiff(0.05)
+    p.setMapUpdateMinAngleDiff(0.02)
+    origo = np.array([0.3, -0.1], np.float32) * np.float32(sc.scale_to_map)
+    hint_o = hint_g = sc.build_poses[0].copy()
+    for t in range(25):
+        mwm = t == 7
+        o.proc_update(sc.build_scans[t], hint_o, origo=origo, map_without_matching=mwm)
+        p.update(sc.build_scans[t], hint_g, mwm, origo=origo)
+        po, _ = o.proc_last_pose()
+        pg = p.getLastScanMatchPose()
+        assert_pose_close(pg, po, f"t={t}")
+        step = sc.build_poses[t + 1] - sc.build_poses[t]
+        hint_o, hint_g = po + step, pg + step
+    for lvl in range(sc.levels):
+        lo_g, ui_g = p.mapRep.download_level(lvl)
+        lo_o, ui_o = o.download_level(lvl)
+        touched = (ui_o >= 0).sum()
+        assert touched > 1000
+        assert (bits(lo_g) != bits(lo_o)).sum() <= 0.002 * touched
+    # with identical poses fed to both, the maps are bit-identical (pure index work)
+    g2 = make_gpu(capi, sc, build=False)
+    o2 = make_oracle(oracle_mod, "ho", sc, build=False)
+    for t in range(10):
+        o2.match(sc.build_poses[t], sc.build_scans[t], origo)       # retains the coarse containers
+        g2.matchData(sc.build_poses[t], sc.build_scans[t], None, origo)
+        o2.update_by_scan(sc.build_poses[t], sc.build_scans[t], origo)
+        g2.updateByScan(sc.build_scans[t], sc.build_poses[t], origo)
+    for lvl in range(sc.levels):
+        a, b = g2.download_level(lvl), o2.download_level(lvl)
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
+
+
+def test_update_edge_cases_bit_exact(capi, oracle_mod, small_scene):
+    """empty scan, begin == end beams, beams leaving the map, robot outside the map, the occupied
+    clamp at 50 and the free->occupied revert -- all bit-exact against the oracle"""
+    sc = small_scene
+    g = make_gpu(capi, sc, build=False)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    s = np.float32(sc.scale_to_map)
+    cases = [
+        (np.array([0, 0, 0], np.float32), np.zeros((0, 2), np.float32)),                       # empty
+        (np.array([0, 0, 0.3], np.float32), np.array([[0.2, 0.1], [0.4, -0.3]], np.float32)),  # begin == end
+        (np.array([10, 0, 0], np.float32), np.array([[5 * s, 0], [2 * s, 1 * s], [1 * s, 40 * s]], np.float32)),  # leaves map
+        (np.array([40, 40, 0], np.float32), np.array([[-30 * s, -30 * s]], np.float32)),       # robot outside
+    ]
+    for pose, pts in cases:
+        g.update_by_scan_level(0, pose, pts)
+        o.update_by_scan_level(0, pose, pts)
+    # hammer one wall until cells saturate at the 50 clamp; crossing beams exercise the revert
+    ring = np.stack([np.cos(np.linspace(0, 2 * np.pi, 720, endpoint=False)),
+                     np.sin(np.linspace(0, 2 * np.pi, 720, endpoint=False))], 1).astype(np.float32) * (3 * s)
+    for k in range(40):
+        pose = np.array([0.01 * k, -0.02 * k, 0.05 * k], np.float32)
+        g.update_by_scan_level(0, pose, ring)
+        o.update_by_scan_level(0, pose, ring)
+    lo_g, ui_g = g.download_level(0)
+    lo_o, ui_o = o.download_level(0)
+    assert lo_o.max() >= 50.0
+    assert np.array_equal(ui_g, ui_o) and np.array_equal(bits(lo_g), bits(lo_o))
+    assert g.getUpdateIndex(0) == len(cases) + 40 - 1
+    bb = g.last_update_bbox(0)
+    ys, xs = np.nonzero(ui_o == ui_o.max())
+    assert bb[0] <= xs.min() and bb[2] >= xs.max() and bb[1] <= ys.min() and bb[3] >= ys.max()
+    rows = g.download_rows(0, int(bb[1]), int(bb[3]) + 1)
+    assert np.array_equal(bits(rows), bits(lo_o[bb[1]:bb[3] + 1]))
+    # reset: every cell back to (0, -1), probability 0.5
+    g.reset()
+    lo_g, ui_g = g.download_level(0)
+    assert not lo_g.any() and (ui_g == -1).all() and (g.download_prob(0) == 0.5).all()
+
+
+# ---------------------------------------------------------------- golden vectors
+def test_golden_config1(capi):
+    g1 = np.load(os.path.join(GOLD, "config1_181beam_256map.npz"))
+    g = capi.MapRepMultiMap(float(g1["resolution"]), int(g1["map_size"]), int(g1["map_size"]), 1)
+    g.upload_level(0, g1["logodds"], g1["update_index"])
+    for q in range(4):
+        pts = g1[f"q{q}_pts"]
+        pose, cov = g.match_level(0, g1[f"q{q}_init"], pts, 5)
+        assert_pose_close(pose, g1[f"q{q}_pose"], f"golden q{q}")
+        assert np.abs(cov - g1[f"q{q}_cov"]).max() <= 1e-4 * np.abs(g1[f"q{q}_cov"]).max()
+        for k in range(7):
+            H, d = g.hessian_derivs(0, g1[f"q{q}_step_pose_map"][k], pts)
+            Hr, dr = g1[f"q{q}_step_H"][k], g1[f"q{q}_step_dTr"][k]
+            assert np.abs(H - Hr).max() <= 2e-5 * np.abs(Hr).max()
+            assert np.abs(d - dr).max() <= 2e-5 * max(np.abs(dr).max(), 1e-3 * np.sqrt(np.abs(Hr).max()))
+
+
+def test_golden_pyramid(capi):
+    g2 = np.load(os.path.join(GOLD, "pyramid_1081beam_512map.npz"))
+    g = capi.MapRepMultiMap(float(g2["resolution"]), int(g2["map_size"]), int(g2["map_size"]), 3)
+    for lvl in range(3):
+        g.upload_level(lvl, g2[f"logodds{lvl}"], g2[f"update_index{lvl}"])
+    for q in range(8):
+        pose, cov = g.matchData(g2["init"][q], g2[f"q{q}_pts"])
+        assert_pose_close(pose, g2["pose"][q], f"golden pyramid q{q}")
+        assert np.abs(cov - g2["cov"][q]).max() <= 1e-4 * np.abs(g2["cov"][q]).max()

@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a batch with shard_bounds and reassemble
+it with the single all-gather the GPU path uses (backend nccl = RCCL there)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    from hector_slam_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(total * 3, dtype=torch.float32).reshape(total, 3) * 0.5 - 7.0
+        b, e = sharding.shard_bounds(total, rank, world)
+        local = full[b:e].clone() + 0.0  # stand-in for the poses this rank's GPU matched
+        got = sharding.all_gather_rows(local, total)
+        ok = bool(torch.equal(got, full))
+        q.put((rank, ok, b, e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 9, 4097])
+def test_two_rank_gather_reassembles_batch(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    spans = sorted((b, e) for _, _, b, e in res)
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == total
+
+
+def test_shard_bounds_partition():
+    from hector_slam_amd import sharding
+    for total in (0, 1, 7, 4096, 32768, 32771):
+        for world in (1, 2, 4, 8):
+            spans = [sharding.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == sharding.max_shard(total, world)
