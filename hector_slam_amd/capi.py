@@ -68,6 +68,7 @@ SIGNATURES = {
     "hsm_hessian_derivs": (_i, [_vp, _i, _f32p, _vp, _i, _f32p, _f32p]),
     "hsm_eval_beams": (_i, [_vp, _i, _f32p, _vp, _i, _vp]),
     "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
+    "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
     "hsm_last_error": (C.c_char_p, []),
@@ -240,10 +241,10 @@ class MapRepMultiMap:
         return self._lib.hsm_gn_iterations_per_match(self._h)
 
     def last_launch_config(self):
-        cfg = np.empty(4, np.int32)
+        cfg = np.empty(5, np.int32)
         _check(self._lib.hsm_last_launch_config(self._h, cfg), "hsm_last_launch_config")
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
-                "block": int(cfg[2]), "grid": int(cfg[3])}
+                "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": int(cfg[4])}
 
     # ---- parity / debug ---------------------------------------------------------------------
     def hessian_derivs(self, level, pose_map, pts_level):
@@ -259,6 +260,12 @@ class MapRepMultiMap:
         _check(self._lib.hsm_eval_beams(self._h, level, _v(pose_map, 3), p, n, out.ctypes.data if n else None),
                "hsm_eval_beams")
         return out
+
+    def debug_sincos(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        s, c = np.empty_like(x), np.empty_like(x)
+        _check(self._lib.hsm_debug_sincos(self._h, x.size, x, s, c), "hsm_debug_sincos")
+        return s, c
 
     def match_level(self, level, begin_world, pts_level, max_iter, cov=None):
         a, p, n = _pts(pts_level)

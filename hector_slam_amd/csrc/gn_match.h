@@ -39,6 +39,7 @@ namespace hsm {
 constexpr int kMaxLevels = 8;
 constexpr int kLayoutQuad = 1;
 constexpr int kLayoutPlane = 2;
+constexpr int kUnroll = 4;  // texel gathers a lane keeps in flight (register-resident form)
 
 // Eigen::Affine2f as the reference builds it: 2x2 linear (column major) + translation.
 struct Affine2 {
@@ -77,11 +78,41 @@ __device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y,
 }
 
 // sinf/cosf of the reference (float overloads): fp64 then one rounding.
+// Lean fp64 kernel instead of the generic libm sincos(double): Cody-Waite reduction by pi/2 in
+// two parts (the 33-bit head makes k*head exact for |k| < 2^20) and the classic degree-13/14
+// minimax polynomials on [-pi/4, pi/4] (fdlibm k_sin/k_cos coefficients, < 1 ulp in fp64).
+// ~25 fp64 instructions, a handful of live registers, no table, no slow path in the hot loop;
+// validated to round to the correctly rounded fp32 value (tests sweep it on the device).
 __device__ __forceinline__ void sincos_f32(float th, float& s, float& c) {
-  double sd, cd;
-  sincos((double)th, &sd, &cd);
-  s = (float)sd;
-  c = (float)cd;
+  double x = (double)th;
+  if (!(fabs(x) < 1048576.0)) {
+    // unrealistically large angles (the matcher normalises theta after every level):
+    // bring them into range first; inf/NaN fall through and yield NaN like libm
+    x = fmod(x, 6.283185307179586476925);
+  }
+  const double k = rint(x * 0.63661977236758134308);
+  double r = x - k * 1.57079632673412561417e+00;  // exact product
+  r = r - k * 6.07710050650619224932e-11;
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = ps * z + -2.50507602534068634195e-08;
+  ps = ps * z + 2.75573137070700676789e-06;
+  ps = ps * z + -1.98412698298579493134e-04;
+  ps = ps * z + 8.33333333332248946124e-03;
+  ps = ps * z + -1.66666666666666324348e-01;
+  const double sr = r + r * z * ps;
+  double pc = -1.13596475577881948265e-11;
+  pc = pc * z + 2.08757232129817482790e-09;
+  pc = pc * z + -2.75573143513906633035e-07;
+  pc = pc * z + 2.48015872894767294178e-05;
+  pc = pc * z + -1.38888888888741095749e-03;
+  pc = pc * z + 4.16666666666666019037e-02;
+  const double cr = 1.0 - 0.5 * z + z * z * pc;
+  const int q = (int)k & 3;
+  const double sd = (q & 1) ? cr : sr;
+  const double cd = (q & 1) ? sr : cr;
+  s = (float)((q & 2) ? -sd : sd);
+  c = (float)(((q + 1) & 2) ? -cd : cd);
 }
 
 // util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
@@ -98,48 +129,64 @@ struct BeamTerms {
   float M, gx, gy;
 };
 
-// a1: interpMapValueWithDerivatives at map coords (cx, cy)
+// a1, split in two so that a lane can ISSUE the texel gathers of several beams back to back
+// (stage 1) before it CONSUMES any of them (stage 2): memory latency is hidden by
+// instruction-level parallelism inside the wavefront, not only by occupancy.
+struct BeamSample {
+  float i0, i1, i2, i3;  // P(ix,iy), P(ix+1,iy), P(ix,iy+1), P(ix+1,iy+1)
+  float fx, fy;
+  bool oob;
+};
+
+// stage 1: bounds test, cell index, fractions, and the (asynchronous) gather
 template <int LAYOUT>
-__device__ __forceinline__ BeamTerms interp_with_derivs(const LevelView& L, float cx, float cy) {
-  // MapDimensionProperties::pointOutOfMapBounds (MapDimensionProperties.h:65-68)
-  const bool oob = (cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy);
-  // out-of-map lanes sample texel 0 and are zeroed below (the reference returns (0,0,0))
-  const float sx_ = oob ? 0.0f : cx;
-  const float sy_ = oob ? 0.0f : cy;
-  const int ix = (int)sx_;  // truncation, :295
+__device__ __forceinline__ BeamSample sample_fetch(const LevelView& L, float cx, float cy, bool live = true) {
+  BeamSample b;
+  // MapDimensionProperties::pointOutOfMapBounds (MapDimensionProperties.h:65-68); `live` is false
+  // for the padding slots of a lane that has fewer beams than its register file holds: they
+  // take the same exact-zero path as an out-of-map beam
+  b.oob = !live || (cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy);
+  // out-of-map lanes sample texel 0 and are zeroed in stage 2 (the reference returns (0,0,0))
+  const float sx_ = b.oob ? 0.0f : cx;
+  const float sy_ = b.oob ? 0.0f : cy;
+  const int ix = (int)sx_;  // truncation, OccGridMapUtil.h:295
   const int iy = (int)sy_;
-  const float fx = sx_ - (float)ix;  // :298
-  const float fy = sy_ - (float)iy;
+  b.fx = sx_ - (float)ix;  // :298
+  b.fy = sy_ - (float)iy;
   const int index = iy * L.sx + ix;  // :302
-  float i0, i1, i2, i3;
   if (LAYOUT == kLayoutQuad) {
     const float4 q = L.quad[index];
-    i0 = q.x;
-    i1 = q.y;
-    i2 = q.z;
-    i3 = q.w;
+    b.i0 = q.x;
+    b.i1 = q.y;
+    b.i2 = q.z;
+    b.i3 = q.w;
   } else {
     // indices index, index+1, index+sizeX, index+sizeX+1 (:306-330).  A NaN coordinate
     // passes the bounds test like in the reference; v_cvt_i32_f32(NaN) = 0 keeps the
     // address inside the plane and the NaN fraction poisons the result as it should.
     const float* p = L.prob + index;
-    i0 = p[0];
-    i1 = p[1];
-    i2 = p[L.sx];
-    i3 = p[L.sx + 1];
+    b.i0 = p[0];
+    b.i1 = p[1];
+    b.i2 = p[L.sx];
+    b.i3 = p[L.sx + 1];
   }
-  const float dx1 = i0 - i1;  // :332-336
-  const float dx2 = i2 - i3;
-  const float dy1 = i0 - i2;
-  const float dy2 = i1 - i3;
-  const float xFacInv = (1.0f - fx);  // :338-339
-  const float yFacInv = (1.0f - fy);
+  return b;
+}
+
+// stage 2: the interpolation and the source-literal "derivatives" (:332-346)
+__device__ __forceinline__ BeamTerms sample_finish(const BeamSample& b) {
+  const float dx1 = b.i0 - b.i1;  // :332-336
+  const float dx2 = b.i2 - b.i3;
+  const float dy1 = b.i0 - b.i2;
+  const float dy2 = b.i1 - b.i3;
+  const float xFacInv = (1.0f - b.fx);  // :338-339
+  const float yFacInv = (1.0f - b.fy);
   BeamTerms r;
   // :341-346, source-literal (x-differences blended with the x fractions)
-  r.M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
-  r.gx = -((dx1 * xFacInv) + (dx2 * fx));
-  r.gy = -((dy1 * yFacInv) + (dy2 * fy));
-  if (oob) {
+  r.M = ((b.i0 * xFacInv + b.i1 * b.fx) * (yFacInv)) + ((b.i2 * xFacInv + b.i3 * b.fx) * (b.fy));
+  r.gx = -((dx1 * xFacInv) + (dx2 * b.fx));
+  r.gy = -((dy1 * yFacInv) + (dy2 * b.fy));
+  if (b.oob) {
     r.M = 0.0f;
     r.gx = 0.0f;
     r.gy = 0.0f;
@@ -153,14 +200,18 @@ struct Acc9 {
   __device__ __forceinline__ void zero() { d0 = d1 = d2 = h00 = h11 = h22 = h01 = h02 = h12 = 0.0f; }
 };
 
+// transform * currPoint with transform = Translation(ex,ey) * Rotation(theta): linear [c -s; s c]
 template <int LAYOUT>
-__device__ __forceinline__ float beam_accumulate(const LevelView& L, float ex, float ey, float sinRot,
-                                                 float cosRot, float px, float py, Acc9& a,
-                                                 BeamTerms* terms_out = nullptr) {
-  // transform * currPoint with transform = Translation(ex,ey) * Rotation(theta): linear [c -s; s c]
+__device__ __forceinline__ BeamSample beam_fetch(const LevelView& L, float ex, float ey, float sinRot,
+                                                 float cosRot, float px, float py, bool live = true) {
   const float tx = ex + (cosRot * px + (-sinRot) * py);
   const float ty = ey + (sinRot * px + cosRot * py);
-  const BeamTerms t = interp_with_derivs<LAYOUT>(L, tx, ty);
+  return sample_fetch<LAYOUT>(L, tx, ty, live);
+}
+
+__device__ __forceinline__ float beam_finish(const BeamSample& b, float sinRot, float cosRot, float px, float py,
+                                             Acc9& a, BeamTerms* terms_out = nullptr) {
+  const BeamTerms t = sample_finish(b);
   const float funVal = 1.0f - t.M;
   a.d0 += t.gx * funVal;
   a.d1 += t.gy * funVal;
@@ -174,6 +225,14 @@ __device__ __forceinline__ float beam_accumulate(const LevelView& L, float ex, f
   a.h12 += t.gy * rotDeriv;
   if (terms_out) *terms_out = t;
   return rotDeriv;
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ float beam_accumulate(const LevelView& L, float ex, float ey, float sinRot,
+                                                 float cosRot, float px, float py, Acc9& a,
+                                                 BeamTerms* terms_out = nullptr, bool live = true) {
+  const BeamSample b = beam_fetch<LAYOUT>(L, ex, ey, sinRot, cosRot, px, py, live);
+  return beam_finish(b, sinRot, cosRot, px, py, a, terms_out);
 }
 
 __device__ __forceinline__ float wave_allreduce(float v) {
@@ -259,9 +318,17 @@ __device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, floa
 
 // One team (WPS wavefronts) per scan; SPB scans per workgroup (SPB > 1 only when WPS == 1,
 // where no barrier is ever executed so the wavefronts of a block are fully independent).
-template <int WPS, int SPB, int LAYOUT>
-__global__ void __launch_bounds__(64 * WPS * SPB) gn_match_kernel(const MatchParams P) {
+//
+// BPL > 0: "beams per lane" register-resident form.  A scan with n <= 64*WPS*BPL beams is loaded
+// ONCE (coalesced float2, beam i -> slot i / (64*WPS) of lane i mod 64*WPS) and stays in VGPRs for
+// all levels and GN steps; the beam loop is fully unrolled so the BPL texel gathers of a step are
+// independent and issue back to back (latency hiding by ILP, not only by occupancy).  The
+// per-lane summation order (ascending beam index) is the same as the memory loop's, so both
+// forms produce identical bits.  Longer scans (or BPL == 0) take the memory loop.
+template <int WPS, int SPB, int LAYOUT, int BPL>
+__global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const MatchParams P) {
   static_assert(WPS == 1 || SPB == 1, "barrier-synchronised teams own their workgroup");
+  constexpr int T = 64 * WPS;  // lanes per team
   __shared__ float red[2][WPS][9];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -288,22 +355,75 @@ __global__ void __launch_bounds__(64 * WPS * SPB) gn_match_kernel(const MatchPar
   }
   const float2* __restrict__ pts = P.pts + beg;
   const int tid_in_team = wit * 64 + lane;
+  constexpr int NREG = BPL > 0 ? BPL : 1;
+  float2 pt[NREG];
+  unsigned live_mask = 0;
+  const bool in_regs = BPL > 0 && n <= T * BPL;  // team-uniform
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int i = tid_in_team + k * T;
+      const bool live = i < n;
+      pt[k] = live ? pts[i] : make_float2(0.0f, 0.0f);
+      live_mask |= (live ? 1u : 0u) << k;
+    }
+  }
   Acc9 acc;
   acc.zero();
   int buf = 0;
+  float reg_scale = 1.0f;  // scale the register-resident endpoints currently carry
   for (int l = P.first_level; l >= P.last_level; --l) {
     const LevelView& L = P.lv[l];
     float ex, ey, eth;
     affine_apply(L.mapTworld, pw0, pw1, ex, ey);  // getMapCoordsPose, GridMapBase.h:235-239
     eth = pw2;
     const float ps = L.pt_scale;
+    if (in_regs) {
+      // DataContainer::setFrom(scan, 2^-level): rescale IN PLACE when the level changes.  All
+      // factors are powers of two, so p*2^-a*2^(a-b) == p*2^-b bit for bit, and no second
+      // register copy of the scan is kept alive across the GN steps.
+      const float ratio = ps / reg_scale;
+      reg_scale = ps;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        pt[k].x *= ratio;
+        pt[k].y *= ratio;
+      }
+    }
     for (int it = 0; it < L.gn_steps; ++it) {
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
-      for (int i = tid_in_team; i < n; i += 64 * WPS) {
-        const float2 p = pts[i];
-        beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x * ps, p.y * ps, acc);
+      if (in_regs) {
+        // chunks of kUnroll beams: issue all gathers of a chunk, then consume them in beam order
+        // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
+#pragma unroll
+        for (int k0 = 0; k0 < NREG; k0 += kUnroll) {
+          BeamSample smp[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            if (k0 + u < NREG)
+              smp[u] = beam_fetch<LAYOUT>(L, ex, ey, sinRot, cosRot, pt[k0 + u].x, pt[k0 + u].y,
+                                          (live_mask >> (k0 + u)) & 1u);
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            if (k0 + u < NREG) beam_finish(smp[u], sinRot, cosRot, pt[k0 + u].x, pt[k0 + u].y, acc);
+          }
+          // Pin the chunk: the accumulators must be final here ("+v") and no later gather may be
+          // hoisted above this point ("memory").  Without it the compiler issues all BPL gathers
+          // first and spills their results; with it at most kUnroll texels are in flight per lane.
+          asm volatile(""
+                       : "+v"(acc.d0), "+v"(acc.d1), "+v"(acc.d2), "+v"(acc.h00), "+v"(acc.h11), "+v"(acc.h22),
+                         "+v"(acc.h01), "+v"(acc.h02), "+v"(acc.h12)
+                       :
+                       : "memory");
+        }
+      } else {
+        for (int i = tid_in_team; i < n; i += T) {
+          const float2 p = pts[i];
+          beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x * ps, p.y * ps, acc);
+        }
       }
       team_allreduce9<WPS>(acc, red, buf, wit, lane);
       buf ^= 1;
@@ -366,6 +486,14 @@ __global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict
   const float2 p = pts[i];
   const float rd = beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x, p.y, acc, &t);
   out[i] = make_float4(t.M, t.gx, t.gy, rd);
+}
+
+// device sin/cos sweep for the parity tests
+__global__ void sincos_debug_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
+                                    float* __restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sincos_f32(x[i], s[i], c[i]);
 }
 
 }  // namespace hsm

@@ -89,7 +89,8 @@ struct hsm_ctx {
   // batch staging for the host-pointer convenience entry
   void* d_batch = nullptr;
   size_t d_batch_cap = 0;
-  int last_cfg[4] = {0, 0, 0, 0};
+  int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
+  int last_cfg[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -200,19 +201,20 @@ int ensure_scan_capacity(float2*& buf, size_t& cap, size_t n) {
   return HSM_OK;
 }
 
-template <int WPS, int SPB>
+template <int WPS, int SPB, int BPL>
 int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
   if (h->layout == kLayoutPlane)
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, BPL>), dim3(grid), dim3(block), 0, stream, P);
   else
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, BPL>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
   h->last_cfg[0] = h->layout;
   h->last_cfg[1] = WPS;
   h->last_cfg[2] = block;
   h->last_cfg[3] = grid;
+  h->last_cfg[4] = BPL;
   return HSM_OK;
 }
 
@@ -226,13 +228,25 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   return wps;
 }
 
+// beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
+// team's VGPRs (0 = stream the endpoints from memory every GN step)
+template <int WPS, int SPB>
+int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
+  if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
+  if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
+  if (per_lane <= 5) return launch_match_t<WPS, SPB, 5>(h, P, stream);
+  if (per_lane <= 9) return launch_match_t<WPS, SPB, 9>(h, P, stream);
+  return launch_match_t<WPS, SPB, 17>(h, P, stream);
+}
+
 int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   switch (choose_wps(h, P.batch, max_n)) {
-    case 1: return launch_match_t<1, 4>(h, P, stream);
-    case 2: return launch_match_t<2, 1>(h, P, stream);
-    case 4: return launch_match_t<4, 1>(h, P, stream);
-    case 8: return launch_match_t<8, 1>(h, P, stream);
-    default: return launch_match_t<16, 1>(h, P, stream);
+    case 1: return launch_match_w<1, 4>(h, P, max_n, stream);
+    case 2: return launch_match_w<2, 1>(h, P, max_n, stream);
+    case 4: return launch_match_w<4, 1>(h, P, max_n, stream);
+    case 8: return launch_match_w<8, 1>(h, P, max_n, stream);
+    default: return launch_match_w<16, 1>(h, P, max_n, stream);
   }
 }
 
@@ -385,6 +399,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     return fail(HSM_ERR_INVALID, "hsm_create: waves_per_scan must be 0,1,2,4,8,16");
   }
   h->wps_override = wps;
+  if (const char* env = getenv("HSM_BPL")) h->bpl_override = atoi(env) == 0 ? 0 : -1;
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -484,9 +499,9 @@ int hsm_on_map_updated(hsm_ctx* h) { return h ? HSM_OK : fail(HSM_ERR_INVALID, "
 int hsm_gn_iterations_per_match(const hsm_ctx* h) {
   return h ? 6 + 4 * ((int)h->levels.size() - 1) : 0;
 }
-int hsm_last_launch_config(const hsm_ctx* h, int cfg[4]) {
+int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]) {
   if (!h || !cfg) return fail(HSM_ERR_INVALID, "null argument");
-  for (int i = 0; i < 4; ++i) cfg[i] = h->last_cfg[i];
+  for (int i = 0; i < 5; ++i) cfg[i] = h->last_cfg[i];
   return HSM_OK;
 }
 
@@ -811,6 +826,26 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c) {
+  if (!h || n < 0 || (n > 0 && (!x || !s || !c))) return fail(HSM_ERR_INVALID, "hsm_debug_sincos: bad argument");
+  if (n == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  float* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 3 * (size_t)n * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sincos_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, n, d + n, d + 2 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(s, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(HSM_ERR_HIP, "hsm_debug_sincos", e);
   return HSM_OK;
 }
 

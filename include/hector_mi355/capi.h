@@ -144,10 +144,14 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
 int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy,
                     int n, int max_iterations, float out_pose_world[3], float cov[9]);
 
+/* device sin/cos (fp64-evaluated, rounded once to fp32) of n angles -- numerics test hook */
+int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
+
 /* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
 int hsm_gn_iterations_per_match(const hsm_ctx* h);
-/* effective kernel configuration of the last match launch: {layout, waves_per_scan, block, grid} */
-int hsm_last_launch_config(const hsm_ctx* h, int cfg[4]);
+/* effective kernel configuration of the last match launch:
+ * {layout, waves_per_scan, block, grid, beams_per_lane (0 = endpoints streamed from memory)} */
+int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]);
 
 const char* hsm_last_error(void);
 const char* hsm_version(void);

