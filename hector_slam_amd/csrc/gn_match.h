@@ -100,7 +100,8 @@ __device__ __forceinline__ void sincos_f32(float th, float& s, float& c) {
   ps = ps * z + -1.98412698298579493134e-04;
   ps = ps * z + 8.33333333332248946124e-03;
   ps = ps * z + -1.66666666666666324348e-01;
-  const double sr = r + r * z * ps;
+  // x == +-0 keeps its sign (k = +-0 turns x - k*c into +0): sinf(-0.0f) = -0.0f
+  const double sr = (x == 0.0) ? x : r + r * z * ps;
   double pc = -1.13596475577881948265e-11;
   pc = pc * z + 2.08757232129817482790e-09;
   pc = pc * z + -2.75573143513906633035e-07;
