@@ -52,6 +52,7 @@ SIGNATURES = {
     "hsm_set_update_factor_occupied": (_i, [_vp, _f]),
     "hsm_on_map_updated": (_i, [_vp]),
     "hsm_match": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
+    "hsm_match_trace": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p, _f32p, _i, C.POINTER(_i)]),
     "hsm_match_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "hsm_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
     "hsm_update_by_scan": (_i, [_vp, _f32p, _vp, _i, _f32p]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "hsm_download_level": (_i, [_vp, _i, _vp, _vp]),
     "hsm_upload_level": (_i, [_vp, _i, _vp, _vp]),
     "hsm_download_rows": (_i, [_vp, _i, _i, _i, _f32p]),
+    "hsm_download_cells": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i]),
     "hsm_last_update_bbox": (_i, [_vp, _i, _i32p]),
     "hsm_download_prob": (_i, [_vp, _i, _f32p]),
     "hsm_hessian_derivs": (_i, [_vp, _i, _f32p, _vp, _i, _f32p, _f32p]),

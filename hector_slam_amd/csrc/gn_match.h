@@ -69,6 +69,8 @@ struct MatchParams {
   int shared_n;
   float* out_pose;           // [B*3]
   float* out_cov;            // [B*9] or nullptr
+  float* trace;              // nullptr, or [steps*12] per-GN-step record of scan 0 (draw/debug hooks):
+                             // {map-frame estimate after the step [3], H of that step [9] col-major}
 };
 
 // Transform<Affine> * Vector2f = t + (l(i,0)*x + l(i,1)*y)   (Eigen Transform.h)
@@ -372,6 +374,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   Acc9 acc;
   acc.zero();
   int buf = 0;
+  int step = 0;
   float reg_scale = 1.0f;  // scale the register-resident endpoints currently carry
   for (int l = P.first_level; l >= P.last_level; --l) {
     const LevelView& L = P.lv[l];
@@ -429,6 +432,16 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       team_allreduce9<WPS>(acc, red, buf, wit, lane);
       buf ^= 1;
       gn_solve_and_step(acc, ex, ey, eth);
+      if (P.trace) {  // kernel-uniform; only the single-scan hook path sets it
+        if (scan == 0 && lane == 0 && wit == 0) {
+          float* t = P.trace + 12 * step;
+          t[0] = ex; t[1] = ey; t[2] = eth;
+          t[3] = acc.h00; t[4] = acc.h01; t[5] = acc.h02;
+          t[6] = acc.h01; t[7] = acc.h11; t[8] = acc.h12;
+          t[9] = acc.h02; t[10] = acc.h12; t[11] = acc.h22;
+        }
+        ++step;
+      }
     }
     eth = normalize_angle(eth);                     // ScanMatcher.h:170
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);    // getWorldCoordsPose, :186

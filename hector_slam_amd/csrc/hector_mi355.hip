@@ -44,6 +44,12 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     if (e__ != hipSuccess) return fail(HSM_ERR_HIP, #expr, e__); \
   } while (0)
 
+// d_small / h_small layout (floats): [0,3) begin pose | [3,6) out pose | [6,15) out cov |
+// [16,28) eval H,dTr | [kTraceOff, kTraceOff + 12 * max steps) per-step trace
+constexpr int kTraceOff = 64;
+constexpr int kMaxTraceSteps = 6 + 4 * (HSM_MAX_LEVELS - 1);
+constexpr int kSmallFloats = kTraceOff + 12 * kMaxTraceSteps;
+
 struct Level {
   int sx = 0, sy = 0;
   float cell_length = 0.f, scale_to_map = 0.f;
@@ -89,6 +95,8 @@ struct hsm_ctx {
   // batch staging for the host-pointer convenience entry
   void* d_batch = nullptr;
   size_t d_batch_cap = 0;
+  void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
+  size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   int last_cfg[5] = {0, 0, 0, 0, 0};
 };
@@ -413,8 +421,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
 
   CREATE_TRY(hipSetDevice(h->device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipMalloc((void**)&h->d_small, 64 * sizeof(float)));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_small, 64 * sizeof(float), hipHostMallocDefault));
+  CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float), hipHostMallocDefault));
 
   // MapRepMultiMap ctor (MapRepMultiMap.h:48-72)
   int rx = size_x, ry = size_y;
@@ -464,6 +472,7 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_retained);
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);
+  (void)hipFree(h->d_cells);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -588,7 +597,7 @@ int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float
 
 // one scan on the first..last levels; pts are host, level-0 units (pt_scale applied per level)
 static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], const float2* d_pts, int n,
-                        float out_pose_world[3], float cov[9]) {
+                        float out_pose_world[3], float cov[9], float* trace = nullptr, int trace_steps = 0) {
   float* hs = h->h_small;
   hs[0] = begin_world[0];
   hs[1] = begin_world[1];
@@ -601,9 +610,14 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.shared_n = n;
   P.out_pose = h->d_small + 3;
   P.out_cov = h->d_small + 6;
+  P.trace = trace_steps > 0 ? h->d_small + kTraceOff : nullptr;
   if (int rc = launch_match(h, P, n, h->stream)) return rc;
   HIP_TRY(hipMemcpyAsync(hs + 3, h->d_small + 3, 12 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (trace_steps > 0)
+    HIP_TRY(hipMemcpyAsync(hs + kTraceOff, h->d_small + kTraceOff, (size_t)trace_steps * 12 * sizeof(float),
+                           hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
   out_pose_world[1] = hs[4];
   out_pose_world[2] = hs[5];
@@ -612,8 +626,26 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   return HSM_OK;
 }
 
+static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
+                      float out_pose_world[3], float cov[9], float* trace, int trace_steps);
+
 int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
               float out_pose_world[3], float cov[9]) {
+  return match_impl(h, begin_world, pts_xy, n, origo, out_pose_world, cov, nullptr, 0);
+}
+
+int hsm_match_trace(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
+                    float out_pose_world[3], float cov[9], float* trace, int trace_cap_steps, int* steps_written) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  const int steps = hsm_gn_iterations_per_match(h);
+  if (!trace || !steps_written || trace_cap_steps < steps)
+    return fail(HSM_ERR_INVALID, "hsm_match_trace: trace buffer smaller than hsm_gn_iterations_per_match()");
+  *steps_written = n > 0 ? steps : 0;
+  return match_impl(h, begin_world, pts_xy, n, origo, out_pose_world, cov, trace, n > 0 ? steps : 0);
+}
+
+static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
+                      float out_pose_world[3], float cov[9], float* trace, int trace_steps) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   if (!begin_world || !out_pose_world || n < 0 || (n > 0 && !pts_xy))
     return fail(HSM_ERR_INVALID, "hsm_match: bad argument");
@@ -634,7 +666,7 @@ int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n
   MatchParams P;
   memset(&P, 0, sizeof P);
   fill_schedule(h, P);
-  return match_single(h, P, begin_world, h->d_retained, n, out_pose_world, cov);
+  return match_single(h, P, begin_world, h->d_retained, n, out_pose_world, cov, trace, trace_steps);
 }
 
 int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy, int n,
@@ -765,6 +797,30 @@ int hsm_download_rows(hsm_ctx* h, int level, int y0, int y1, float* rows) {
   if (y1 > y0)
     HIP_TRY(hipMemcpy(rows, L.d_logodds + (size_t)y0 * L.sx, (size_t)(y1 - y0) * L.sx * sizeof(float),
                       hipMemcpyDeviceToHost));
+  return HSM_OK;
+}
+int hsm_download_cells(hsm_ctx* h, int level, int x0, int y0, int x1, int y1, void* dst_cells, int dst_pitch_cells) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  if (x0 < 0 || y0 < 0 || x1 >= L.sx || y1 >= L.sy || x1 < x0 || y1 < y0 || !dst_cells || dst_pitch_cells < x1 - x0 + 1)
+    return fail(HSM_ERR_INVALID, "hsm_download_cells: bad rectangle");
+  const int w = x1 - x0 + 1, hgt = y1 - y0 + 1;
+  const size_t need = (size_t)w * hgt * 8;
+  if (need > h->d_cells_cap) {
+    if (h->d_cells) HIP_TRY(hipFree(h->d_cells));
+    h->d_cells = nullptr;
+    h->d_cells_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_cells, need + need / 2));
+    h->d_cells_cap = need + need / 2;
+  }
+  hipLaunchKernelGGL(pack_cells_kernel, dim3(grid_for((size_t)w * hgt)), dim3(256), 0, h->stream, level_rw(L), x0, y0, w,
+                     hgt, reinterpret_cast<int2*>(h->d_cells));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy2DAsync(dst_cells, (size_t)dst_pitch_cells * 8, h->d_cells, (size_t)w * 8, (size_t)w * 8, hgt,
+                           hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }
 int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]) {

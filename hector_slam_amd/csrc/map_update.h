@@ -190,6 +190,16 @@ __global__ void fill_level_kernel(LevelRW L, float logodds, int update_index) {
   }
 }
 
+// rectangle (x0,y0,w,h) of the two SoA planes -> the reference's AoS LogOddsCell {float, int}
+__global__ void pack_cells_kernel(LevelRW L, int x0, int y0, int w, int h, int2* __restrict__ out) {
+  const size_t n = (size_t)w * h;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = x0 + (int)(i % (size_t)w), y = y0 + (int)(i / (size_t)w);
+    const size_t c = (size_t)y * L.sx + x;
+    out[i] = make_int2(__float_as_int(L.logodds[c]), L.update_index[c]);
+  }
+}
+
 __global__ void rebuild_prob_kernel(LevelRW L) {
   const size_t n = (size_t)L.sx * L.sy;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -86,6 +86,15 @@ int hsm_on_map_updated(hsm_ctx* h);
 int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n,
               const float origo[2], float out_pose_world[3], float cov[9]);
 
+/* hsm_match plus a per-GN-step trace for the reference's draw/debug hooks
+ * (ScanMatcher.h:100-110: drawArrow(estimate) and addHessianMatrix(H) per loop iteration).
+ * trace[12*k .. 12*k+11] = {map-frame estimate after step k [3], H used by step k [9] col-major},
+ * steps in schedule order (coarsest level first; 4 per coarse level, 6 on level 0).
+ * *steps_written = number of records (0 for an empty scan). */
+int hsm_match_trace(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n,
+                    const float origo[2], float out_pose_world[3], float cov[9], float* trace,
+                    int trace_cap_steps, int* steps_written);
+
 /* Batched extension (not in the reference): B independent (pose hypothesis, scan)
  * pairs against the read-only pyramid in ONE launch.  DEVICE pointers:
  *   d_begin_world  [B*3]       d_pts_xy [total*2]
@@ -126,6 +135,12 @@ int hsm_download_level(hsm_ctx* h, int level, float* logodds, int* update_index)
 int hsm_upload_level(hsm_ctx* h, int level, const float* logodds, const int* update_index);
 /* rows [y0, y1) of the log-odds plane only (cheap mirror refresh after an update) */
 int hsm_download_rows(hsm_ctx* h, int level, int y0, int y1, float* logodds_rows);
+/* cells [x0..x1] x [y0..y1] (inclusive) as the reference's LogOddsCell AoS
+ * {float logOddsVal; int updateIndex} (GridMapLogOdds.h:89-100), written to dst_cells (= address
+ * of cell (x0,y0) in a host grid whose rows are dst_pitch_cells cells apart): the host-mirror
+ * refresh behind getGridMap() */
+int hsm_download_cells(hsm_ctx* h, int level, int x0, int y0, int x1, int y1, void* dst_cells,
+                       int dst_pitch_cells);
 /* cell bounding box {x0, y0, x1, y1} (inclusive) touched by the last update of `level`;
  * x1 < x0 when nothing was touched */
 int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]);

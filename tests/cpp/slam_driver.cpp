@@ -1,0 +1,130 @@
+// slam_driver.cpp -- a stand-in for hector_mapping's ROS node (HectorMappingRos.cpp) that drives the
+// reference's UNCHANGED HectorSlamProcessor the way scanCallback / publishMap do, from a scenario
+// file.  TEST INFRASTRUCTURE.  The same source is compiled twice (oracle/Makefile):
+//   _ref/slam_driver_ref    against the reference's own include tree            (CPU reference)
+//   _ref/slam_driver_mi355  against an overlay of that tree in which only
+//                           slam_main/MapRepMultiMap.h is replaced by ours       (GPU drop-in)
+// and tests/test_facade_dropin.py compares what the two print.  Nothing here knows which one it is.
+//
+// scenario file (little endian): float res; int size, levels; float free, occ, minDist, minAng;
+//   int hooks, n_steps; then per step: float hint[3]; int use_last_pose, map_without_matching;
+//   float origo[2]; int n; float pts[2n]
+// output file: per step float pose[3], cov[9]; then hook log; then per level the mirror grid.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "slam_main/HectorSlamProcessor.h"
+
+namespace {
+
+struct Locker : public MapLockerInterface {
+  int locks = 0, unlocks = 0;
+  virtual void lockMap() { ++locks; }
+  virtual void unlockMap() { ++unlocks; }
+};
+
+std::vector<float> g_log;  // flat record of every hook call: tag, argc, args...
+
+struct Draw : public DrawInterface {
+  void rec(float tag, std::initializer_list<double> a) {
+    g_log.push_back(tag);
+    g_log.push_back((float)a.size());
+    for (double v : a) g_log.push_back((float)v);
+  }
+  virtual void drawPoint(const Eigen::Vector2f& p) { rec(1, {p[0], p[1]}); }
+  virtual void drawArrow(const Eigen::Vector3f& p) { rec(2, {p[0], p[1], p[2]}); }
+  virtual void drawCovariance(const Eigen::Vector2f& m, const Eigen::Matrix2f& c) { rec(3, {m[0], m[1], c(0, 0), c(1, 1)}); }
+  virtual void setScale(double s) { rec(4, {s}); }
+  virtual void setColor(double r, double g, double b, double a = 1.0) { rec(5, {r, g, b, a}); }
+  virtual void sendAndResetData() { rec(6, {}); }
+};
+
+struct Debug : public HectorDebugInfoInterface {
+  virtual void sendAndResetData() { g_log.push_back(7); g_log.push_back(0); }
+  virtual void addHessianMatrix(const Eigen::Matrix3f& H) {
+    g_log.push_back(8);
+    g_log.push_back(9);
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) g_log.push_back(H(r, c));
+  }
+  virtual void addPoseLikelihood(float lh) { g_log.push_back(9); g_log.push_back(1); g_log.push_back(lh); }
+};
+
+template <typename T> T rd(FILE* f) {
+  T v;
+  if (fread(&v, sizeof v, 1, f) != 1) { fprintf(stderr, "slam_driver: short scenario file\n"); exit(2); }
+  return v;
+}
+template <typename T> void wr(FILE* f, const T& v) { fwrite(&v, sizeof v, 1, f); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc != 3) { fprintf(stderr, "usage: %s scenario.bin out.bin\n", argv[0]); return 2; }
+  FILE* in = fopen(argv[1], "rb");
+  FILE* out = fopen(argv[2], "wb");
+  if (!in || !out) { perror("slam_driver"); return 2; }
+  const float res = rd<float>(in);
+  const int size = rd<int>(in), levels = rd<int>(in);
+  const float ffree = rd<float>(in), focc = rd<float>(in), minDist = rd<float>(in), minAng = rd<float>(in);
+  const int hooks = rd<int>(in), steps = rd<int>(in);
+
+  Draw draw;
+  Debug debug;
+  // HectorMappingRos.cpp:127-134
+  hectorslam::HectorSlamProcessor* slam = new hectorslam::HectorSlamProcessor(
+      res, size, size, Eigen::Vector2f(0.5f, 0.5f), levels, hooks ? &draw : 0, hooks ? &debug : 0);
+  slam->setUpdateFactorFree(ffree);
+  slam->setUpdateFactorOccupied(focc);
+  slam->setMapUpdateMinDistDiff(minDist);
+  slam->setMapUpdateMinAngleDiff(minAng);
+  Locker* locker = new Locker();  // owned by the map representation from here on
+  slam->addMapMutex(0, locker);
+
+  hectorslam::DataContainer scan;
+  for (int t = 0; t < steps; ++t) {
+    float hint[3];
+    for (int k = 0; k < 3; ++k) hint[k] = rd<float>(in);
+    const int use_last = rd<int>(in), mwm = rd<int>(in);
+    const float ox = rd<float>(in), oy = rd<float>(in);
+    const int n = rd<int>(in);
+    scan.clear();
+    scan.setOrigo(Eigen::Vector2f(ox, oy));
+    for (int i = 0; i < n; ++i) {
+      const float x = rd<float>(in), y = rd<float>(in);
+      scan.add(Eigen::Vector2f(x, y));
+    }
+    // scanCallback: start estimate = last pose (+ the scenario's odometry delta) or the given hint
+    Eigen::Vector3f start(hint[0], hint[1], hint[2]);
+    if (use_last) start += slam->getLastScanMatchPose();
+    slam->update(scan, start, mwm != 0);
+    const Eigen::Vector3f& p = slam->getLastScanMatchPose();
+    const Eigen::Matrix3f& c = slam->getLastScanMatchCovariance();
+    for (int k = 0; k < 3; ++k) wr(out, p[k]);
+    for (int k = 0; k < 9; ++k) wr(out, c(k % 3, k / 3));
+  }
+  wr(out, (int)g_log.size());
+  if (!g_log.empty()) fwrite(&g_log[0], sizeof(float), g_log.size(), out);
+  wr(out, locker->locks);
+  wr(out, locker->unlocks);
+  wr(out, slam->getScaleToMap());
+  wr(out, slam->getMapLevels());
+  // publishMap (HectorMappingRos.cpp:435-481): read every cell of every level through getGridMap()
+  for (int l = 0; l < slam->getMapLevels(); ++l) {
+    const hectorslam::GridMap& g = slam->getGridMap(l);
+    wr(out, g.getSizeX());
+    wr(out, g.getSizeY());
+    wr(out, g.getCellLength());
+    wr(out, g.getUpdateIndex());
+    const int cells = g.getSizeX() * g.getSizeY();
+    for (int i = 0; i < cells; ++i) {
+      const signed char occ = g.isOccupied(i) ? 100 : (g.isFree(i) ? 0 : -1);
+      wr(out, occ);
+    }
+    for (int i = 0; i < cells; ++i) wr(out, g.getCell(i).getValue());
+  }
+  delete slam;
+  fclose(in);
+  fclose(out);
+  return 0;
+}

@@ -1,0 +1,166 @@
+"""Drop-in proof for the C++ boundary: tests/cpp/slam_driver.cpp drives the reference's
+UNCHANGED HectorSlamProcessor.h like the ROS node does.  oracle/Makefile compiles that one source twice:
+
+  oracle/_ref/slam_driver_ref    reference include tree only                       -> CPU reference
+  oracle/_ref/slam_driver_mi355  same tree with slam_main/MapRepMultiMap.h replaced by
+                                 include/hector_slam_lib/slam_main/MapRepMultiMap.h   -> MI355X drop-in
+
+Both binaries are built in the build container (where /root/reference exists) and travel to the GPU
+box with the snapshot.  CPU tests pin the driver against the oracle; the gpu test runs both binaries
+on the same scenario and compares poses (1e-4 m / 1e-4 rad), covariances, the draw/debug hook
+streams, locker usage and the host-mirror grids the map publisher would read.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ang_diff, make_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "slam_driver_ref")
+GPU_BIN = os.path.join(ROOT, "oracle", "_ref", "slam_driver_mi355")
+FACADE = os.path.join(ROOT, "include", "hector_slam_lib", "slam_main", "MapRepMultiMap.h")
+
+
+def write_scenario(path, sc, steps, hooks, min_dist=0.05, min_ang=0.02, origo=(0.3, -0.1), mwm_at=(7,)):
+    s = np.float32(sc.scale_to_map)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<fiiffffii", sc.resolution, sc.map_size, sc.levels, 0.4, 0.9, min_dist, min_ang,
+                            1 if hooks else 0, steps))
+        for t in range(steps):
+            if t == 0:
+                hint, use_last = sc.build_poses[0], 0
+            else:  # odometry delta on top of the last matched pose, like scanCallback's start estimate
+                hint, use_last = sc.build_poses[t] - sc.build_poses[t - 1], 1
+            pts = np.ascontiguousarray(sc.build_scans[t], np.float32)
+            f.write(struct.pack("<fffii", *[float(v) for v in hint], use_last, 1 if t in mwm_at else 0))
+            f.write(struct.pack("<ffi", float(origo[0] * s), float(origo[1] * s), pts.shape[0]))
+            f.write(pts.tobytes())
+
+
+def read_output(path, steps):
+    buf = open(path, "rb").read()
+    off = 0
+    pc = np.frombuffer(buf, np.float32, steps * 12, off).reshape(steps, 12)
+    off += steps * 48
+    (nlog,) = struct.unpack_from("<i", buf, off)
+    off += 4
+    log = np.frombuffer(buf, np.float32, nlog, off)
+    off += 4 * nlog
+    locks, unlocks, scale, levels = struct.unpack_from("<iifi", buf, off)
+    off += 16
+    grids = []
+    for _ in range(levels):
+        sx, sy, cell, upd = struct.unpack_from("<iifi", buf, off)
+        off += 16
+        occ = np.frombuffer(buf, np.int8, sx * sy, off).reshape(sy, sx)
+        off += sx * sy
+        val = np.frombuffer(buf, np.float32, sx * sy, off).reshape(sy, sx)
+        off += 4 * sx * sy
+        grids.append(dict(sx=sx, sy=sy, cell=cell, update_index=upd, occ=occ, val=val))
+    assert off == len(buf)
+    return dict(pose=pc[:, :3], cov=pc[:, 3:], log=log, locks=locks, unlocks=unlocks, scale=scale, grids=grids)
+
+
+def parse_log(log):
+    calls, i = [], 0
+    while i < len(log):
+        tag, n = int(log[i]), int(log[i + 1])
+        calls.append((tag, log[i + 2:i + 2 + n]))
+        i += 2 + n
+    return calls
+
+
+def run(binary, scenario, out):
+    r = subprocess.run([binary, scenario, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/slam_driver_ref not built")
+
+
+def test_facade_is_source_only_forwarding():
+    """the facade has no compute path of its own: it forwards to the C ABI and nothing else"""
+    src = open(FACADE).read()
+    for sym in ("hsm_create", "hsm_match", "hsm_match_trace", "hsm_update_by_scan", "hsm_download_cells",
+                "hsm_set_update_factor_free", "hsm_set_update_factor_occupied", "hsm_reset", "hsm_destroy"):
+        assert sym in src
+    for forbidden in ("interpMapValueWithDerivatives", "getCompleteHessianDerivs", "ScanMatcher", "oracle"):
+        assert forbidden not in src.replace("ScanMatcher.h", "").replace("ScanMatcher::", ""), forbidden
+    assert "class MapRepMultiMap : public MapRepresentationInterface" in src
+
+
+@needs_ref
+def test_reference_driver_matches_oracle(tmp_path, oracle_mod, pyramid_scene):
+    """pins the driver + scenario format: the reference binary == the oracle's HectorSlamProcessor loop"""
+    sc, steps = pyramid_scene, 12
+    scen, out = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    write_scenario(scen, sc, steps, hooks=False)
+    run(REF_BIN, scen, out)
+    r = read_output(out, steps)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o.proc_set_thresholds(0.05, 0.02)
+    origo = np.array([0.3, -0.1], np.float32) * np.float32(sc.scale_to_map)
+    last = np.zeros(3, np.float32)
+    for t in range(steps):
+        hint = sc.build_poses[0] if t == 0 else (sc.build_poses[t] - sc.build_poses[t - 1]) + last
+        o.proc_update(sc.build_scans[t], hint.astype(np.float32), origo=origo, map_without_matching=(t == 7))
+        last, cov = o.proc_last_pose()
+        assert np.array_equal(last.view(np.uint32), r["pose"][t].view(np.uint32)), t
+    for lvl in range(sc.levels):
+        lo, _ = o.download_level(lvl)
+        assert np.array_equal(lo.view(np.uint32), r["grids"][lvl]["val"].view(np.uint32))
+    assert r["locks"] == r["unlocks"] > 0
+
+
+@needs_ref
+def test_hook_stream_of_reference_driver(tmp_path, pyramid_scene):
+    sc, steps = pyramid_scene, 4
+    scen, out = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    write_scenario(scen, sc, steps, hooks=True, mwm_at=())
+    run(REF_BIN, scen, out)
+    calls = parse_log(read_output(out, steps)["log"])
+    # per update: 3+3+5 addHessianMatrix, one debug send, one draw send
+    assert sum(1 for t, _ in calls if t == 8) == steps * 11
+    assert sum(1 for t, _ in calls if t == 6) == steps and sum(1 for t, _ in calls if t == 7) == steps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hooks", [False, True])
+def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
+    assert os.path.exists(GPU_BIN) and os.path.exists(REF_BIN), "drivers must be prebuilt by build()"
+    sc, steps = pyramid_scene, 25
+    scen = str(tmp_path / "s.bin")
+    write_scenario(scen, sc, steps, hooks=hooks)
+    run(REF_BIN, scen, str(tmp_path / "ref.bin"))
+    stdout = run(GPU_BIN, scen, str(tmp_path / "gpu.bin"))
+    assert "MI355X resident" in stdout  # the facade's banner: proves which MapRepMultiMap was compiled in
+    r, g = read_output(str(tmp_path / "ref.bin"), steps), read_output(str(tmp_path / "gpu.bin"), steps)
+    dxy = np.abs(r["pose"][:, :2].astype(np.float64) - g["pose"][:, :2]).max()
+    dth = ang_diff(r["pose"][:, 2], g["pose"][:, 2]).max()
+    assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
+    assert np.abs(r["cov"] - g["cov"]).max() <= 1e-3 * np.abs(r["cov"]).max()
+    assert (g["locks"], g["unlocks"]) == (r["locks"], r["unlocks"])
+    assert g["scale"] == r["scale"] and len(g["grids"]) == len(r["grids"])
+    for a, b in zip(r["grids"], g["grids"]):
+        assert (a["sx"], a["sy"], a["cell"], a["update_index"]) == (b["sx"], b["sy"], b["cell"], b["update_index"])
+        touched = (a["val"] != 0).sum()
+        assert touched > 1000
+        # poses differ in the last bits -> a handful of Bresenham end cells may flip
+        assert (a["val"].view(np.uint32) != b["val"].view(np.uint32)).sum() <= 0.002 * touched
+        assert (a["occ"] != b["occ"]).sum() <= 0.002 * touched
+    ca, cb = parse_log(r["log"]), parse_log(g["log"])
+    assert [t for t, _ in ca] == [t for t, _ in cb]  # identical hook call sequence
+    if hooks:
+        assert len(ca) > 1000
+        for (t, x), (_, y) in zip(ca, cb):
+            if t == 8:    # Hessians
+                assert np.abs(x - y).max() <= 1e-3 * max(np.abs(x).max(), 1.0)
+            elif t in (1, 2):  # drawn points / arrows, world frame
+                assert np.abs(x[:2] - y[:2]).max() <= 2e-4
+            else:
+                assert np.array_equal(x, y)

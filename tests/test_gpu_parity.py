@@ -32,6 +32,14 @@ def assert_pose_close(p, q, what=""):
     return dxy, dth
 
 
+def assert_dtr_close(d, dr, H, n):
+    """dTr_k = sum_i g_ik * f_i is a sum of CANCELLING terms near convergence, so its error scales with
+    the sum of |terms| <= sqrt(H_kk * n) (Cauchy-Schwarz, f_i <= 1), not with |dTr_k|: both the
+    reference's sequential fp32 chain and the device's tree carry ~eps * sqrt(n) of that."""
+    tol = 2e-5 * np.abs(dr) + 1e-7 * np.sqrt(np.abs(np.diag(H)) * n)
+    assert (np.abs(d - dr) <= tol).all(), (d, dr, tol)
+
+
 @pytest.fixture(scope="module")
 def capi():
     import torch
@@ -181,7 +189,7 @@ def test_hessian_derivs_match_oracle(pyr, pyramid_scene):
             Ho, do = o.hessian_derivs(lvl, pm, pts)
             scale = np.abs(Ho).max()
             assert np.abs(Hg - Ho).max() <= 2e-5 * scale
-            assert np.abs(dg - do).max() <= 2e-5 * max(np.abs(do).max(), 1e-3 * np.sqrt(scale))
+            assert_dtr_close(dg, do, Ho, pts.shape[0])
             assert np.array_equal(Hg, Hg.T)
 
 
@@ -241,10 +249,29 @@ def test_far_starts_clamp_and_out_of_map_beams(pyr, pyramid_scene):
         assert_pose_close(pg, po, f"first step q{q}")
         pg, _ = g.matchData(init, sc.query_scans[q])
         assert np.isfinite(pg).all()
+    # start near the map border: ~80 % of the beams fall outside the map and contribute exact zeros.
+    # What is left is (nearly) rank deficient -- cond(H) ~ 1e10, so the reference's OWN fp32 solve is
+    # rounding noise there (it jumps 2.5 m) and the pose cannot be a parity target.  The out-of-map
+    # handling itself is checked where it is well defined: per-beam terms bit-exact, H/dTr to
+    # summation-order accuracy, and the step stays finite.
     far = np.array([11.5, 9.0, 0.3], np.float32)
-    pg, _ = g.match_level(0, far, sc.query_scans[0], 0)
-    po, _ = o.match_level(0, far, sc.query_scans[0], 0)
-    assert_pose_close(pg, po, "border start")
+    pm = o.map_coords_pose(0, far)
+    pts = sc.query_scans[0]
+    s_, c_ = np.float32(np.sin(np.float64(pm[2]))), np.float32(np.cos(np.float64(pm[2])))
+    tx = pm[0] + (c_ * pts[:, 0] + (-s_) * pts[:, 1])
+    ty = pm[1] + (s_ * pts[:, 0] + c_ * pts[:, 1])
+    ref = o.interp(0, np.stack([tx, ty], 1).astype(np.float32))
+    oob = (tx < 0) | (tx > sc.map_size - 2) | (ty < 0) | (ty > sc.map_size - 2)
+    assert 0.5 < oob.mean() < 0.95 and not ref[oob].any()
+    got = g.eval_beams(0, pm, pts)
+    assert np.array_equal(bits(got[:, :3]), bits(ref))
+    Hg, dg = g.hessian_derivs(0, pm, pts)
+    Ho, do = o.hessian_derivs(0, pm, pts)
+    assert np.abs(Hg - Ho).max() <= 2e-5 * np.abs(Ho).max()
+    assert_dtr_close(dg, do, Ho, pts.shape[0])
+    assert np.linalg.cond(Ho.astype(np.float64)) > 1e8
+    pg, _ = g.match_level(0, far, pts, 0)
+    assert np.isfinite(pg).all()
 
 
 # ---------------------------------------------------------------- batched path
@@ -397,7 +424,7 @@ def test_golden_config1(capi):
             H, d = g.hessian_derivs(0, g1[f"q{q}_step_pose_map"][k], pts)
             Hr, dr = g1[f"q{q}_step_H"][k], g1[f"q{q}_step_dTr"][k]
             assert np.abs(H - Hr).max() <= 2e-5 * np.abs(Hr).max()
-            assert np.abs(d - dr).max() <= 2e-5 * max(np.abs(dr).max(), 1e-3 * np.sqrt(np.abs(Hr).max()))
+            assert_dtr_close(d, dr, Hr, pts.shape[0])
 
 
 def test_golden_pyramid(capi):
