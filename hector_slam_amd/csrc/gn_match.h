@@ -48,9 +48,11 @@ struct Affine2 {
 
 // read-only view of one pyramid level for the matcher
 struct LevelView {
-  const float4* quad;  // [sy*sx] texels {P00,P10,P01,P11}
-  const float* prob;   // [sy*sx] plain probability plane
+  const float4* quad;  // texels {P00,P10,P01,P11}, tiled (quad_index), + one all-zero texel at quad_texels
+  const float* prob;   // [sy*sx] plain probability plane (row major) + sx+2 zero cells
   int sx, sy;
+  int tiles_x;         // quad tiles per row = ceil(sx / 4)
+  int quad_texels;     // tiles_x * ceil(sy / 2) * 8
   float limx, limy;    // dims - 2  (MapDimensionProperties.h:70-74)
   Affine2 mapTworld;   // GridMapBase.h:272
   Affine2 worldTmap;   // GridMapBase.h:279
@@ -72,6 +74,31 @@ struct MatchParams {
   float* trace;              // nullptr, or [steps*12] per-GN-step record of scan 0 (draw/debug hooks):
                              // {map-frame estimate after the step [3], H of that step [9] col-major}
 };
+
+// Texel address of cell (x, y) in the quad plane.
+// HSM_QUAD_TILE == 0 (default): row major, index = y*sizeX + x like the reference's grid -- one
+//   v_mad_u32_u24 per beam.
+// HSM_QUAD_TILE == 1: 4x2-cell tiles (= eight 16-byte texels = one 128-byte line), Morton order
+//   inside (x0, y0, x1), which cuts the cache-line requests of a gather along a wall by about a
+//   third but costs five more integer VALU ops per beam.  Measured on MI355X the matcher is
+//   VALU-issue bound and both variants run at the same speed (profiles/r01/kernel_ab_tile.jsonl),
+//   so the simpler one is the default; the switch is kept for maps that outgrow the L2.
+#ifndef HSM_QUAD_TILE
+#define HSM_QUAD_TILE 0
+#endif
+__host__ __device__ __forceinline__ unsigned quad_index(unsigned x, unsigned y, int tiles_x, int sx) {
+#if HSM_QUAD_TILE
+  (void)sx;
+  return ((((y >> 1) * (unsigned)tiles_x) + (x >> 2)) << 3) | ((x & 2) << 1) | ((y & 1) << 1) | (x & 1);
+#else
+  (void)tiles_x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(y, (unsigned)sx) + x;
+#else
+  return y * (unsigned)sx + x;
+#endif
+#endif
+}
 
 // Transform<Affine> * Vector2f = t + (l(i,0)*x + l(i,1)*y)   (Eigen Transform.h)
 __device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y, float& ox, float& oy) {
@@ -128,135 +155,212 @@ __device__ __forceinline__ float normalize_angle(float angle) {
   return a;
 }
 
-struct BeamTerms {
-  float M, gx, gy;
+// The LevelView fields the beam loop reads, pulled into registers ONCE per level (the kernel
+// argument block lives in memory; re-reading it per beam costs a scalar load + wait each time).
+struct LevelRegs {
+  const float4* quad;
+  const float* prob;
+  int sx;
+  int tiles_x;
+  float limx, limy;
+  int zero_index;  // index of the all-zero texel / pad cells behind the plane (see sample_fetch)
 };
+
+template <int LAYOUT>
+__device__ __forceinline__ LevelRegs level_regs(const LevelView& L) {
+  LevelRegs R;
+  R.quad = L.quad;
+  R.prob = L.prob;
+  R.sx = L.sx;
+  R.tiles_x = L.tiles_x;
+  R.limx = L.limx;
+  R.limy = L.limy;
+  R.zero_index = LAYOUT == kLayoutQuad ? L.quad_texels : L.sx * L.sy;
+  return R;
+}
 
 // a1, split in two so that a lane can ISSUE the texel gathers of several beams back to back
 // (stage 1) before it CONSUMES any of them (stage 2): memory latency is hidden by
 // instruction-level parallelism inside the wavefront, not only by occupancy.
+// Two fp32 values kept together (storage only).  Measured on MI355X (tools/microbench/valu_rate.hip,
+// profiles/r01/valu_rate.txt): v_mul/v_add/v_fma_f32 issue every ~2.5 cycles per wave64, while
+// v_pk_mul/v_pk_add_f32 -- and v_med3, v_fract, v_cvt, v_mad_u32_u24 -- take ~4: a packed op is
+// worth 1.6 scalar ones, which the v_mov shuffles needed to form pairs eat up again.  So the
+// arithmetic below is plain scalar fp32 and the library is built with -fno-slp-vectorize.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct BeamSample {
-  float i0, i1, i2, i3;  // P(ix,iy), P(ix+1,iy), P(ix,iy+1), P(ix+1,iy+1)
-  float fx, fy;
-  bool oob;
+  f2 lo, hi;  // (P(ix,iy), P(ix+1,iy)), (P(ix,iy+1), P(ix+1,iy+1))
+  f2 X, Y;    // (xFacInv, fx), (yFacInv, fy)  -- OccGridMapUtil.h:298,338-339
 };
 
-// stage 1: bounds test, cell index, fractions, and the (asynchronous) gather
+// stage 1: bounds test, cell index, fractions, and the (asynchronous) gather.
+//
+// Out-of-map beams (MapDimensionProperties::pointOutOfMapBounds, MapDimensionProperties.h:65-68)
+// must contribute EXACT zeros, like the (0,0,0) the reference returns at OccGridMapUtil.h:290-292.
+// They are pointed at an all-zero texel stored behind the plane: P00=P10=P01=P11=0 gives
+// dM/dx = dM/dy = -0 and M = 0, so every product added to H and dTr is +-0 and the running fp32
+// sums are unchanged bit for bit -- the same outcome as the reference's explicit zeros, without a
+// branch or three selects per beam.  The matcher is VALU-issue bound (profiles/r01), so the test
+// itself is written for instruction count: v_med3_f32 clamps the coordinate into [0, dims-2]; the
+// beam is outside exactly when the clamp changed it (x < 0 or x > dims-2, as in the reference),
+// and the clamped value doubles as the finite stand-in coordinate of an outside beam.  A NaN
+// coordinate never equals its clamp, so it counts as outside (the reference would index the map
+// with (int)NaN there and crash).  v_fract_f32(x) == x - (float)(int)x exactly for 0 <= x < 2^23.
 template <int LAYOUT>
-__device__ __forceinline__ BeamSample sample_fetch(const LevelView& L, float cx, float cy, bool live = true) {
+__device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
   BeamSample b;
-  // MapDimensionProperties::pointOutOfMapBounds (MapDimensionProperties.h:65-68); `live` is false
-  // for the padding slots of a lane that has fewer beams than its register file holds: they
-  // take the same exact-zero path as an out-of-map beam
-  b.oob = !live || (cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy);
-  // out-of-map lanes sample texel 0 and are zeroed in stage 2 (the reference returns (0,0,0))
-  const float sx_ = b.oob ? 0.0f : cx;
-  const float sy_ = b.oob ? 0.0f : cy;
-  const int ix = (int)sx_;  // truncation, OccGridMapUtil.h:295
-  const int iy = (int)sy_;
-  b.fx = sx_ - (float)ix;  // :298
-  b.fy = sy_ - (float)iy;
-  const int index = iy * L.sx + ix;  // :302
+  const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, L.limx);
+  const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, L.limy);
+  const bool oob = (sx_ != c.x) | (sy_ != c.y);
+  const unsigned ix = (unsigned)(int)sx_;  // truncation, OccGridMapUtil.h:295
+  const unsigned iy = (unsigned)(int)sy_;
+  b.X.y = __builtin_amdgcn_fractf(sx_);  // :298
+  b.Y.y = __builtin_amdgcn_fractf(sy_);
+  b.X.x = 1.0f - b.X.y;  // :338-339
+  b.Y.x = 1.0f - b.Y.y;
   if (LAYOUT == kLayoutQuad) {
-    const float4 q = L.quad[index];
-    b.i0 = q.x;
-    b.i1 = q.y;
-    b.i2 = q.z;
-    b.i3 = q.w;
+    const unsigned index = oob ? (unsigned)L.zero_index : quad_index(ix, iy, L.tiles_x, L.sx);
+    // 32-bit byte offset on a uniform base: one global_load_dwordx4 with an SGPR base address
+    const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(index << 4));
+    b.lo = f2{q.x, q.y};
+    b.hi = f2{q.z, q.w};
   } else {
-    // indices index, index+1, index+sizeX, index+sizeX+1 (:306-330).  A NaN coordinate
-    // passes the bounds test like in the reference; v_cvt_i32_f32(NaN) = 0 keeps the
-    // address inside the plane and the NaN fraction poisons the result as it should.
-    const float* p = L.prob + index;
-    b.i0 = p[0];
-    b.i1 = p[1];
-    b.i2 = p[L.sx];
-    b.i3 = p[L.sx + 1];
+    // indices index, index+1, index+sizeX, index+sizeX+1 (:302-330); the plane is followed by
+    // sizeX+2 zero cells so that the zero_index footprint is all zeros too
+    const unsigned index = oob ? (unsigned)L.zero_index : __umul24(iy, (unsigned)L.sx) + ix;
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.prob) + (size_t)(index << 2));
+    b.lo = f2{p[0], p[1]};
+    b.hi = f2{p[L.sx], p[L.sx + 1]};
   }
   return b;
 }
 
-// stage 2: the interpolation and the source-literal "derivatives" (:332-346)
+// stage 2: the interpolation and the source-literal "derivatives" (:332-346):
+//   M  = ((P00*xFacInv + P10*fx) * yFacInv) + ((P01*xFacInv + P11*fx) * fy)
+//   gx = -((P00-P10)*xFacInv + (P01-P11)*fx)      gy = -((P00-P01)*yFacInv + (P10-P11)*fy)
+// (x-differences blended with the x fractions, as the source does -- SURVEY.md row a1).
+// Returned as M and G = (-gx, -gy): the two negations of the source are exact sign flips, and
+// every consumer below absorbs them into an operand-negate modifier or a product of two of them.
+struct BeamTerms {
+  float M;
+  f2 G;  // (-dM/dx, -dM/dy) as the source defines them
+};
+
 __device__ __forceinline__ BeamTerms sample_finish(const BeamSample& b) {
-  const float dx1 = b.i0 - b.i1;  // :332-336
-  const float dx2 = b.i2 - b.i3;
-  const float dy1 = b.i0 - b.i2;
-  const float dy2 = b.i1 - b.i3;
-  const float xFacInv = (1.0f - b.fx);  // :338-339
-  const float yFacInv = (1.0f - b.fy);
+  const float xFacInv = b.X.x, fx = b.X.y, yFacInv = b.Y.x, fy = b.Y.y;
+  const float i0 = b.lo.x, i1 = b.lo.y, i2 = b.hi.x, i3 = b.hi.y;
+  const float dx1 = i0 - i1;  // :332-336
+  const float dx2 = i2 - i3;
+  const float dy1 = i0 - i2;
+  const float dy2 = i1 - i3;
   BeamTerms r;
-  // :341-346, source-literal (x-differences blended with the x fractions)
-  r.M = ((b.i0 * xFacInv + b.i1 * b.fx) * (yFacInv)) + ((b.i2 * xFacInv + b.i3 * b.fx) * (b.fy));
-  r.gx = -((dx1 * xFacInv) + (dx2 * b.fx));
-  r.gy = -((dy1 * yFacInv) + (dy2 * b.fy));
-  if (b.oob) {
-    r.M = 0.0f;
-    r.gx = 0.0f;
-    r.gy = 0.0f;
-  }
+  r.M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));  // :341-344
+  r.G.x = ((dx1 * xFacInv) + (dx2 * fx));  // -gx  :345
+  r.G.y = ((dy1 * yFacInv) + (dy2 * fy));  // -gy  :346
   return r;
 }
 
-// per-beam contribution to (dTr, H) -- OccGridMapUtil.h:76-98
+// per-beam contribution to (dTr, H) -- OccGridMapUtil.h:76-98; paired accumulators
 struct Acc9 {
-  float d0, d1, d2, h00, h11, h22, h01, h02, h12;
-  __device__ __forceinline__ void zero() { d0 = d1 = d2 = h00 = h11 = h22 = h01 = h02 = h12 = 0.0f; }
+  f2 d01;   // dTr[0], dTr[1]
+  f2 hd;    // H(0,0), H(1,1)
+  f2 hr;    // H(0,2), H(1,2)
+  float d2, h22, h01;
+  __device__ __forceinline__ void zero() {
+    d01 = hd = hr = f2{0.0f, 0.0f};
+    d2 = h22 = h01 = 0.0f;
+  }
 };
 
-// transform * currPoint with transform = Translation(ex,ey) * Rotation(theta): linear [c -s; s c]
+// The rotated endpoint R(theta) * p, shared by the transform and by rotDeriv:
+//   transform * currPoint   = t + [c -s; s c] p = (ex + (c*px + (-s)*py), ey + (s*px + c*py))   (:80)
+//   rotDeriv (:87)          = (-s*px - c*py) * gx + (c*px - s*py) * gy
+// In IEEE arithmetic (-s)*py == -(s*py) and a + (-b) == a - b exactly, and round-to-nearest is
+// symmetric, so  c*px + (-s)*py == c*px - s*py == rx  and  -s*px - c*py == -(s*px + c*py) == -ry
+// BIT FOR BIT: the two products/one sum per component are computed once and reused.
+struct BeamRot {
+  f2 r;  // (rx, ry)
+};
+
+// cs = (cos, sin), sc = (sin, cos) of the current estimate; e = (ex, ey); p = endpoint
 template <int LAYOUT>
-__device__ __forceinline__ BeamSample beam_fetch(const LevelView& L, float ex, float ey, float sinRot,
-                                                 float cosRot, float px, float py, bool live = true) {
-  const float tx = ex + (cosRot * px + (-sinRot) * py);
-  const float ty = ey + (sinRot * px + cosRot * py);
-  return sample_fetch<LAYOUT>(L, tx, ty, live);
+__device__ __forceinline__ BeamSample beam_fetch(const LevelRegs& L, f2 e, f2 cs, f2 sc, f2 p, BeamRot& r) {
+  r.r.x = cs.x * p.x - sc.x * p.y;  // c*px - s*py
+  r.r.y = cs.y * p.x + sc.y * p.y;  // s*px + c*py
+  return sample_fetch<LAYOUT>(L, f2{e.x + r.r.x, e.y + r.r.y});
 }
 
-__device__ __forceinline__ float beam_finish(const BeamSample& b, float sinRot, float cosRot, float px, float py,
-                                             Acc9& a, BeamTerms* terms_out = nullptr) {
+// With g = -G (the source's gx, gy) and rd = rotDeriv, in IEEE arithmetic:
+//   rd      = (-ry)*gx + rx*gy = ry*Gx - rx*Gy          (sign flips are exact)
+//   dTr    += g*funVal, rd*funVal  ==  dTr -= G*funVal  (a + (-b) == a - b)
+//   H      += g*g, gx*gy           ==  G*G, Gx*Gy
+//   H(.,2) += g*rd                 ==  H(.,2) -= G*rd
+__device__ __forceinline__ float beam_finish(const BeamSample& b, const BeamRot& r, Acc9& a,
+                                             BeamTerms* terms_out = nullptr) {
   const BeamTerms t = sample_finish(b);
+  const float Gx = t.G.x, Gy = t.G.y;
   const float funVal = 1.0f - t.M;
-  a.d0 += t.gx * funVal;
-  a.d1 += t.gy * funVal;
-  const float rotDeriv = ((-sinRot * px - cosRot * py) * t.gx + (cosRot * px - sinRot * py) * t.gy);  // :87
+  const float rotDeriv = r.r.y * Gx - r.r.x * Gy;  // :87
+  a.d01.x -= Gx * funVal;
+  a.d01.y -= Gy * funVal;
   a.d2 += rotDeriv * funVal;
-  a.h00 += t.gx * t.gx;
-  a.h11 += t.gy * t.gy;
+  a.hd.x += Gx * Gx;
+  a.hd.y += Gy * Gy;
   a.h22 += rotDeriv * rotDeriv;
-  a.h01 += t.gx * t.gy;
-  a.h02 += t.gx * rotDeriv;
-  a.h12 += t.gy * rotDeriv;
+  a.h01 += Gx * Gy;
+  a.hr.x -= Gx * rotDeriv;
+  a.hr.y -= Gy * rotDeriv;
   if (terms_out) *terms_out = t;
   return rotDeriv;
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ float beam_accumulate(const LevelView& L, float ex, float ey, float sinRot,
+__device__ __forceinline__ float beam_accumulate(const LevelRegs& L, float ex, float ey, float sinRot,
                                                  float cosRot, float px, float py, Acc9& a,
-                                                 BeamTerms* terms_out = nullptr, bool live = true) {
-  const BeamSample b = beam_fetch<LAYOUT>(L, ex, ey, sinRot, cosRot, px, py, live);
-  return beam_finish(b, sinRot, cosRot, px, py, a, terms_out);
+                                                 BeamTerms* terms_out = nullptr) {
+  BeamRot r;
+  const BeamSample b = beam_fetch<LAYOUT>(L, f2{ex, ey}, f2{cosRot, sinRot}, f2{sinRot, cosRot}, f2{px, py}, r);
+  return beam_finish(b, r, a, terms_out);
+}
+
+// Wavefront all-reduce without LDS traffic: four DPP steps inside each row of 16 lanes (the
+// cross-lane operand rides on the v_add itself), then the two gfx950 row/half swaps
+// (v_permlane16_swap, v_permlane32_swap).  Every lane ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ float wave_allreduce(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f32<0x141>(v);  // row_half_mirror: the other quad of the 8-lane half row
+  v += dpp_f32<0x140>(v);  // row_mirror: the other half of the 16-lane row
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(r[0]) + __int_as_float(r[1]);  // rows 0+1, 2+3
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(r[0]) + __int_as_float(r[1]);  // lower + upper 32 lanes
+  }
   return v;
 }
 
 __device__ __forceinline__ void wave_allreduce9(Acc9& a) {
-  a.d0 = wave_allreduce(a.d0);
-  a.d1 = wave_allreduce(a.d1);
+  a.d01.x = wave_allreduce(a.d01.x);
+  a.d01.y = wave_allreduce(a.d01.y);
   a.d2 = wave_allreduce(a.d2);
-  a.h00 = wave_allreduce(a.h00);
-  a.h11 = wave_allreduce(a.h11);
+  a.hd.x = wave_allreduce(a.hd.x);
+  a.hd.y = wave_allreduce(a.hd.y);
   a.h22 = wave_allreduce(a.h22);
   a.h01 = wave_allreduce(a.h01);
-  a.h02 = wave_allreduce(a.h02);
-  a.h12 = wave_allreduce(a.h12);
+  a.hr.x = wave_allreduce(a.hr.x);
+  a.hr.y = wave_allreduce(a.hr.y);
 }
 
-// team-wide totals: wave butterfly, then (WPS > 1) LDS staging of the per-wave
+// team-wide totals: wave all-reduce, then (WPS > 1) LDS staging of the per-wave
 // partials; every thread of the team returns with identical bits.
 template <int WPS>
 __device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[WPS][9], int buf, int wave_in_team,
@@ -265,9 +369,9 @@ __device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[WPS][9], i
   if (WPS > 1) {
     if (lane == 0) {
       float* r = red[buf][wave_in_team];
-      r[0] = a.d0; r[1] = a.d1; r[2] = a.d2;
-      r[3] = a.h00; r[4] = a.h11; r[5] = a.h22;
-      r[6] = a.h01; r[7] = a.h02; r[8] = a.h12;
+      r[0] = a.d01.x; r[1] = a.d01.y; r[2] = a.d2;
+      r[3] = a.hd.x; r[4] = a.hd.y; r[5] = a.h22;
+      r[6] = a.h01; r[7] = a.hr.x; r[8] = a.hr.y;
     }
     __syncthreads();
     float t[9];
@@ -278,20 +382,20 @@ __device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[WPS][9], i
 #pragma unroll
       for (int k = 0; k < 9; ++k) t[k] += red[buf][w][k];
     }
-    a.d0 = t[0]; a.d1 = t[1]; a.d2 = t[2];
-    a.h00 = t[3]; a.h11 = t[4]; a.h22 = t[5];
-    a.h01 = t[6]; a.h02 = t[7]; a.h12 = t[8];
+    a.d01 = f2{t[0], t[1]}; a.d2 = t[2];
+    a.hd = f2{t[3], t[4]}; a.h22 = t[5];
+    a.h01 = t[6]; a.hr = f2{t[7], t[8]};
   }
 }
 
 // H.inverse() * dTr as Eigen evaluates it (LU/InverseImpl.h cofactors * invdet, then a
 // coefficient-based product; 3-term sums are x0 + (x1 + x2)), ScanMatcher.h:201-217.
 __device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, float& ey, float& eth) {
-  if ((a.h00 != 0.0f) && (a.h11 != 0.0f)) {
+  if ((a.hd.x != 0.0f) && (a.hd.y != 0.0f)) {
     // symmetric H: m(r,c)
-    const float m00 = a.h00, m01 = a.h01, m02 = a.h02;
-    const float m10 = a.h01, m11 = a.h11, m12 = a.h12;
-    const float m20 = a.h02, m21 = a.h12, m22 = a.h22;
+    const float m00 = a.hd.x, m01 = a.h01, m02 = a.hr.x;
+    const float m10 = a.h01, m11 = a.hd.y, m12 = a.hr.y;
+    const float m20 = a.hr.x, m21 = a.hr.y, m22 = a.h22;
     // cofactor_3x3<i,j> = m(i1,j1)*m(i2,j2) - m(i1,j2)*m(i2,j1), i1=(i+1)%3 ...
     const float c00 = m11 * m22 - m12 * m21;
     const float c10 = m21 * m02 - m22 * m01;
@@ -305,9 +409,9 @@ __device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, floa
     const float i20 = (m10 * m21 - m11 * m20) * invdet;  // cofactor<0,2>
     const float i21 = (m20 * m01 - m21 * m00) * invdet;  // cofactor<1,2>
     const float i22 = (m00 * m11 - m01 * m10) * invdet;  // cofactor<2,2>
-    const float s0 = i00 * a.d0 + (i01 * a.d1 + i02 * a.d2);
-    const float s1 = i10 * a.d0 + (i11 * a.d1 + i12 * a.d2);
-    float s2 = i20 * a.d0 + (i21 * a.d1 + i22 * a.d2);
+    const float s0 = i00 * a.d01.x + (i01 * a.d01.y + i02 * a.d2);
+    const float s1 = i10 * a.d01.x + (i11 * a.d01.y + i12 * a.d2);
+    float s2 = i20 * a.d01.x + (i21 * a.d01.y + i22 * a.d2);
     if (s2 > 0.2f) {
       s2 = 0.2f;
     } else if (s2 < -0.2f) {
@@ -359,16 +463,18 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   const float2* __restrict__ pts = P.pts + beg;
   const int tid_in_team = wit * 64 + lane;
   constexpr int NREG = BPL > 0 ? BPL : 1;
-  float2 pt[NREG];
-  unsigned live_mask = 0;
+  f2 pt[NREG];
   const bool in_regs = BPL > 0 && n <= T * BPL;  // team-uniform
   if (in_regs) {
 #pragma unroll
     for (int k = 0; k < NREG; ++k) {
       const int i = tid_in_team + k * T;
-      const bool live = i < n;
-      pt[k] = live ? pts[i] : make_float2(0.0f, 0.0f);
-      live_mask |= (live ? 1u : 0u) << k;
+      // padding slots of the last partial row: an endpoint far outside ANY map.  |R(theta) p| =
+      // |p| ~ 1.4e30 for every theta, so the transformed point is out of bounds on at least one
+      // axis and takes the exact-zero path of sample_fetch; all intermediates stay finite and the
+      // per-level power-of-two rescale keeps it huge.
+      const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);
+      pt[k] = f2{q.x, q.y};
     }
   }
   Acc9 acc;
@@ -382,6 +488,8 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
     affine_apply(L.mapTworld, pw0, pw1, ex, ey);  // getMapCoordsPose, GridMapBase.h:235-239
     eth = pw2;
     const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<LAYOUT>(L);
     if (in_regs) {
       // DataContainer::setFrom(scan, 2^-level): rescale IN PLACE when the level changes.  All
       // factors are powers of two, so p*2^-a*2^(a-b) == p*2^-b bit for bit, and no second
@@ -389,44 +497,43 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       const float ratio = ps / reg_scale;
       reg_scale = ps;
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        pt[k].x *= ratio;
-        pt[k].y *= ratio;
-      }
+      for (int k = 0; k < NREG; ++k) pt[k] *= f2{ratio, ratio};
     }
-    for (int it = 0; it < L.gn_steps; ++it) {
+    for (int it = 0; it < gn_steps; ++it) {
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
+      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
       if (in_regs) {
         // chunks of kUnroll beams: issue all gathers of a chunk, then consume them in beam order
         // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
 #pragma unroll
         for (int k0 = 0; k0 < NREG; k0 += kUnroll) {
           BeamSample smp[kUnroll];
+          BeamRot rot[kUnroll];
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
             if (k0 + u < NREG)
-              smp[u] = beam_fetch<LAYOUT>(L, ex, ey, sinRot, cosRot, pt[k0 + u].x, pt[k0 + u].y,
-                                          (live_mask >> (k0 + u)) & 1u);
+              smp[u] = beam_fetch<LAYOUT>(R, e2, cs, sc, pt[k0 + u], rot[u]);
           }
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
-            if (k0 + u < NREG) beam_finish(smp[u], sinRot, cosRot, pt[k0 + u].x, pt[k0 + u].y, acc);
+            if (k0 + u < NREG) beam_finish(smp[u], rot[u], acc);
           }
           // Pin the chunk: the accumulators must be final here ("+v") and no later gather may be
           // hoisted above this point ("memory").  Without it the compiler issues all BPL gathers
           // first and spills their results; with it at most kUnroll texels are in flight per lane.
           asm volatile(""
-                       : "+v"(acc.d0), "+v"(acc.d1), "+v"(acc.d2), "+v"(acc.h00), "+v"(acc.h11), "+v"(acc.h22),
-                         "+v"(acc.h01), "+v"(acc.h02), "+v"(acc.h12)
+                       : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
                        :
                        : "memory");
         }
       } else {
         for (int i = tid_in_team; i < n; i += T) {
           const float2 p = pts[i];
-          beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x * ps, p.y * ps, acc);
+          BeamRot r;
+          const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+          beam_finish(b, r, acc);
         }
       }
       team_allreduce9<WPS>(acc, red, buf, wit, lane);
@@ -436,9 +543,9 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
         if (scan == 0 && lane == 0 && wit == 0) {
           float* t = P.trace + 12 * step;
           t[0] = ex; t[1] = ey; t[2] = eth;
-          t[3] = acc.h00; t[4] = acc.h01; t[5] = acc.h02;
-          t[6] = acc.h01; t[7] = acc.h11; t[8] = acc.h12;
-          t[9] = acc.h02; t[10] = acc.h12; t[11] = acc.h22;
+          t[3] = acc.hd.x; t[4] = acc.h01; t[5] = acc.hr.x;
+          t[6] = acc.h01; t[7] = acc.hd.y; t[8] = acc.hr.y;
+          t[9] = acc.hr.x; t[10] = acc.hr.y; t[11] = acc.h22;
         }
         ++step;
       }
@@ -453,9 +560,9 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
     P.out_pose[3 * scan + 2] = pw2;
     if (P.out_cov) {  // covMatrix = H of the last evaluation (ScanMatcher.h:184), column major
       float* c = P.out_cov + 9 * scan;
-      c[0] = acc.h00; c[1] = acc.h01; c[2] = acc.h02;
-      c[3] = acc.h01; c[4] = acc.h11; c[5] = acc.h12;
-      c[6] = acc.h02; c[7] = acc.h12; c[8] = acc.h22;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
     }
   }
 }
@@ -473,16 +580,17 @@ __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const 
   sincos_f32(eth, sinRot, cosRot);
   Acc9 acc;
   acc.zero();
+  const LevelRegs R = level_regs<LAYOUT>(L);
   for (int i = threadIdx.x; i < n; i += 1024) {
     const float2 p = pts[i];
-    beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x, p.y, acc);
+    beam_accumulate<LAYOUT>(R, ex, ey, sinRot, cosRot, p.x, p.y, acc);
   }
   team_allreduce9<16>(acc, red, 0, wit, lane);
   if (threadIdx.x == 0) {
-    out12[0] = acc.h00; out12[1] = acc.h01; out12[2] = acc.h02;
-    out12[3] = acc.h01; out12[4] = acc.h11; out12[5] = acc.h12;
-    out12[6] = acc.h02; out12[7] = acc.h12; out12[8] = acc.h22;
-    out12[9] = acc.d0; out12[10] = acc.d1; out12[11] = acc.d2;
+    out12[0] = acc.hd.x; out12[1] = acc.h01; out12[2] = acc.hr.x;
+    out12[3] = acc.h01; out12[4] = acc.hd.y; out12[5] = acc.hr.y;
+    out12[6] = acc.hr.x; out12[7] = acc.hr.y; out12[8] = acc.h22;
+    out12[9] = acc.d01.x; out12[10] = acc.d01.y; out12[11] = acc.d2;
   }
 }
 
@@ -498,8 +606,17 @@ __global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict
   acc.zero();
   BeamTerms t;
   const float2 p = pts[i];
-  const float rd = beam_accumulate<LAYOUT>(L, ex, ey, sinRot, cosRot, p.x, p.y, acc, &t);
-  out[i] = make_float4(t.M, t.gx, t.gy, rd);
+  const LevelRegs R = level_regs<LAYOUT>(L);
+  float rd = beam_accumulate<LAYOUT>(R, ex, ey, sinRot, cosRot, p.x, p.y, acc, &t);
+  // out-of-map beams: the matcher's zero-texel trick yields dM = -0 where the reference returns
+  // literal +0 (same sums, different sign bit); report the reference's literal values here
+  const float cx = ex + (cosRot * p.x - sinRot * p.y), cy = ey + (sinRot * p.x + cosRot * p.y);
+  float gx = -t.G.x, gy = -t.G.y;
+  if ((cx < 0.0f) | (cx > R.limx) | (cy < 0.0f) | (cy > R.limy)) {
+    t.M = gx = gy = 0.0f;
+    rd = ((-sinRot * p.x - cosRot * p.y) * gx + (cosRot * p.x - sinRot * p.y) * gy);
+  }
+  out[i] = make_float4(t.M, gx, gy, rd);
 }
 
 // device sin/cos sweep for the parity tests

@@ -69,6 +69,14 @@ struct Level {
   unsigned int serial = 0;  // key-plane generation (map_update.h)
   int bbox[4] = {0, 0, -1, -1};
   size_t cells() const { return (size_t)sx * sy; }
+  int tiles_x() const { return (sx + 3) / 4; }
+  int quad_texels() const {
+#if HSM_QUAD_TILE
+    return tiles_x() * ((sy + 1) / 2) * 8;
+#else
+    return sx * sy;
+#endif
+  }
 };
 
 }  // namespace
@@ -149,6 +157,8 @@ LevelRW level_rw(const Level& L) {
   v.key_occ = L.d_key_occ;
   v.sx = L.sx;
   v.sy = L.sy;
+  v.tiles_x = L.tiles_x();
+  v.quad_texels = L.quad_texels();
   return v;
 }
 
@@ -158,6 +168,8 @@ LevelView level_view(const Level& L, float pt_scale, int gn_steps) {
   v.prob = L.d_prob;
   v.sx = L.sx;
   v.sy = L.sy;
+  v.tiles_x = L.tiles_x();
+  v.quad_texels = L.quad_texels();
   v.limx = L.limx;
   v.limy = L.limy;
   v.mapTworld = L.mapTworld;
@@ -375,6 +387,9 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   *out = nullptr;
   if (levels < 1 || levels > HSM_MAX_LEVELS || size_x < 2 || size_y < 2 || !(map_resolution > 0.0f))
     return fail(HSM_ERR_INVALID, "hsm_create: bad map geometry");
+  // the samplers address texels with a 32-bit byte offset (16 B per cell) and 24-bit multiplies
+  if (size_x >= (1 << 24) || size_y >= (1 << 24) || ((size_t)size_x + 3) * ((size_t)size_y + 1) >= ((size_t)1 << 28))
+    return fail(HSM_ERR_TOO_LARGE, "hsm_create: map larger than 2^28 cells");
   if ((size_x >> (levels - 1)) < 2 || (size_y >> (levels - 1)) < 2)
     return fail(HSM_ERR_INVALID, "hsm_create: too many levels for this map size");
   int ndev = 0;
@@ -443,8 +458,12 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     const size_t n = L.cells();
     CREATE_TRY(hipMalloc((void**)&L.d_logodds, n * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&L.d_update_index, n * sizeof(int)));
-    CREATE_TRY(hipMalloc((void**)&L.d_prob, n * sizeof(float)));
-    CREATE_TRY(hipMalloc((void**)&L.d_quad, n * sizeof(float4)));
+    // the samplers point out-of-map beams at an all-zero footprint stored BEHIND the planes
+    // (gn_match.h sample_fetch): one extra texel, resp. sizeX + 2 extra cells, zeroed once here
+    CREATE_TRY(hipMalloc((void**)&L.d_prob, (n + (size_t)rx + 2) * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&L.d_quad, ((size_t)L.quad_texels() + 1) * sizeof(float4)));
+    CREATE_TRY(hipMemsetAsync(L.d_prob + n, 0, ((size_t)rx + 2) * sizeof(float), h->stream));
+    CREATE_TRY(hipMemsetAsync(L.d_quad + L.quad_texels(), 0, sizeof(float4), h->stream));
     CREATE_TRY(hipMalloc((void**)&L.d_key_free, n * sizeof(unsigned int)));
     CREATE_TRY(hipMalloc((void**)&L.d_key_occ, n * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, n * sizeof(unsigned int), h->stream));

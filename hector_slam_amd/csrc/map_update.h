@@ -42,6 +42,7 @@ struct LevelRW {
   unsigned int* key_free; // first free-touching beam of the current scan
   unsigned int* key_occ;  // first end-cell beam of the current scan
   int sx, sy;
+  int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
 };
 
 struct UpdateParams {
@@ -68,10 +69,10 @@ __device__ __forceinline__ void store_probability(const LevelRW& L, int x, int y
   const int idx = y * L.sx + x;
   L.prob[idx] = p;
   float* q = reinterpret_cast<float*>(L.quad);
-  q[4 * idx + 0] = p;                                     // texel (x,   y  ).P00
-  if (x > 0) q[4 * (idx - 1) + 1] = p;                    // texel (x-1, y  ).P10
-  if (y > 0) q[4 * (idx - L.sx) + 2] = p;                 // texel (x,   y-1).P01
-  if (x > 0 && y > 0) q[4 * (idx - L.sx - 1) + 3] = p;    // texel (x-1, y-1).P11
+  q[4 * quad_index(x, y, L.tiles_x, L.sx) + 0] = p;                              // texel (x,   y  ).P00
+  if (x > 0) q[4 * quad_index(x - 1, y, L.tiles_x, L.sx) + 1] = p;               // texel (x-1, y  ).P10
+  if (y > 0) q[4 * quad_index(x, y - 1, L.tiles_x, L.sx) + 2] = p;               // texel (x,   y-1).P01
+  if (x > 0 && y > 0) q[4 * quad_index(x - 1, y - 1, L.tiles_x, L.sx) + 3] = p;  // texel (x-1, y-1).P11
 }
 
 struct BeamLine {
@@ -186,6 +187,10 @@ __global__ void fill_level_kernel(LevelRW L, float logodds, int update_index) {
     L.logodds[i] = logodds;
     L.update_index[i] = update_index;
     L.prob[i] = p;
+  }
+  // every texel of the tiled plane, including the padding of partial edge tiles
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)L.quad_texels;
+       i += (size_t)gridDim.x * blockDim.x) {
     L.quad[i] = make_float4(p, p, p, p);
   }
 }
@@ -215,7 +220,7 @@ __global__ void rebuild_quad_kernel(LevelRW L) {
     const int x = (int)(i % (size_t)L.sx), y = (int)(i / (size_t)L.sx);
     const int x1 = x + 1 < L.sx ? x + 1 : x;
     const int y1 = y + 1 < L.sy ? y + 1 : y;
-    L.quad[i] = make_float4(L.prob[(size_t)y * L.sx + x], L.prob[(size_t)y * L.sx + x1],
+    L.quad[quad_index(x, y, L.tiles_x, L.sx)] = make_float4(L.prob[(size_t)y * L.sx + x], L.prob[(size_t)y * L.sx + x1],
                             L.prob[(size_t)y1 * L.sx + x], L.prob[(size_t)y1 * L.sx + x1]);
   }
 }

@@ -37,7 +37,7 @@ enum {
   HSM_ERR_INVALID = -1,    /* bad argument */
   HSM_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at init */
   HSM_ERR_HIP = -3,        /* HIP runtime error (text in hsm_last_error) */
-  HSM_ERR_TOO_LARGE = -4   /* scan longer than HSM_MAX_UPDATE_BEAMS in update_by_scan */
+  HSM_ERR_TOO_LARGE = -4   /* scan longer than HSM_MAX_UPDATE_BEAMS in update_by_scan, or map > 2^28 cells */
 };
 
 #define HSM_MAX_LEVELS 8

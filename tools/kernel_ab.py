@@ -32,8 +32,9 @@ def main():
     stream = torch.cuda.current_stream()
     variants = []
     for spec in args.variants.split(","):
-        layout, wps, regs = spec.split(":")
+        layout, wps, regs = spec.split(":")[:3]
         os.environ["HSM_BPL"] = regs
+        os.environ["HSM_EXPERIMENT"] = spec.split(":")[3] if spec.count(":") >= 3 else "0"
         m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, args.levels, device=0,
                                 layout=capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE,
                                 waves_per_scan=int(wps))
@@ -42,10 +43,11 @@ def main():
         m.build_map(bp, bs)
         pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
         cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
-        variants.append({"spec": spec, "m": m, "pose": pose, "cov": cov, "ms": []})
+        variants.append({"spec": spec, "exp": os.environ["HSM_EXPERIMENT"], "m": m, "pose": pose, "cov": cov, "ms": []})
     os.environ.pop("HSM_BPL", None)
 
     def launch(v):
+        os.environ["HSM_EXPERIMENT"] = v["exp"]
         v["m"].match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS,
                                   v["pose"].data_ptr(), v["cov"].data_ptr(), stream.cuda_stream)
 
