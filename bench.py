@@ -37,6 +37,16 @@ RESOLUTION = 0.05
 BATCH_PER_GPU = 4096
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 
+# Extra single-GPU workloads (BASELINE.json configs other than the headline one), `--workload NAME`:
+#   name: (beams, map size, resolution, room, sensor range, levels, batch per GPU)
+WORKLOADS = {
+    "config3": (1081, 2048, 0.05, (40.0, 30.0), 30.0, 1, 4096),        # headline (configs[2]), level-0 GN
+    "config3pyr": (1081, 2048, 0.05, (40.0, 30.0), 30.0, 3, 4096),     # the same batch, full 3-level matchData
+    "config2": (1081, 1024, 0.05, (40.0, 30.0), 30.0, 3, 1),           # configs[1]: one scan, latency
+    "config4": (1081, 4096, 0.05, (160.0, 120.0), 120.0, 3, 4096),     # configs[3]: one GPU's share of 32768
+    "config5": (16384, 8192, 0.05, (320.0, 240.0), 240.0, 3, 1),       # configs[4]: dense scan, match+update loop
+}
+
 
 def algorithmic_bytes_per_iteration(n_beams: int) -> int:
     return 24 * n_beams + 60  # 8 B endpoint + 4 x 4 B samples per beam; 12 B pose in + 48 B H,dTr out
@@ -117,6 +127,216 @@ def cpu_baseline(build_poses, build_scans, init, pts, offs, gpu_pose, levels: in
     }
 
 
+def extra_workload(name: str, args, local_rank: int):
+    """Single-GPU measurement of one of the non-headline BASELINE configs; prints one JSON line in the same
+    schema (metric = GN iterations/s of that workload; roofline on its matcher launch; reference CPU leg)."""
+    import torch
+    from hector_slam_amd import capi, synth
+    beams, size, res, room, rmax, levels, batch = WORKLOADS[name]
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    sfac = float(np.float32(1.0) / np.float32(res))
+    world = synth.World.make(room[0], room[1], seed=1234)
+    rng_noise = np.random.default_rng(1235)
+    its = 6 + 4 * (levels - 1)
+
+    def cpu_oracle():
+        from oracle import pyoracle
+        pyoracle.build()
+        kind = "hr" if pyoracle.available("hr") else "ho"
+        o = pyoracle.Oracle(kind, res, size, size, levels)
+        o.set_update_factor_free(0.4)
+        o.set_update_factor_occupied(0.9)
+        return o, ("reference" if kind == "hr" else "port")
+
+    out = {"metric": "scan-match GN iterations/sec", "unit": "GN it/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic"}
+
+    if name == "config5":
+        # trajectory: every step = matchData (14 GN it over ~16k beams) + updateByScan on all 3 levels, via
+        # the host C ABI exactly as HectorSlamProcessor::update drives it (zero thresholds: always update)
+        T = args.warmup + args.steps
+        n_init = 8  # scans mapped at their true poses first, so that the matching starts well conditioned
+        allp = synth.loop_trajectory(world, 40 * (T + n_init))[: T + n_init + 1].astype(np.float32)  # ~0.4 m apart
+        alls = [synth.make_scan(world, p, beams, sfac, rng_noise, range_max=rmax) for p in allp]
+        poses, scans = allp[n_init:], alls[n_init:]
+        m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+        for k in range(n_init + 1):
+            m.matchData(allp[k], alls[k])      # retains the coarse-level containers (result unused)
+            m.updateByScan(alls[k], allp[k])
+            m.onMapUpdated()
+        t_match = t_upd = 0.0
+        pose = poses[0]
+        gpu_poses = []
+        for t in range(1, T + 1):
+            if t == args.warmup + 1:
+                torch.cuda.synchronize()
+                t_match = t_upd = 0.0
+                t0 = time.perf_counter()
+            hint = pose + (poses[t] - poses[t - 1])
+            a = time.perf_counter()
+            pose, _ = m.matchData(hint, scans[t])
+            b = time.perf_counter()
+            m.updateByScan(scans[t], pose)
+            m.onMapUpdated()
+            c = time.perf_counter()
+            t_match += b - a
+            t_upd += c - b
+            gpu_poses.append(pose)
+        dt = time.perf_counter() - t0
+        nb = float(np.mean([s_.shape[0] for s_ in scans[1:]]))
+        out.update({"value": args.steps * its / dt, "ms_per_step": dt / args.steps * 1e3,
+                    "config": {"workload": f"configs[4] (one replica): dense {beams}-beam scans (mean {nb:.0f} valid), "
+                                           f"{size}^2 map, {levels} levels, matchData + updateByScan interleaved",
+                               "beams": beams, "map": size, "levels": levels, "gn_iterations_per_scan": its,
+                               "kernel": m.last_launch_config()},
+                    "match_ms": t_match / args.steps * 1e3, "update_ms": t_upd / args.steps * 1e3,
+                    "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9, "traffic": None,
+                                 "achieved": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / 1e9,
+                                 "frac": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / HBM_PEAK,
+                                 "note": "host-call latency of ONE scan (H2D + launch + D2H), not a throughput kernel"}})
+        if not args.no_cpu:
+            o, kind = cpu_oracle()
+            o.proc_set_thresholds(0.0, 0.0)
+            for k in range(n_init + 1):
+                o.match(allp[k], alls[k])
+                o.update_by_scan(allp[k], alls[k])
+                o.on_map_updated()  # HectorSlamProcessor.h:93 -- the reference's probability cache must be dropped
+            pose = poses[0]
+            n_cpu = min(T, 12)
+            dmax = 0.0
+            t0 = time.perf_counter()
+            for t in range(1, n_cpu + 1):
+                hint = pose + (poses[t] - poses[t - 1])
+                pose, _ = o.match(hint, scans[t])
+                o.update_by_scan(pose, scans[t])
+                o.on_map_updated()
+                dmax = max(dmax, float(np.abs(pose[:2].astype(np.float64) - gpu_poses[t - 1][:2]).max()))
+            dtc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
+                                   "sample": f"{n_cpu} match+update steps of the same trajectory, {dtc:.1f} s",
+                                   "ms_per_step": dtc / n_cpu * 1e3, "max_abs_dxy_m_vs_gpu": dmax}
+        print(json.dumps(out))
+        return
+
+    # map built from ground-truth posed scans by the product's own update kernels
+    n_build = 100
+    build_poses = synth.loop_trajectory(world, n_build).astype(np.float32)
+    build_scans = [synth.make_scan(world, p, beams, sfac, rng_noise, range_max=rmax) for p in build_poses]
+    m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
+    m.setUpdateFactorFree(0.4)
+    m.setUpdateFactorOccupied(0.9)
+    m.build_map(build_poses, build_scans)
+    rng = np.random.default_rng(1236)
+    nq = max(batch, 64)
+    base = synth.loop_trajectory(world, nq, phase=rng.uniform(0, 2 * math.pi)).astype(np.float64)
+    base[:, :2] += rng.uniform(-0.5, 0.5, size=(nq, 2)) * (room[0] / 40.0)
+    base[:, 2] += rng.uniform(-0.3, 0.3, size=nq)
+    truth = base.astype(np.float32)
+    rng_q = np.random.default_rng(1237)
+    scans = [synth.make_scan(world, p, beams, sfac, rng_q, pad_to_full=True, range_max=rmax) for p in truth]
+    init = synth.perturb_poses(truth, np.random.default_rng(1239), 0.15 if levels > 1 else 0.04,
+                               0.05 if levels > 1 else 0.01)
+    pts, offs = synth.pack_scans(scans)
+
+    if name == "config2":
+        # one scan at a time through the host entry (what the ROS node calls): latency
+        lat = []
+        for k in range(args.warmup + args.steps):
+            q = k % nq
+            a = time.perf_counter()
+            pg, _ = m.matchData(init[q], scans[q])
+            lat.append(time.perf_counter() - a)
+        lat = np.array(lat[args.warmup:])
+        out.update({"value": its / float(np.median(lat)), "ms_per_step": float(np.median(lat)) * 1e3,
+                    "config": {"workload": f"configs[1]: ONE {beams}-beam scan, {levels}-level {size}/{size // 2}/{size // 4} "
+                                           f"pyramid, hsm_match host call (H2D + 1 launch + D2H), median of {args.steps}",
+                               "beams": beams, "map": size, "levels": levels, "gn_iterations_per_scan": its,
+                               "kernel": m.last_launch_config()},
+                    "latency_us": {"median": float(np.median(lat)) * 1e6, "p90": float(np.percentile(lat, 90)) * 1e6,
+                                   "min": float(lat.min()) * 1e6},
+                    "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9, "traffic": None,
+                                 "achieved": algorithmic_bytes_per_iteration(beams) * its / float(np.median(lat)) / 1e9,
+                                 "frac": algorithmic_bytes_per_iteration(beams) * its / float(np.median(lat)) / HBM_PEAK,
+                                 "note": "single-scan latency is launch/PCIe bound by construction"}})
+        if not args.no_cpu:
+            o, kind = cpu_oracle()
+            o.build_map(build_poses, build_scans)
+            for q in range(8):
+                o.match(init[q], scans[q])
+            t0 = time.perf_counter()
+            n_cpu = 2000
+            for k in range(n_cpu):
+                o.match(init[k % nq], scans[k % nq])
+            dtc = time.perf_counter() - t0
+            d = max(float(np.abs(o.match(init[q], scans[q])[0].astype(np.float64) - m.matchData(init[q], scans[q])[0]).max())
+                    for q in range(32))
+            out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
+                                   "sample": f"{n_cpu} matchData calls, warm cache, {dtc:.1f} s",
+                                   "latency_us": dtc / n_cpu * 1e6, "max_abs_dev_vs_gpu": d}
+        print(json.dumps(out))
+        return
+
+    # batched workloads (config3pyr, config4)
+    B = batch
+    d_init = torch.from_numpy(init).to(dev)
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    d_pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+    d_cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), beams, d_pose.data_ptr(),
+                             d_cov.data_ptr(), stream.cuda_stream)
+        if ev:
+            ev[1].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    bytes_per_launch = algorithmic_bytes_per_iteration(beams) * its * B
+    gpu_pose = d_pose.cpu().numpy()
+    out.update({"value": B * its * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                "matchdata_per_s": B * args.steps / dt,
+                "config": {"workload": f"{name}: batch={B} concurrent {beams}-beam scans, {levels}-level pyramid on a "
+                                       f"{size}^2 map ({res} m cells, {room[0]:.0f} m x {room[1]:.0f} m room)",
+                           "batch_per_gpu": B, "beams": beams, "map": size, "levels": levels,
+                           "gn_iterations_per_scan": its, "kernel": m.last_launch_config()},
+                "roofline": {"bound": "hbm", "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                             "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                             "kernel": "gn_match_kernel", "kernel_ms": kern_ms,
+                             "algorithmic_bytes_per_launch": bytes_per_launch}})
+    if not args.no_cpu:
+        o, kind = cpu_oracle()
+        o.build_map(build_poses, build_scans)
+        n_cpu = min(B, 1024)
+        o.match_many(init[:64], pts, offs[:65])
+        t0 = time.perf_counter()
+        cpu_pose = o.match_many(init[:n_cpu], pts, offs[:n_cpu + 1])
+        dtc = time.perf_counter() - t0
+        cpu2 = o.match_many(cpu_pose, pts, offs[:n_cpu + 1])
+        settled = np.abs(cpu2.astype(np.float64) - cpu_pose)[:, :2].max(1) <= 1e-3
+        d = np.abs(cpu_pose.astype(np.float64) - gpu_pose[:n_cpu])
+        out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
+                               "sample": f"{n_cpu} matchData calls on the same map + scans, {dtc:.1f} s",
+                               "settled_fraction_of_reference": float(settled.mean()),
+                               "max_abs_dxy_m_on_settled": float(d[settled, :2].max()) if settled.any() else None,
+                               "frac_within_1e-4_all": float((d[:, :2].max(1) <= 1e-4).mean())}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +346,8 @@ def main():
     ap.add_argument("--levels", type=int, default=1, help="pyramid levels of the headline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-pyramid", action="store_true", help="skip the 3-level extra run")
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
+                    help="config3 = the headline (BASELINE configs[2]); others are single-GPU extras")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +365,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.workload != "config3":
+        assert world == 1, "the extra workloads are single-GPU measurements"
+        extra_workload(args.workload, args, local_rank)
+        return
 
     B = args.batch
     build_poses, build_scans, truth, init, init_pyr, pts, offs = make_inputs(rank, B)

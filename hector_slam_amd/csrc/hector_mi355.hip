@@ -335,19 +335,19 @@ int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2*
     P.log_odds_occ = L.log_odds_occ;
     P.mark_free = L.curr_mark_free;
     P.mark_occ = L.curr_mark_occ;
-    const int grid = (n + 3) / 4;  // 4 beams (wavefronts) per 256-thread workgroup
-    hipLaunchKernelGGL(update_mark_kernel, dim3(grid), dim3(256), 0, h->stream, P);
-    hipLaunchKernelGGL(update_apply_kernel, dim3(grid), dim3(256), 0, h->stream, P);
-    HIP_TRY(hipGetLastError());
-    // touched bounding box (host, same fp32 expressions as the kernels)
-    if (h_pts && bxi >= 0 && bxi < L.sx && byi >= 0 && byi < L.sy) {
-      int x0 = L.sx, y0 = L.sy, x1 = -1, y1 = -1;
+    // cell bounding box of everything this scan can touch: the begin cell and every in-map end
+    // cell (a Bresenham line stays inside the box of its end points).  Host, same fp32
+    // expressions as beam_line(); pure index work.
+    const bool begin_in = bxi >= 0 && bxi < L.sx && byi >= 0 && byi < L.sy;
+    int x0 = L.sx, y0 = L.sy, x1 = -1, y1 = -1;
+    if (begin_in) {
+      const float fsx = (float)L.sx + 2.0f, fsy = (float)L.sy + 2.0f;
       for (int i = 0; i < n; ++i) {
         float ex, ey;
         affine_apply_host(T, h_pts[2 * i] * pt_scale, h_pts[2 * i + 1] * pt_scale, ex, ey);
         ex += 0.5f;
         ey += 0.5f;
-        if (!(ex > -2.0f && ex < (float)L.sx + 2.0f && ey > -2.0f && ey < (float)L.sy + 2.0f)) continue;
+        if (!(ex > -2.0f && ex < fsx && ey > -2.0f && ey < fsy)) continue;
         const int exi = (int)ex, eyi = (int)ey;
         if (exi < 0 || exi >= L.sx || eyi < 0 || eyi >= L.sy) continue;
         if (exi == bxi && eyi == byi) continue;
@@ -356,12 +356,19 @@ int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2*
         if (eyi < y0) y0 = eyi;
         if (eyi > y1) y1 = eyi;
       }
-      if (x1 >= 0) {
-        L.bbox[0] = x0 < bxi ? x0 : bxi;
-        L.bbox[1] = y0 < byi ? y0 : byi;
-        L.bbox[2] = x1 > bxi ? x1 : bxi;
-        L.bbox[3] = y1 > byi ? y1 : byi;
-      }
+    }
+    if (x1 >= 0) {  // at least one beam survives the skips of updateByScan / updateLineBresenhami
+      L.bbox[0] = P.x0 = x0 < bxi ? x0 : bxi;
+      L.bbox[1] = P.y0 = y0 < byi ? y0 : byi;
+      L.bbox[2] = P.x1 = x1 > bxi ? x1 : bxi;
+      L.bbox[3] = P.y1 = y1 > byi ? y1 : byi;
+      const int grid = (n + 3) / 4;  // 4 beams (wavefronts) per 256-thread workgroup
+      const size_t box = (size_t)(P.x1 - P.x0 + 2) * (size_t)(P.y1 - P.y0 + 2);
+      hipLaunchKernelGGL(update_mark_occ_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, P);
+      hipLaunchKernelGGL(update_mark_free_kernel, dim3(grid), dim3(256), 0, h->stream, P);
+      hipLaunchKernelGGL(update_apply_kernel, dim3(grid_for(box)), dim3(256), 0, h->stream, P);
+      hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(box)), dim3(256), 0, h->stream, P);
+      HIP_TRY(hipGetLastError());
     }
   }
   L.last_update_index++;     // setUpdated(), GridMapBase.h:343

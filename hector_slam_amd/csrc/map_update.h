@@ -11,21 +11,26 @@
 //     is ((l + f) - f) [+ o] instead of l [+ o].  That rounding artefact is reproduced.
 //
 // Parallel formulation (bit-exact with the sequential reference):
-//   pass 1 "mark":  one wavefront per beam; lane k owns Bresenham steps k, k+64, ...
-//       The cell of step i has a closed form (minor steps = floor((e0 + i*db)/da)), so
-//       no lane walks the line sequentially.  Each touched cell receives
-//       atomicMax(key) with key = (scan serial << 16) | (0xFFFF - beam index) on the
-//       free-key plane (line cells) or the occ-key plane (end cell): the plane then
-//       holds, per cell, the FIRST beam (lowest index) that touched it in this scan.
-//   pass 2 "apply": same geometry; the unique lane whose key won a cell applies the
-//       update to the log-odds plane, writes the reference's updateIndex stamp and
-//       refreshes the probability plane and the four quad texels that contain the
-//       cell.  No float atomics, no races: every word has exactly one writer.
-// Keys of earlier scans are always smaller than the current ones, so the key planes
-// never need clearing (only when the 16-bit serial wraps, every 65535 updates).
+//   pass 1 "mark" (per beam), two launches: (a) every beam atomicMax'es
+//       key = (scan serial << 16) | (0xFFFF - beam index) into the occ-key plane at its end cell,
+//       which leaves the FIRST beam (lowest index) ending there; (b) one wavefront per beam, lane k
+//       owns Bresenham steps k, k+64, ... -- the cell of step i has a closed form (minor steps =
+//       floor((e0 + i*db)/da)), so no lane walks the line sequentially -- and tags every crossed
+//       cell in the free-key plane: a plain store of the serial where no beam ends, atomicMax of
+//       the key (lowest crossing beam index, needed for the revert artefact) where one does.
+//   pass 2 "apply" (per cell, DENSE over the bounding box of the scan):  every cell whose keys
+//       carry the current serial applies the reference's rule -- occupied if any beam ends there
+//       (after undoing the free update when a lower-indexed beam crossed it first), else free --
+//       to the log-odds plane, writes the reference's updateIndex stamp and the new probability.
+//       Rows are contiguous, so all loads and stores are coalesced; no float atomics, no races.
+//   pass 3 "texels" (per cell, dense over the box grown by one):  rebuilds the float4 texels
+//       {P(x,y),P(x+1,y),P(x,y+1),P(x+1,y+1)} the matcher samples.
+// Keys of earlier scans are always smaller than the current ones, so the key planes never need
+// clearing (only when the 16-bit serial wraps, every 65535 updates).
 //
-// Traffic: per touched cell 2 key atomics + 8 B log-odds/stamp RMW +
-// 20 B probability/texel stores; HBM-bound scattered integer/byte work, no MFMA.
+// Traffic: mark = one 4-byte load (+ rarely an atomic) per visited cell; apply = 12 B
+// read + 12 B written per touched cell of the box; texels = 16 B written per cell of the box.
+// HBM/L2-bound integer/byte work, no MFMA.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -55,6 +60,7 @@ struct UpdateParams {
   unsigned int serial;    // 1..65535
   float log_odds_free, log_odds_occ;
   int mark_free, mark_occ;  // currMarkFreeIndex / currMarkOccIndex (OccGridMapBase.h:123-124)
+  int x0, y0, x1, y1;       // inclusive cell bounding box of everything this scan can touch
 };
 
 // GridMapLogOddsFunctions::getGridProbability (GridMapLogOdds.h:163-166);
@@ -62,17 +68,6 @@ struct UpdateParams {
 __device__ __forceinline__ float grid_probability(float log_odds) {
   const float odds = (float)exp((double)log_odds);
   return odds / (odds + 1.0f);
-}
-
-// write P of cell (x,y) into the probability plane and the 4 texels that contain it
-__device__ __forceinline__ void store_probability(const LevelRW& L, int x, int y, float p) {
-  const int idx = y * L.sx + x;
-  L.prob[idx] = p;
-  float* q = reinterpret_cast<float*>(L.quad);
-  q[4 * quad_index(x, y, L.tiles_x, L.sx) + 0] = p;                              // texel (x,   y  ).P00
-  if (x > 0) q[4 * quad_index(x - 1, y, L.tiles_x, L.sx) + 1] = p;               // texel (x-1, y  ).P10
-  if (y > 0) q[4 * quad_index(x, y - 1, L.tiles_x, L.sx) + 2] = p;               // texel (x,   y-1).P01
-  if (x > 0 && y > 0) q[4 * quad_index(x - 1, y - 1, L.tiles_x, L.sx) + 3] = p;  // texel (x-1, y-1).P11
 }
 
 struct BeamLine {
@@ -128,54 +123,87 @@ __device__ __forceinline__ unsigned int line_cell(const BeamLine& b, unsigned in
   return b.start + (unsigned int)((int)i * b.offset_a) + (unsigned int)((int)minor * b.offset_b);
 }
 
-__global__ void __launch_bounds__(256) update_mark_kernel(const UpdateParams P) {
+// pass 1a: end cells.  One thread per beam: atomicMax leaves the FIRST beam that ends in a cell.
+__global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateParams P) {
+  const int beam = blockIdx.x * blockDim.x + threadIdx.x;
+  if (beam >= P.n) return;
+  const BeamLine b = beam_line(P, beam);
+  if (!b.valid) return;
+  const unsigned int key = (P.serial << 16) | (0xFFFFu - (unsigned int)beam);
+  atomicMax(&P.lv.key_occ[(unsigned int)(b.y1 * P.lv.sx + b.x1)], key);
+}
+
+// pass 1b: line cells (after 1a has completed).  WHICH beam crossed a cell first only matters
+// where some beam also ENDS (the free-then-occupied revert, OccGridMapBase.h:231-233); everywhere
+// else "some beam of this scan crossed it" is all the apply pass needs.  So a cell that is nobody's
+// end cell gets a plain store of the bare serial tag (all writers store the same word: a benign
+// race, and stores do not serialise in L2 the way same-address atomics do next to the sensor),
+// and only end cells -- a few thousand per scan -- take the atomicMax that keeps the lowest beam
+// index.  A cell is classified by key_occ, which pass 1a finalised, so the two kinds of access
+// never mix on one word.
+__global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParams P) {
   const int lane = threadIdx.x & 63;
   const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
-  const unsigned int key = (P.serial << 16) | (0xFFFFu - (unsigned int)beam);
+  const unsigned int tag = P.serial << 16;
+  const unsigned int key = tag | (0xFFFFu - (unsigned int)beam);
   for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
-    atomicMax(&P.lv.key_free[line_cell(b, i)], key);
-  }
-  if (lane == 0) {
-    atomicMax(&P.lv.key_occ[(unsigned int)(b.y1 * P.lv.sx + b.x1)], key);
+    const unsigned int c = line_cell(b, i);
+    if ((P.lv.key_occ[c] >> 16) == P.serial) {
+      atomicMax(&P.lv.key_free[c], key);
+    } else {
+      P.lv.key_free[c] = tag;
+    }
   }
 }
 
+// dense over the box [x0..x1] x [y0..y1]: bresenhamCellFree / bresenhamCellOcc (OccGridMapBase.h:216-241)
 __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateParams P) {
-  const int lane = threadIdx.x & 63;
-  const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (beam >= P.n) return;
-  const BeamLine b = beam_line(P, beam);
-  if (!b.valid) return;
-  const unsigned int key = (P.serial << 16) | (0xFFFFu - (unsigned int)beam);
-  for (unsigned int i = lane; i < b.abs_da; i += 64) {
-    const unsigned int c = line_cell(b, i);
-    if (P.lv.key_free[c] != key) continue;                  // another beam touched it first
-    if ((P.lv.key_occ[c] >> 16) == P.serial) continue;      // occupied wins, its owner handles it
+  const int w = P.x1 - P.x0 + 1, h = P.y1 - P.y0 + 1;
+  const size_t n = (size_t)w * h;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int x = P.x0 + (int)(t % (size_t)w), y = P.y0 + (int)(t / (size_t)w);
+    const size_t c = (size_t)y * P.lv.sx + x;
+    const unsigned int kf = P.lv.key_free[c];
+    const unsigned int ko = P.lv.key_occ[c];
+    const bool fre = (kf >> 16) == P.serial;
+    const bool occ = (ko >> 16) == P.serial;
+    if (!fre && !occ) continue;
     float l = P.lv.logodds[c];
-    l += P.log_odds_free;                                   // updateSetFree
-    P.lv.logodds[c] = l;
-    P.lv.update_index[c] = P.mark_free;
-    store_probability(P.lv, (int)(c % (unsigned int)P.lv.sx), (int)(c / (unsigned int)P.lv.sx),
-                      grid_probability(l));
-  }
-  if (lane == 0) {
-    const unsigned int c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
-    if (P.lv.key_occ[c] == key) {
-      float l = P.lv.logodds[c];
-      const unsigned int kf = P.lv.key_free[c];
-      if ((kf >> 16) == P.serial && (0xFFFFu - (kf & 0xFFFFu)) < (unsigned int)beam) {
-        // free-touched by an earlier beam of this scan: applied, then reverted (:231-233)
+    int stamp;
+    if (occ) {
+      // free-touched by an earlier beam of this scan: applied, then reverted (:231-233)
+      if (fre && (0xFFFFu - (kf & 0xFFFFu)) < (0xFFFFu - (ko & 0xFFFFu))) {
         l += P.log_odds_free;
         l -= P.log_odds_free;
       }
-      if (l < 50.0f) l += P.log_odds_occ;                   // updateSetOccupied
-      P.lv.logodds[c] = l;
-      P.lv.update_index[c] = P.mark_occ;
-      store_probability(P.lv, b.x1, b.y1, grid_probability(l));
+      if (l < 50.0f) l += P.log_odds_occ;  // updateSetOccupied
+      stamp = P.mark_occ;
+    } else {
+      l += P.log_odds_free;                // updateSetFree
+      stamp = P.mark_free;
     }
+    P.lv.logodds[c] = l;
+    P.lv.update_index[c] = stamp;
+    P.lv.prob[c] = grid_probability(l);
+  }
+}
+
+// dense over the box grown by one cell towards -x/-y: texel (x,y) holds P of (x..x+1, y..y+1)
+__global__ void __launch_bounds__(256) update_texels_kernel(const UpdateParams P) {
+  const int tx0 = P.x0 > 0 ? P.x0 - 1 : 0, ty0 = P.y0 > 0 ? P.y0 - 1 : 0;
+  const int w = P.x1 - tx0 + 1, h = P.y1 - ty0 + 1;
+  const size_t n = (size_t)w * h;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int x = tx0 + (int)(t % (size_t)w), y = ty0 + (int)(t / (size_t)w);
+    const int xn = x + 1 < P.lv.sx ? x + 1 : x;
+    const int yn = y + 1 < P.lv.sy ? y + 1 : y;
+    const float* p = P.lv.prob;
+    P.lv.quad[quad_index(x, y, P.lv.tiles_x, P.lv.sx)] =
+        make_float4(p[(size_t)y * P.lv.sx + x], p[(size_t)y * P.lv.sx + xn], p[(size_t)yn * P.lv.sx + x],
+                    p[(size_t)yn * P.lv.sx + xn]);
   }
 }
 
