@@ -65,7 +65,8 @@ struct MatchParams {
   int first_level;         // coarsest level to run (levels first_level .. last_level, descending)
   int last_level;
   int batch;
-  const float* begin_world;  // [B*3]
+  const float* begin_world;  // [B*3], or nullptr: the single start estimate travels in begin_inline
+  float begin_inline[3];
   const float2* pts;         // packed endpoints
   const int* offsets;        // [B+1] or nullptr (shared scan)
   int shared_n;
@@ -449,9 +450,16 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
     beg = P.offsets[scan];
     n = P.offsets[scan + 1] - beg;
   }
-  float pw0 = P.begin_world[3 * scan + 0];
-  float pw1 = P.begin_world[3 * scan + 1];
-  float pw2 = P.begin_world[3 * scan + 2];
+  float pw0, pw1, pw2;
+  if (P.begin_world) {
+    pw0 = P.begin_world[3 * scan + 0];
+    pw1 = P.begin_world[3 * scan + 1];
+    pw2 = P.begin_world[3 * scan + 2];
+  } else {  // single-scan host entry: the pose rides in the kernel arguments, no H2D copy
+    pw0 = P.begin_inline[0];
+    pw1 = P.begin_inline[1];
+    pw2 = P.begin_inline[2];
+  }
   if (n == 0) {  // ScanMatcher.h:68,189: pose passes through, cov untouched
     if (lane == 0 && wit == 0) {
       P.out_pose[3 * scan + 0] = pw0;

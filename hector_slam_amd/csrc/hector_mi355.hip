@@ -103,6 +103,10 @@ struct hsm_ctx {
   // batch staging for the host-pointer convenience entry
   void* d_batch = nullptr;
   size_t d_batch_cap = 0;
+  // single-scan fast path: endpoints staged in pinned, device-mapped host memory and read by the
+  // matcher ONCE (they stay in VGPRs); results written by the kernel straight into h_small
+  float2* h_scan_pinned = nullptr;
+  size_t h_scan_pinned_cap = 0;
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
@@ -245,7 +249,12 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   int wps = 1;
   const long target_waves = 256L * 4 * 4;  // 4 waves per SIMD
   while (wps < 16 && (long)batch * wps < target_waves && 64 * wps < max_n) wps *= 2;
-  return wps;
+  // ... but keep about five beams per lane: every extra wavefront adds LDS staging + a barrier to each
+  // of the 14 dependent GN steps, which costs more than the beam loop saves (single 1081-beam scan on
+  // MI355X: 72 / 58 / 53 / 61 / 79 us for 1 / 2 / 4 / 8 / 16 waves, profiles/r01/README.md)
+  int lat = 1;
+  while (lat < 16 && 64 * 5 * lat < max_n) lat *= 2;
+  return wps < lat ? wps : lat;
 }
 
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
@@ -444,7 +453,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   CREATE_TRY(hipSetDevice(h->device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float), hipHostMallocMapped));
 
   // MapRepMultiMap ctor (MapRepMultiMap.h:48-72)
   int rx = size_x, ry = size_y;
@@ -499,6 +508,7 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);
   (void)hipFree(h->d_cells);
+  if (h->h_scan_pinned) (void)hipHostFree(h->h_scan_pinned);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -621,27 +631,32 @@ int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float
   return HSM_OK;
 }
 
-// one scan on the first..last levels; pts are host, level-0 units (pt_scale applied per level)
-static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], const float2* d_pts, int n,
+// Largest scan the matcher keeps entirely in registers (16 waves x 64 lanes x 17 beams): such a scan is
+// read exactly once per match, so the kernel can fetch it directly from pinned host memory over PCIe
+// and the host entry needs no H2D copy at all.
+constexpr int kMaxRegisterResidentBeams = 16 * 64 * 17;
+
+// One scan on the levels selected in P.  `pts` is a device-accessible pointer (device memory or pinned
+// mapped host memory), level-0 units.  Latency path of the ROS node: ONE kernel launch and one stream
+// synchronise -- the start estimate travels in the kernel arguments and the kernel writes pose, H and
+// the optional hook trace straight into the pinned h_small block.
+static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], const float2* pts, int n,
                         float out_pose_world[3], float cov[9], float* trace = nullptr, int trace_steps = 0) {
   float* hs = h->h_small;
-  hs[0] = begin_world[0];
-  hs[1] = begin_world[1];
-  hs[2] = begin_world[2];
-  HIP_TRY(hipMemcpyAsync(h->d_small, hs, 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  float* hs_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&hs_dev, hs, 0));
   P.batch = 1;
-  P.begin_world = h->d_small;
-  P.pts = d_pts;
+  P.begin_world = nullptr;
+  P.begin_inline[0] = begin_world[0];
+  P.begin_inline[1] = begin_world[1];
+  P.begin_inline[2] = begin_world[2];
+  P.pts = pts;
   P.offsets = nullptr;
   P.shared_n = n;
-  P.out_pose = h->d_small + 3;
-  P.out_cov = h->d_small + 6;
-  P.trace = trace_steps > 0 ? h->d_small + kTraceOff : nullptr;
+  P.out_pose = hs_dev + 3;
+  P.out_cov = hs_dev + 6;
+  P.trace = trace_steps > 0 ? hs_dev + kTraceOff : nullptr;
   if (int rc = launch_match(h, P, n, h->stream)) return rc;
-  HIP_TRY(hipMemcpyAsync(hs + 3, h->d_small + 3, 12 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (trace_steps > 0)
-    HIP_TRY(hipMemcpyAsync(hs + kTraceOff, h->d_small + kTraceOff, (size_t)trace_steps * 12 * sizeof(float),
-                           hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
@@ -649,6 +664,30 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   out_pose_world[2] = hs[5];
   if (n != 0 && cov)
     for (int i = 0; i < 9; ++i) cov[i] = hs[6 + i];
+  return HSM_OK;
+}
+
+// stage a host scan where the matcher can read it: pinned mapped host memory when it will be read
+// once (register resident), device memory otherwise
+static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, size_t& d_cap, const float2** out) {
+  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0) {
+    if ((size_t)n > h->h_scan_pinned_cap) {
+      if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
+      h->h_scan_pinned = nullptr;
+      h->h_scan_pinned_cap = 0;
+      const size_t want = n < 4096 ? 4096 : (size_t)n + n / 2;
+      HIP_TRY(hipHostMalloc((void**)&h->h_scan_pinned, want * sizeof(float2), hipHostMallocMapped));
+      h->h_scan_pinned_cap = want;
+    }
+    if (n > 0) memcpy(h->h_scan_pinned, pts_xy, (size_t)n * sizeof(float2));
+    float2* dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&dev, h->h_scan_pinned, 0));
+    *out = dev;
+    return HSM_OK;
+  }
+  if (int rc = ensure_scan_capacity(d_buf, d_cap, (size_t)n)) return rc;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(d_buf, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  *out = d_buf;
   return HSM_OK;
 }
 
@@ -685,14 +724,15 @@ static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_x
     h->retained_origo[1] = origo ? origo[1] : 0.0f;
     h->retained_valid = true;
   }
-  if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)n)) return rc;
-  if (n > 0)
-    HIP_TRY(hipMemcpyAsync(h->d_retained, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  h->d_retained_current = h->levels.size() > 1;
+  const float2* pts = nullptr;
+  if (int rc = stage_scan(h, pts_xy, n, h->d_retained, h->d_retained_cap, &pts)) return rc;
+  // the device copy of the retained scan is (re)uploaded lazily by the next update when the
+  // matcher read the scan from pinned host memory
+  h->d_retained_current = h->levels.size() > 1 && pts == h->d_retained;
   MatchParams P;
   memset(&P, 0, sizeof P);
   fill_schedule(h, P);
-  return match_single(h, P, begin_world, h->d_retained, n, out_pose_world, cov, trace, trace_steps);
+  return match_single(h, P, begin_world, pts, n, out_pose_world, cov, trace, trace_steps);
 }
 
 int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy, int n,
@@ -702,15 +742,14 @@ int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const flo
     return fail(HSM_ERR_INVALID, "hsm_match_level: bad argument");
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
-  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
-  if (n > 0)
-    HIP_TRY(hipMemcpyAsync(h->d_scan, pts_level_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  const float2* pts = nullptr;
+  if (int rc = stage_scan(h, pts_level_xy, n, h->d_scan, h->d_scan_cap, &pts)) return rc;
   MatchParams P;
   memset(&P, 0, sizeof P);
   P.lv[level] = level_view(h->levels[level], 1.0f, 1 + max_iterations);
   P.first_level = level;
   P.last_level = level;
-  return match_single(h, P, begin_world, h->d_scan, n, out_pose_world, cov);
+  return match_single(h, P, begin_world, pts, n, out_pose_world, cov);
 }
 
 int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2]) {
@@ -728,16 +767,23 @@ int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_x
   // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
   const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
   if (h->levels.size() > 1) {
-    if (rn > 0 && !h->d_retained_current) {
-      if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)rn)) return rc;
-      HIP_TRY(hipMemcpyAsync(h->d_retained, h->retained_pts.data(), (size_t)rn * sizeof(float2),
-                             hipMemcpyHostToDevice, h->stream));
-      h->d_retained_current = true;
+    const float2* d_coarse = nullptr;
+    if (rn == n && n > 0 && !h->d_retained_current &&
+        memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0) {
+      d_coarse = h->d_scan;  // the usual flow: update with the container that was just matched
+    } else {
+      if (rn > 0 && !h->d_retained_current) {
+        if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)rn)) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_retained, h->retained_pts.data(), (size_t)rn * sizeof(float2),
+                               hipMemcpyHostToDevice, h->stream));
+        h->d_retained_current = true;
+      }
+      d_coarse = h->d_retained;  // read only after a possible (re)allocation above
     }
     for (size_t l = 1; l < h->levels.size(); ++l) {
       const float factor = (float)(1.0 / pow(2.0, (double)l));
       const float ol[2] = {h->retained_origo[0] * factor, h->retained_origo[1] * factor};  // setFrom :48
-      if (int rc = update_level(h, (int)l, pose_world, h->d_retained, h->retained_pts.data(), rn, factor, ol))
+      if (int rc = update_level(h, (int)l, pose_world, d_coarse, h->retained_pts.data(), rn, factor, ol))
         return rc;
     }
   }
