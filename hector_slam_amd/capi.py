@@ -57,6 +57,10 @@ SIGNATURES = {
     "hsm_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
     "hsm_update_by_scan": (_i, [_vp, _f32p, _vp, _i, _f32p]),
     "hsm_update_by_scan_level": (_i, [_vp, _i, _f32p, _vp, _i, _f32p]),
+    "hsm_ingest_laser_scan": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
+    "hsm_match_ingested": (_i, [_vp, _f32p, _f32p, _f32p]),
+    "hsm_update_by_ingested": (_i, [_vp, _f32p]),
+    "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
     "hsm_world_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -217,6 +221,34 @@ class MapRepMultiMap:
         sx, sy, _, _ = self.level_info(level)
         out = np.empty((sy, sx), np.float32)
         _check(self._lib.hsm_download_prob(self._h, level, out.reshape(-1)), "hsm_download_prob")
+        return out
+
+    # ---- rows next to the path (ROS-node side) -------------------------------------
+    def ingest_laser_scan(self, ranges, angle_min, angle_increment, range_min, range_max, scale_to_map=None):
+        """rosLaserScanToDataContainer on the device; returns the (n_valid, 2) endpoints (host copy)."""
+        r = np.ascontiguousarray(ranges, np.float32).reshape(-1)
+        out = np.empty((r.size, 2), np.float32)
+        m = _i()
+        s = self.getScaleToMap() if scale_to_map is None else scale_to_map
+        _check(self._lib.hsm_ingest_laser_scan(self._h, r.ctypes.data if r.size else None, r.size, angle_min,
+                                               angle_increment, range_min, range_max, s, out.ctypes.data,
+                                               C.byref(m)), "hsm_ingest_laser_scan")
+        return out[:m.value].copy()
+
+    def match_ingested(self, beginEstimateWorld, covMatrix=None):
+        out = np.empty(3, np.float32)
+        cov = np.zeros(9, np.float32) if covMatrix is None else _v(covMatrix, 9).copy()
+        _check(self._lib.hsm_match_ingested(self._h, _v(beginEstimateWorld, 3), out, cov), "hsm_match_ingested")
+        return out, cov
+
+    def update_by_ingested(self, robotPoseWorld):
+        _check(self._lib.hsm_update_by_ingested(self._h, _v(robotPoseWorld, 3)), "hsm_update_by_ingested")
+
+    def occupancy_grid(self, level=0):
+        """publishMap's int8 grid: -1 unknown, 0 free, 100 occupied"""
+        sx, sy, _, _ = self.level_info(level)
+        out = np.empty((sy, sx), np.int8)
+        _check(self._lib.hsm_occupancy_grid(self._h, level, out.ctypes.data), "hsm_occupancy_grid")
         return out
 
     # ---- batched extension ---------------------------------------------------------------

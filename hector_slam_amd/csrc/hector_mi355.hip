@@ -107,6 +107,17 @@ struct hsm_ctx {
   // matcher ONCE (they stay in VGPRs); results written by the kernel straight into h_small
   float2* h_scan_pinned = nullptr;
   size_t h_scan_pinned_cap = 0;
+  // ingested scan (hsm_ingest_laser_scan): device container + host copy, sensor trig table cache
+  float* d_ranges = nullptr;
+  float2* d_trig = nullptr;
+  float2* d_ingest = nullptr;
+  size_t ingest_cap = 0;
+  std::vector<float> h_ingest;      // endpoints as the matcher/updater see them (host copy)
+  int ingest_n = -1;                // -1 = nothing ingested yet
+  float trig_a0 = 0.f, trig_inc = 0.f;
+  int trig_n = -1;
+  signed char* d_occ = nullptr;     // occupancy export staging
+  size_t d_occ_cap = 0;
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
@@ -508,6 +519,10 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);
   (void)hipFree(h->d_cells);
+  (void)hipFree(h->d_ranges);
+  (void)hipFree(h->d_trig);
+  (void)hipFree(h->d_ingest);
+  (void)hipFree(h->d_occ);
   if (h->h_scan_pinned) (void)hipHostFree(h->h_scan_pinned);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -692,7 +707,8 @@ static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, si
 }
 
 static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
-                      float out_pose_world[3], float cov[9], float* trace, int trace_steps);
+                      float out_pose_world[3], float cov[9], float* trace, int trace_steps,
+                      const float2* d_prestaged = nullptr);
 
 int hsm_match(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
               float out_pose_world[3], float cov[9]) {
@@ -710,7 +726,8 @@ int hsm_match_trace(hsm_ctx* h, const float begin_world[3], const float* pts_xy,
 }
 
 static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_xy, int n, const float origo[2],
-                      float out_pose_world[3], float cov[9], float* trace, int trace_steps) {
+                      float out_pose_world[3], float cov[9], float* trace, int trace_steps,
+                      const float2* d_prestaged) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   if (!begin_world || !out_pose_world || n < 0 || (n > 0 && !pts_xy))
     return fail(HSM_ERR_INVALID, "hsm_match: bad argument");
@@ -724,8 +741,9 @@ static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_x
     h->retained_origo[1] = origo ? origo[1] : 0.0f;
     h->retained_valid = true;
   }
-  const float2* pts = nullptr;
-  if (int rc = stage_scan(h, pts_xy, n, h->d_retained, h->d_retained_cap, &pts)) return rc;
+  const float2* pts = d_prestaged;
+  if (!pts)
+    if (int rc = stage_scan(h, pts_xy, n, h->d_retained, h->d_retained_cap, &pts)) return rc;
   // the device copy of the retained scan is (re)uploaded lazily by the next update when the
   // matcher read the scan from pinned host memory
   h->d_retained_current = h->levels.size() > 1 && pts == h->d_retained;
@@ -752,25 +770,39 @@ int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const flo
   return match_single(h, P, begin_world, pts, n, out_pose_world, cov);
 }
 
+static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2],
+                       const float2* d_prestaged);
+
 int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2]) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   if (!pose_world || n < 0 || (n > 0 && !pts_xy)) return fail(HSM_ERR_INVALID, "hsm_update_by_scan: bad argument");
   std::lock_guard<std::mutex> lk(h->mu);
+  return update_impl(h, pose_world, pts_xy, n, origo, nullptr);
+}
+
+// pts_xy: host copy of the endpoints (always needed: the touched bounding box is computed on the host);
+// d_prestaged: the same endpoints already on the device, or nullptr to upload them
+static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2],
+                       const float2* d_prestaged) {
   if (int rc = select_device(h)) return rc;
   const float zero[2] = {0.0f, 0.0f};
   const float* o = origo ? origo : zero;
   // level 0: the caller's container
-  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
-  if (n > 0)
-    HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  if (int rc = update_level(h, 0, pose_world, h->d_scan, pts_xy, n, 1.0f, o)) return rc;
+  const float2* d_level0 = d_prestaged;
+  if (!d_level0) {
+    if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+    if (n > 0)
+      HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    d_level0 = h->d_scan;
+  }
+  if (int rc = update_level(h, 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
   // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
   const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
   if (h->levels.size() > 1) {
     const float2* d_coarse = nullptr;
     if (rn == n && n > 0 && !h->d_retained_current &&
         memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0) {
-      d_coarse = h->d_scan;  // the usual flow: update with the container that was just matched
+      d_coarse = d_level0;  // the usual flow: update with the container that was just matched
     } else {
       if (rn > 0 && !h->d_retained_current) {
         if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)rn)) return rc;
@@ -805,6 +837,100 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
   if (int rc = update_level(h, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
                             origo_level ? origo_level : zero))
     return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
+                          float range_min, float range_max, float scale_to_map, float* out_pts_xy, int* out_n) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (n < 0 || (n > 0 && !ranges) || n > HSM_MAX_UPDATE_BEAMS)
+    return fail(HSM_ERR_INVALID, "hsm_ingest_laser_scan: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if ((size_t)n > h->ingest_cap) {
+    (void)hipFree(h->d_ranges);
+    (void)hipFree(h->d_trig);
+    (void)hipFree(h->d_ingest);
+    h->d_ranges = nullptr;
+    h->d_trig = nullptr;
+    h->d_ingest = nullptr;
+    h->ingest_cap = 0;
+    h->trig_n = -1;
+    const size_t want = n < 2048 ? 2048 : (size_t)n + n / 2;
+    HIP_TRY(hipMalloc((void**)&h->d_ranges, want * sizeof(float) + sizeof(int)));  // + the count
+    HIP_TRY(hipMalloc((void**)&h->d_trig, want * sizeof(float2)));
+    HIP_TRY(hipMalloc((void**)&h->d_ingest, want * sizeof(float2)));
+    h->ingest_cap = want;
+  }
+  if (h->trig_n != n || h->trig_a0 != angle_min || h->trig_inc != angle_increment) {
+    // the node's running fp32 angle and its float cos/sin (HectorMappingRos.cpp:487,502,505): sensor
+    // constants, evaluated once per geometry on the host exactly as the node does
+    std::vector<float> t(2 * (size_t)n);
+    float angle = angle_min;
+    for (int i = 0; i < n; ++i) {
+      t[2 * i] = cosf(angle);
+      t[2 * i + 1] = sinf(angle);
+      angle += angle_increment;
+    }
+    if (n > 0) HIP_TRY(hipMemcpy(h->d_trig, t.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+    h->trig_n = n;
+    h->trig_a0 = angle_min;
+    h->trig_inc = angle_increment;
+  }
+  int* d_count = reinterpret_cast<int*>(h->d_ranges + h->ingest_cap);
+  if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_ranges, ranges, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const float maxRangeForContainer = range_max - 0.1f;  // :493
+  hipLaunchKernelGGL(ingest_laser_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_ranges, h->d_trig, n,
+                     range_min, maxRangeForContainer, scale_to_map, h->d_ingest, d_count);
+  HIP_TRY(hipGetLastError());
+  int m = 0;
+  HIP_TRY(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->h_ingest.resize(2 * (size_t)m);
+  if (m > 0) HIP_TRY(hipMemcpy(h->h_ingest.data(), h->d_ingest, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost));
+  h->ingest_n = m;
+  if (out_pts_xy && m > 0) memcpy(out_pts_xy, h->h_ingest.data(), (size_t)m * sizeof(float2));
+  if (out_n) *out_n = m;
+  return HSM_OK;
+}
+
+int hsm_match_ingested(hsm_ctx* h, const float begin_world[3], float out_pose_world[3], float cov[9]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (h->ingest_n < 0) return fail(HSM_ERR_INVALID, "hsm_match_ingested: no scan ingested");
+  const float origo[2] = {0.0f, 0.0f};  // dataContainer.setOrigo(Vector2f::Zero()), HectorMappingRos.cpp:491
+  static const float dummy[2] = {0.0f, 0.0f};
+  const float* hp = h->ingest_n > 0 ? h->h_ingest.data() : dummy;
+  return match_impl(h, begin_world, hp, h->ingest_n, origo, out_pose_world, cov, nullptr, 0, h->d_ingest);
+}
+
+int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (!pose_world || h->ingest_n < 0) return fail(HSM_ERR_INVALID, "hsm_update_by_ingested: no scan ingested");
+  std::lock_guard<std::mutex> lk(h->mu);
+  const float origo[2] = {0.0f, 0.0f};
+  static const float dummy[2] = {0.0f, 0.0f};
+  const float* hp = h->ingest_n > 0 ? h->h_ingest.data() : dummy;
+  return update_impl(h, pose_world, hp, h->ingest_n, origo, h->d_ingest);
+}
+
+int hsm_occupancy_grid(hsm_ctx* h, int level, signed char* out) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!out) return fail(HSM_ERR_INVALID, "hsm_occupancy_grid: out is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  if (L.cells() > h->d_occ_cap) {
+    (void)hipFree(h->d_occ);
+    h->d_occ = nullptr;
+    h->d_occ_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->d_occ, L.cells()));
+    h->d_occ_cap = L.cells();
+  }
+  hipLaunchKernelGGL(occupancy_grid_kernel, dim3(grid_for(L.cells() / 4)), dim3(256), 0, h->stream, L.d_logodds,
+                     L.cells(), h->d_occ);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, h->d_occ, L.cells(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }

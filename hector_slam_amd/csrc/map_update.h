@@ -233,6 +233,65 @@ __global__ void pack_cells_kernel(LevelRW L, int x0, int y0, int w, int h, int2*
   }
 }
 
+// ---- rows next to the path ----------------------------------------------------
+// publishMap's cell loop (hector_mapping/src/HectorMappingRos.cpp:449-468): four cells per thread,
+// one coalesced 16-byte load and one 4-byte store
+__global__ void occupancy_grid_kernel(const float* __restrict__ logodds, size_t n, signed char* __restrict__ out) {
+  const size_t n4 = n / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 l = reinterpret_cast<const float4*>(logodds)[i];
+    char4 o;
+    o.x = l.x < 0.0f ? 0 : (l.x > 0.0f ? 100 : -1);  // isFree / isOccupied, GridMapLogOdds.h:76-84
+    o.y = l.y < 0.0f ? 0 : (l.y > 0.0f ? 100 : -1);
+    o.z = l.z < 0.0f ? 0 : (l.z > 0.0f ? 100 : -1);
+    o.w = l.w < 0.0f ? 0 : (l.w > 0.0f ? 100 : -1);
+    reinterpret_cast<char4*>(out)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float l = logodds[n4 * 4 + threadIdx.x];
+    out[n4 * 4 + threadIdx.x] = l < 0.0f ? 0 : (l > 0.0f ? 100 : -1);
+  }
+}
+
+// rosLaserScanToDataContainer (HectorMappingRos.cpp:483-507).  trig[i] = (cosf(angle_i), sinf(angle_i))
+// comes from the host (the running fp32 angle and the libm calls are the node's); this kernel applies
+// the range gate, the scale and the products, and compacts the survivors IN ORDER: one workgroup,
+// chunks of 1024 beams, wave ballot + LDS for the ordered offsets.
+__global__ void __launch_bounds__(1024) ingest_laser_scan_kernel(const float* __restrict__ ranges,
+                                                                const float2* __restrict__ trig, int n,
+                                                                float range_min, float max_range_for_container,
+                                                                float scale_to_map, float2* __restrict__ out,
+                                                                int* __restrict__ out_n) {
+  __shared__ int wave_count[16];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    float dist = i < n ? ranges[i] : 0.0f;
+    const bool keep = (i < n) && (dist > range_min) && (dist < max_range_for_container);
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_count[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_count[w];
+    if (keep) {
+      dist *= scale_to_map;
+      const float2 cs = trig[i];
+      out[off + __popcll(m & ((1ull << lane) - 1ull))] = make_float2(cs.x * dist, cs.y * dist);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_count[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out_n = base;
+}
+
 __global__ void rebuild_prob_kernel(LevelRW L) {
   const size_t n = (size_t)L.sx * L.sy;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

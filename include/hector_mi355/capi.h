@@ -145,6 +145,24 @@ int hsm_download_cells(hsm_ctx* h, int level, int x0, int y0, int x1, int y1, vo
  * x1 < x0 when nothing was touched */
 int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]);
 
+/* ---- the rows either side of the path; reference = the ROS node,
+ *      hector_mapping/src/HectorMappingRos.cpp.  Optional: the facade does not need them. ---- */
+/* replaces: rosLaserScanToDataContainer (HectorMappingRos.cpp:483-507): raw LaserScan ranges ->
+ * DataContainer endpoints (fp32 running angle, range gate (range_min, range_max - 0.1f), ordered
+ * compaction), computed on the device; the container STAYS on the device as the "ingested scan"
+ * (origo = 0,0 like the reference).  The cos/sin table of the sensor geometry (angle_min,
+ * angle_increment, n) is evaluated once on the host with the float libm calls the node uses and cached.
+ * out_pts_xy (host, capacity 2*n floats, may be NULL) receives the endpoints, *out_n their count. */
+int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
+                          float range_min, float range_max, float scale_to_map, float* out_pts_xy, int* out_n);
+/* hsm_match / hsm_update_by_scan on the ingested scan (no endpoint upload) */
+int hsm_match_ingested(hsm_ctx* h, const float begin_world[3], float out_pose_world[3], float cov[9]);
+int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]);
+/* replaces: publishMap's cell loop (HectorMappingRos.cpp:449-468) with LogOddsCell::isFree/isOccupied
+ * (GridMapLogOdds.h:76-84): -1 unknown, 0 free (logOdds < 0), 100 occupied (logOdds > 0).
+ * out: host, sx*sy bytes, row major. */
+int hsm_occupancy_grid(hsm_ctx* h, int level, signed char* out);
+
 /* ---- parity / debug entry points (used by tests, not by the facade) ------------ */
 /* device probability plane p = e^l/(e^l+1) (GridMapLogOdds.h:163-166) */
 int hsm_download_prob(hsm_ctx* h, int level, float* prob);

@@ -617,6 +617,42 @@ void ho_proc_last_pose(void* h, float pose[3], float cov[9]) {
   for (int i = 0; i < 3; ++i) pose[i] = c.lastScanMatchPose[i];
   for (int i = 0; i < 9; ++i) cov[i] = c.lastScanMatchCov[i];
 }
+// f2: HectorMappingRos::publishMap cell loop (HM/src/HectorMappingRos.cpp:449-468) with
+// LogOddsCell::isFree / isOccupied (GridMapLogOdds.h:76-84)
+void ho_occupancy_grid(void* h, int level, signed char* out) {
+  const Level& L = ((Ctx*)h)->levels[level];
+  const int size = L.sx * L.sy;
+  memset(out, -1, (size_t)size);
+  for (int i = 0; i < size; ++i) {
+    if (L.logOdds[i] < 0.0f) {
+      out[i] = 0;
+    } else if (L.logOdds[i] > 0.0f) {
+      out[i] = 100;
+    }
+  }
+}
+
+// f1: HectorMappingRos::rosLaserScanToDataContainer (HM/src/HectorMappingRos.cpp:483-507).  `angle` is a
+// float accumulated by repeated += (sequential rounding); cos/sin bind to the float overloads in the
+// node's translation unit.
+int ho_laser_scan_to_container(const float* ranges, int n, float angle_min, float angle_increment,
+                               float range_min, float range_max, float scaleToMap, float* out_pts) {
+  float angle = angle_min;
+  int m = 0;
+  const float maxRangeForContainer = range_max - 0.1f;
+  for (int i = 0; i < n; ++i) {
+    float dist = ranges[i];
+    if ((dist > range_min) && (dist < maxRangeForContainer)) {
+      dist *= scaleToMap;
+      out_pts[2 * m] = cosf(angle) * dist;
+      out_pts[2 * m + 1] = sinf(angle) * dist;
+      ++m;
+    }
+    angle += angle_increment;
+  }
+  return m;
+}
+
 float ho_normalize_angle(float a) { return normalize_angle(a); }
 int ho_pose_difference_larger_than(const float p1[3], const float p2[3], float d, float a) {
   return pose_difference_larger_than(p1, p2, d, a) ? 1 : 0;

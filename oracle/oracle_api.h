@@ -84,6 +84,15 @@ void ORF(proc_last_pose)(void* h, float pose[3], float cov[9]);
 float ORF(normalize_angle)(float a);
 int ORF(pose_difference_larger_than)(const float p1[3], const float p2[3], float dist, float ang);
 
+/* ---- rows next to the path, restated from the ROS node hector_mapping/src/HectorMappingRos.cpp */
+/* f2: publishMap's cell loop (:449-468): -1 unknown, 0 if isFree (logOdds < 0), 100 if isOccupied (> 0);
+ * GridMapLogOdds.h:76-84 */
+void ORF(occupancy_grid)(void* h, int level, signed char* out);
+/* f1: rosLaserScanToDataContainer (:483-507): fp32 running angle, range gate (range_min, range_max - 0.1f),
+ * float cos/sin; returns the number of endpoints written to out_pts (capacity n). */
+int ORF(laser_scan_to_container)(const float* ranges, int n, float angle_min, float angle_increment,
+                                 float range_min, float range_max, float scale_to_map, float* out_pts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ def _load(kind: str):
         "proc_set_thresholds": (None, [vp, f, f]),
         "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
         "proc_last_pose": (None, [vp, _f32p, _f32p]),
+        "occupancy_grid": (None, [vp, i, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
+        "laser_scan_to_container": (i, [_f32p, i, f, f, f, f, f, _f32p]),
         "normalize_angle": (f, [f]),
         "pose_difference_larger_than": (i, [_f32p, _f32p, f, f]),
     }
@@ -203,6 +205,19 @@ class Oracle:
         cov = np.empty(9, np.float32)
         self.f["proc_last_pose"](self.h, pose, cov)
         return pose, cov
+
+    def occupancy_grid(self, level):
+        sx, sy, _, _ = self.level_info(level)
+        out = np.empty((sy, sx), np.int8)
+        self.f["occupancy_grid"](self.h, level, out)
+        return out
+
+    def laser_scan_to_container(self, ranges, angle_min, angle_increment, range_min, range_max, scale_to_map):
+        r = np.ascontiguousarray(ranges, np.float32)
+        out = np.empty(2 * r.size, np.float32)
+        m = self.f["laser_scan_to_container"](r, r.size, angle_min, angle_increment, range_min, range_max,
+                                              scale_to_map, out)
+        return out[:2 * m].reshape(m, 2).copy()
 
     def normalize_angle(self, a) -> float:
         return self.f["normalize_angle"](float(a))

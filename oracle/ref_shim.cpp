@@ -204,4 +204,29 @@ int hr_pose_difference_larger_than(const float p1[3], const float p2[3], float d
   return util::poseDifferenceLargerThan(v3(p1), v3(p2), d, a) ? 1 : 0;
 }
 
+// f2 through the reference's own GridMap::isFree / isOccupied (GridMapLogOdds.h:76-84)
+void hr_occupancy_grid(void* h, int level, signed char* out) {
+  const RefGridMap& g = ((Ref*)h)->proc->getGridMap(level);
+  const int size = g.getSizeX() * g.getSizeY();
+  for (int i = 0; i < size; ++i) out[i] = g.isFree(i) ? 0 : (g.isOccupied(i) ? 100 : -1);
+}
+// f1 lives in the ROS node (needs sensor_msgs); only the restatement exists -- forwarded so both
+// libraries export the same symbols
+int hr_laser_scan_to_container(const float* r, int n, float a0, float inc, float rmin, float rmax, float s, float* out) {
+  float angle = a0;
+  int m = 0;
+  const float maxRangeForContainer = rmax - 0.1f;
+  for (int i = 0; i < n; ++i) {
+    float dist = r[i];
+    if ((dist > rmin) && (dist < maxRangeForContainer)) {
+      dist *= s;
+      out[2 * m] = cos(angle) * dist;  // unqualified, float argument: resolves as in the node's TU
+      out[2 * m + 1] = sin(angle) * dist;
+      ++m;
+    }
+    angle += inc;
+  }
+  return m;
+}
+
 }  // extern "C"

@@ -1,0 +1,124 @@
+"""Rows next to the hot path: LaserScan ingestion (rosLaserScanToDataContainer,
+hector_mapping/src/HectorMappingRos.cpp:483-507) and occupancy export (publishMap's cell loop, :449-468).
+Integer / byte / index work: BIT-EXACT against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import bits, make_oracle
+
+
+def synthetic_ranges(rng, n, lo=0.0, hi=35.0):
+    r = rng.uniform(lo, hi, n).astype(np.float32)
+    # sprinkle the values a real driver produces: inf (no return), NaN, 0, exactly the gates
+    idx = rng.choice(n, size=max(n // 10, 1), replace=False)
+    r[idx[0::5]] = np.inf
+    r[idx[1::5]] = np.nan
+    r[idx[2::5]] = 0.0
+    r[idx[3::5]] = np.float32(0.4)
+    r[idx[4::5]] = np.float32(30.0) - np.float32(0.1)
+    return r
+
+
+def test_oracle_node_rows_restatement_matches_reference_types(oracle_mod, small_scene):
+    """CPU: the two checkers agree (occupancy goes through the reference's own isFree/isOccupied in hr)"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref not built")
+    sc = small_scene
+    a, b = make_oracle(oracle_mod, "ho", sc), make_oracle(oracle_mod, "hr", sc)
+    ga, gb = a.occupancy_grid(0), b.occupancy_grid(0)
+    assert np.array_equal(ga, gb) and set(np.unique(ga)) == {-1, 0, 100}
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 181, 1081):
+        r = synthetic_ranges(rng, n) if n else np.zeros(0, np.float32)
+        pa = a.laser_scan_to_container(r, -2.35619449, 0.00436332, 0.4, 30.0, 20.0)
+        pb = b.laser_scan_to_container(r, -2.35619449, 0.00436332, 0.4, 30.0, 20.0)
+        assert np.array_equal(bits(pa), bits(pb))
+        if n:
+            keep = (r > np.float32(0.4)) & (r < np.float32(30.0) - np.float32(0.1))
+            assert pa.shape[0] == keep.sum()
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import torch
+    assert torch.cuda.is_available()
+    from hector_slam_amd import capi as m
+    m.load_library()
+    return m
+
+
+@pytest.mark.gpu
+def test_ingest_laser_scan_bit_exact(capi, oracle_mod, pyramid_scene):
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    rng = np.random.default_rng(2)
+    s = g.getScaleToMap()
+    geoms = [(-2.35619449, 0.00436332, 1081), (-1.5707964, 0.017453292, 181), (-3.1415927, 0.00038349519, 16384),
+             (0.3, -0.01, 700), (-2.35619449, 0.00436332, 1081)]
+    for a0, inc, n in geoms:
+        for trial in range(3):
+            r = synthetic_ranges(rng, n)
+            got = g.ingest_laser_scan(r, a0, inc, 0.4, 30.0)
+            ref = o.laser_scan_to_container(r, a0, inc, 0.4, 30.0, s)
+            assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (a0, inc, n, trial)
+    # edge cases: empty scan, nothing valid, everything valid, sizes around the 1024-beam chunk
+    assert g.ingest_laser_scan(np.zeros(0, np.float32), 0.0, 0.1, 0.4, 30.0).shape == (0, 2)
+    assert g.ingest_laser_scan(np.full(500, np.inf, np.float32), 0.0, 0.01, 0.4, 30.0).shape == (0, 2)
+    for n in (1, 63, 64, 65, 1023, 1024, 1025, 2049):
+        r = rng.uniform(1.0, 20.0, n).astype(np.float32)
+        got = g.ingest_laser_scan(r, -1.0, 0.002, 0.4, 30.0)
+        ref = o.laser_scan_to_container(r, -1.0, 0.002, 0.4, 30.0, s)
+        assert got.shape[0] == n and np.array_equal(bits(got), bits(ref)), n
+
+
+@pytest.mark.gpu
+def test_ingested_scan_drives_match_and_update_identically(capi, oracle_mod, pyramid_scene):
+    """ranges -> device container -> matchData / updateByScan == the same calls fed with host endpoints"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    a = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    b = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    for m in (a, b):
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+    ang = synth.beam_angles(1081)
+    a0, inc = float(ang[0]), float(np.float32(synth.SCAN_SHAPES[1081][1]))
+    rng = np.random.default_rng(3)
+    for t in range(12):
+        r = sc.world.raycast(sc.build_poses[t], ang).astype(np.float32)
+        r = (r + rng.normal(0, 0.01, r.shape)).astype(np.float32)
+        pts = a.ingest_laser_scan(r, a0, inc, 0.4, 30.0)
+        assert pts.shape[0] > 900
+        pa, ca = a.match_ingested(sc.build_poses[t])
+        pb, cb = b.matchData(sc.build_poses[t], pts)
+        assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(ca), bits(cb))
+        a.update_by_ingested(sc.build_poses[t])
+        b.updateByScan(pts, sc.build_poses[t])
+    for lvl in range(sc.levels):
+        la, lb = a.download_level(lvl), b.download_level(lvl)
+        assert (la[0] != 0).sum() > 500
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1])
+
+
+@pytest.mark.gpu
+def test_occupancy_grid_bit_exact(capi, oracle_mod, pyramid_scene, small_scene):
+    for sc in (pyramid_scene, small_scene):
+        g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+        g.setUpdateFactorFree(0.4)
+        g.setUpdateFactorOccupied(0.9)
+        g.build_map(sc.build_poses[:30], sc.build_scans[:30])
+        o = make_oracle(oracle_mod, "ho", sc, build=False)
+        o.build_map(sc.build_poses[:30], sc.build_scans[:30])
+        for lvl in range(sc.levels):
+            got, ref = g.occupancy_grid(lvl), o.occupancy_grid(lvl)
+            assert np.array_equal(got, ref)
+            assert (ref == 100).sum() > 50 and (ref == 0).sum() > 1000 and (ref == -1).sum() > 1000
+    # odd-sized level (cells not a multiple of 4) and a fresh map (all unknown)
+    g = capi.MapRepMultiMap(0.1, 250, 250, 2)
+    assert (g.occupancy_grid(1) == -1).all() and g.occupancy_grid(1).shape == (125, 125)
+    lo = np.random.default_rng(4).normal(0, 1, (125, 125)).astype(np.float32)
+    lo[::7, ::3] = 0.0
+    g.upload_level(1, lo)
+    exp = np.where(lo < 0, 0, np.where(lo > 0, 100, -1)).astype(np.int8)
+    assert np.array_equal(g.occupancy_grid(1), exp)
