@@ -61,6 +61,7 @@ SIGNATURES = {
     "hsm_match_ingested": (_i, [_vp, _f32p, _f32p, _f32p]),
     "hsm_update_by_ingested": (_i, [_vp, _f32p]),
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
+    "hsm_likelihood_states": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
     "hsm_world_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -243,6 +244,15 @@ class MapRepMultiMap:
 
     def update_by_ingested(self, robotPoseWorld):
         _check(self._lib.hsm_update_by_ingested(self._h, _v(robotPoseWorld, 3)), "hsm_update_by_ingested")
+
+    def likelihood_states(self, level, states_map, pts):
+        """OccGridMapUtil::getLikelihoodForState for a batch of map-frame states; pts in level-0 units"""
+        st = np.ascontiguousarray(states_map, np.float32).reshape(-1, 3)
+        a, p, n = _pts(pts)
+        out = np.empty(st.shape[0], np.float32)
+        _check(self._lib.hsm_likelihood_states(self._h, level, st.shape[0], st.reshape(-1), p, n, out),
+               "hsm_likelihood_states")
+        return out
 
     def occupancy_grid(self, level=0):
         """publishMap's int8 grid: -1 unknown, 0 free, 100 occupied"""

@@ -627,6 +627,36 @@ __global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict
   out[i] = make_float4(t.M, gx, gy, rd);
 }
 
+// ---- f3: pose likelihood for a batch of map-frame states against ONE scan --------
+// OccGridMapUtil::getLikelihoodForState (OccGridMapUtil.h:184-214): residual = sum_i (1 - M_i),
+// likelihood = 1 - residual / size, with M from interpMapValue (:233-285) -- the same bilinear sample
+// as the matcher without the gradient.  One wavefront per state, beams strided over the lanes, the
+// texel gather and the zero-texel treatment of out-of-map beams shared with the matcher (an
+// out-of-map beam reads M = 0, i.e. funval = 1, exactly the reference's `return 0.0f`).
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, const float* __restrict__ states,
+                                                         int batch, const float2* __restrict__ pts, int n,
+                                                         float pt_scale, float* __restrict__ out_lh) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const float ex = states[3 * b], ey = states[3 * b + 1];
+  float sinRot, cosRot;
+  sincos_f32(states[3 * b + 2], sinRot, cosRot);
+  const LevelRegs R = level_regs<LAYOUT>(L);
+  const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+  float residual = 0.0f;
+  for (int i = lane; i < n; i += 64) {
+    const float2 p = pts[i];
+    BeamRot r;
+    const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+    const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+    residual += 1.0f - M;
+  }
+  residual = wave_allreduce(residual);
+  if (lane == 0) out_lh[b] = 1 - (residual / (float)n);
+}
+
 // device sin/cos sweep for the parity tests
 __global__ void sincos_debug_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
                                     float* __restrict__ c) {

@@ -914,6 +914,42 @@ int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]) {
   return update_impl(h, pose_world, hp, h->ingest_n, origo, h->d_ingest);
 }
 
+int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                          float* out_lh) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (batch < 0 || n < 0 || (batch > 0 && (!states_map || !out_lh)) || (n > 0 && !pts_xy))
+    return fail(HSM_ERR_INVALID, "hsm_likelihood_states: bad argument");
+  if (batch == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  const size_t need = (size_t)batch * 4 * sizeof(float);
+  if (need > h->d_batch_cap) {
+    if (h->d_batch) HIP_TRY(hipFree(h->d_batch));
+    h->d_batch = nullptr;
+    h->d_batch_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_batch, need));
+    h->d_batch_cap = need;
+  }
+  float* d_states = (float*)h->d_batch;
+  float* d_out = d_states + 3 * (size_t)batch;
+  HIP_TRY(hipMemcpyAsync(d_states, states_map, (size_t)batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const float factor = (float)(1.0 / pow(2.0, (double)level));
+  const LevelView v = level_view(h->levels[level], factor, 1);
+  const int grid = (batch + 3) / 4;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((likelihood_kernel<kLayoutPlane>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
+                       n, factor, d_out);
+  else
+    hipLaunchKernelGGL((likelihood_kernel<kLayoutQuad>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
+                       n, factor, d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_lh, d_out, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
 int hsm_occupancy_grid(hsm_ctx* h, int level, signed char* out) {
   if (int rc = valid_level(h, level)) return rc;
   if (!out) return fail(HSM_ERR_INVALID, "hsm_occupancy_grid: out is null");

@@ -158,6 +158,12 @@ int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_mi
 /* hsm_match / hsm_update_by_scan on the ingested scan (no endpoint upload) */
 int hsm_match_ingested(hsm_ctx* h, const float begin_world[3], float out_pose_world[3], float cov[9]);
 int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]);
+/* replaces: OccGridMapUtil::getLikelihoodForState (HSL/map/OccGridMapUtil.h:184-214) evaluated for
+ * `batch` MAP-frame states of `level` against one scan (pts: level-0 units, scaled by 2^-level here):
+ * out_lh[b] = 1 - sum_i(1 - M_i)/n -- the particle-weight primitive of the batched-hypotheses use case.
+ * Host pointers. */
+int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                          float* out_lh);
 /* replaces: publishMap's cell loop (HectorMappingRos.cpp:449-468) with LogOddsCell::isFree/isOccupied
  * (GridMapLogOdds.h:76-84): -1 unknown, 0 free (logOdds < 0), 100 occupied (logOdds > 0).
  * out: host, sx*sy bytes, row major. */

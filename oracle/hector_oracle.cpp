@@ -617,6 +617,41 @@ void ho_proc_last_pose(void* h, float pose[3], float cov[9]) {
   for (int i = 0; i < 3; ++i) pose[i] = c.lastScanMatchPose[i];
   for (int i = 0; i < 9; ++i) cov[i] = c.lastScanMatchCov[i];
 }
+// f3: OccGridMapUtil::interpMapValue (OccGridMapUtil.h:233-285), getResidualForState (:198-214),
+// getLikelihoodForResidual (:191-197), getLikelihoodForState (:184-189)
+static inline float interp_map_value(Level& L, float cx, float cy) {
+  if ((cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy)) return 0.0f;
+  const int ix = (int)cx, iy = (int)cy;
+  const float fx = cx - (float)ix, fy = cy - (float)iy;
+  int index = iy * L.sx + ix;
+  const float i0 = cached_prob(L, index);
+  ++index;
+  const float i1 = cached_prob(L, index);
+  index += L.sx - 1;
+  const float i2 = cached_prob(L, index);
+  ++index;
+  const float i3 = cached_prob(L, index);
+  const float xFacInv = (1.0f - fx);
+  const float yFacInv = (1.0f - fy);
+  return ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
+}
+void ho_likelihood_states(void* h, int level, int batch, const float* states, const float* pts, int n,
+                          float* out) {
+  Level& L = ((Ctx*)h)->levels[level];
+  for (int b = 0; b < batch; ++b) {
+    const Affine2 T = pose_transform(states[3 * b], states[3 * b + 1], states[3 * b + 2]);
+    float residual = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      float tx, ty;
+      affine_apply(T, pts[2 * i], pts[2 * i + 1], tx, ty);
+      const float funval = 1.0f - interp_map_value(L, tx, ty);
+      residual += funval;
+    }
+    const float sizef = (float)n;
+    out[b] = 1 - (residual / sizef);
+  }
+}
+
 // f2: HectorMappingRos::publishMap cell loop (HM/src/HectorMappingRos.cpp:449-468) with
 // LogOddsCell::isFree / isOccupied (GridMapLogOdds.h:76-84)
 void ho_occupancy_grid(void* h, int level, signed char* out) {

@@ -88,6 +88,10 @@ int ORF(pose_difference_larger_than)(const float p1[3], const float p2[3], float
 /* f2: publishMap's cell loop (:449-468): -1 unknown, 0 if isFree (logOdds < 0), 100 if isOccupied (> 0);
  * GridMapLogOdds.h:76-84 */
 void ORF(occupancy_grid)(void* h, int level, signed char* out);
+/* f3: OccGridMapUtil::getLikelihoodForState (OccGridMapUtil.h:184-214, interpMapValue :233-285) for
+ * `batch` map-frame states against one level-scaled scan: out_lh[b] = 1 - residual/size */
+void ORF(likelihood_states)(void* h, int level, int batch, const float* states_map, const float* pts_level,
+                            int n, float* out_lh);
 /* f1: rosLaserScanToDataContainer (:483-507): fp32 running angle, range gate (range_min, range_max - 0.1f),
  * float cos/sin; returns the number of endpoints written to out_pts (capacity n). */
 int ORF(laser_scan_to_container)(const float* ranges, int n, float angle_min, float angle_increment,

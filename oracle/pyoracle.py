@@ -65,6 +65,7 @@ def _load(kind: str):
         "proc_set_thresholds": (None, [vp, f, f]),
         "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
         "proc_last_pose": (None, [vp, _f32p, _f32p]),
+        "likelihood_states": (None, [vp, i, i, _f32p, _f32p, i, _f32p]),
         "occupancy_grid": (None, [vp, i, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
         "laser_scan_to_container": (i, [_f32p, i, f, f, f, f, f, _f32p]),
         "normalize_angle": (f, [f]),
@@ -205,6 +206,14 @@ class Oracle:
         cov = np.empty(9, np.float32)
         self.f["proc_last_pose"](self.h, pose, cov)
         return pose, cov
+
+    def likelihood_states(self, level, states_map, pts_level):
+        st = np.ascontiguousarray(states_map, np.float32).reshape(-1, 3)
+        p = _pts(pts_level)
+        out = np.empty(st.shape[0], np.float32)
+        self.f["likelihood_states"](self.h, level, st.shape[0], st.reshape(-1), p.reshape(-1) if p.size else
+                                    np.zeros(2, np.float32), p.shape[0], out)
+        return out
 
     def occupancy_grid(self, level):
         sx, sy, _, _ = self.level_info(level)

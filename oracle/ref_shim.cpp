@@ -204,6 +204,12 @@ int hr_pose_difference_larger_than(const float p1[3], const float p2[3], float d
   return util::poseDifferenceLargerThan(v3(p1), v3(p2), d, a) ? 1 : 0;
 }
 
+// f3 through the reference's own OccGridMapUtil::getLikelihoodForState
+void hr_likelihood_states(void* h, int level, int batch, const float* states, const float* pts, int n, float* out) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, 0);
+  for (int b = 0; b < batch; ++b) out[b] = r->level(level).gridMapUtil->getLikelihoodForState(v3(states + 3 * b), dc);
+}
 // f2 through the reference's own GridMap::isFree / isOccupied (GridMapLogOdds.h:76-84)
 void hr_occupancy_grid(void* h, int level, signed char* out) {
   const RefGridMap& g = ((Ref*)h)->proc->getGridMap(level);

@@ -122,3 +122,34 @@ def test_occupancy_grid_bit_exact(capi, oracle_mod, pyramid_scene, small_scene):
     g.upload_level(1, lo)
     exp = np.where(lo < 0, 0, np.where(lo > 0, 100, -1)).astype(np.int8)
     assert np.array_equal(g.occupancy_grid(1), exp)
+
+
+@pytest.mark.gpu
+def test_likelihood_states_matches_reference(capi, oracle_mod, pyramid_scene):
+    """f3: getLikelihoodForState for 7-sigma-point style hypothesis sets (getCovarianceForPose's pattern,
+    OccGridMapUtil.h:106-160) and a 4096-particle cloud; per-beam M is bit-exact, the residual sum differs
+    only in summation order (tree vs the reference's 1081-term sequential fp32 chain, whose own rounding is ~sqrt(n)*eps): |dlh| <= 1e-5"""
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    kinds = ["ho"] + (["hr"] if oracle_mod.available("hr") else [])
+    orc = {k: make_oracle(oracle_mod, k, sc) for k in kinds}
+    rng = np.random.default_rng(9)
+    for lvl in range(sc.levels):
+        f = np.float32(1.0 / 2 ** lvl)
+        for q in range(4):
+            pm = orc["ho"].map_coords_pose(lvl, sc.query_truth[q])
+            x, y, a = (float(v) for v in pm)
+            sig = np.array([[x + 1.5, y, a], [x - 1.5, y, a], [x, y + 1.5, a], [x, y - 1.5, a], [x, y, a + 0.05],
+                            [x, y, a - 0.05], [x, y, a]], np.float32)
+            cloud = (pm[None, :] + rng.normal(0, [2.0, 2.0, 0.05], (4096, 3))).astype(np.float32)
+            far = np.array([[-50.0, 3.0, 0.1], [1e6, 1e6, 0.0]], np.float32)  # (almost) everything out of map
+            states = np.concatenate([sig, cloud, far])
+            got = g.likelihood_states(lvl, states, sc.query_scans[q])
+            for k in kinds:
+                ref = orc[k].likelihood_states(lvl, states, sc.query_scans[q] * f)
+                assert np.abs(got - ref).max() <= 1e-5, (lvl, q, k, np.abs(got - ref).max())
+            assert got[6] > got[:6].max() - 1e-3 and got[-1] == 0.0  # truth is (near) the best sigma point
+    assert g.likelihood_states(0, np.zeros((0, 3), np.float32), sc.query_scans[0]).shape == (0,)
