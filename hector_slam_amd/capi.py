@@ -95,6 +95,8 @@ def load_library(build_if_missing: bool = True):
     if _lib is not None:
         return _lib
     path = _build.build_native() if build_if_missing else _build.LIB
+    if os.environ.get("HSM_LIB"):  # kernel A/B experiments: an alternative build of the same library
+        path = os.environ["HSM_LIB"]
     if not os.path.exists(path):
         raise HsmError(f"{path} not found and could not be built; hector_slam_amd has no CPU fallback")
     lib = C.CDLL(path)

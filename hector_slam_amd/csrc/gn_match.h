@@ -39,7 +39,17 @@ namespace hsm {
 constexpr int kMaxLevels = 8;
 constexpr int kLayoutQuad = 1;
 constexpr int kLayoutPlane = 2;
-constexpr int kUnroll = 4;  // texel gathers a lane keeps in flight (register-resident form)
+// HSM_PIPELINE=1 issues the gather of beam k+1 before beam k is consumed; HSM_UNROLL=n gathers n beams
+// back to back before consuming them.  Measured on MI355X (profiles/r01/README.md): one beam at a
+// time is fastest (372 M it/s; pipelined 358; chunks of 2 / 4 / 6 / 9: 359 / 342 / 340 / 309) --
+// the four waves per SIMD already interleave, extra texels in flight only cost registers.
+#ifndef HSM_PIPELINE
+#define HSM_PIPELINE 0
+#endif
+#ifndef HSM_UNROLL
+#define HSM_UNROLL 1
+#endif
+constexpr int kUnroll = HSM_UNROLL;  // texel gathers a lane keeps in flight (register-resident form)
 
 // Eigen::Affine2f as the reference builds it: 2x2 linear (column major) + translation.
 struct Affine2 {
@@ -223,7 +233,13 @@ __device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
   if (LAYOUT == kLayoutQuad) {
     const unsigned index = oob ? (unsigned)L.zero_index : quad_index(ix, iy, L.tiles_x, L.sx);
     // 32-bit byte offset on a uniform base: one global_load_dwordx4 with an SGPR base address
+#if defined(HSM_EXP_NOLOAD)  // experiment: the beam body without any texel traffic
+    const float4 q = make_float4(__uint_as_float(index | 0x3f000000u), 0.25f, 0.75f, __uint_as_float((index >> 3) | 0x3f000000u));
+#elif defined(HSM_EXP_SAMELINE)  // experiment: every lane reads the same texel
+    const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)((index & 0u) + 4096u));
+#else
     const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(index << 4));
+#endif
     b.lo = f2{q.x, q.y};
     b.hi = f2{q.z, q.w};
   } else {
@@ -513,6 +529,26 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       acc.zero();
       const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
       if (in_regs) {
+#if HSM_PIPELINE
+        // Software pipeline of depth one (experiment switch): the texel gather of beam k+1 is issued
+        // BEFORE beam k is consumed.  The accumulation order stays k = 0, 1, 2 ... so the bits equal
+        // the memory loop's.
+        BeamRot rot_cur, rot_nxt;
+        BeamSample cur = beam_fetch<LAYOUT>(R, e2, cs, sc, pt[0], rot_cur), nxt;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          if (k + 1 < NREG) nxt = beam_fetch<LAYOUT>(R, e2, cs, sc, pt[k + 1], rot_nxt);
+          beam_finish(cur, rot_cur, acc);
+          // Pin: the accumulators are final here ("+v") and no later gather may be hoisted above
+          // this point ("memory") -- exactly one texel in flight while one is being consumed.
+          asm volatile(""
+                       : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
+                       :
+                       : "memory");
+          cur = nxt;
+          rot_cur = rot_nxt;
+        }
+#else
         // chunks of kUnroll beams: issue all gathers of a chunk, then consume them in beam order
         // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
 #pragma unroll
@@ -536,6 +572,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
                        :
                        : "memory");
         }
+#endif
       } else {
         for (int i = tid_in_team; i < n; i += T) {
           const float2 p = pts[i];

@@ -1,0 +1,14 @@
+#!/usr/bin/env python
+"""Build alternative libhector_mi355 variants (extra -D / -mllvm flags) into hector_slam_amd/lib/variants/
+for A/B runs: HSM_LIB=<path> python bench.py ...   usage: build_variants.py name:"flags" ..."""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hector_slam_amd import build as b
+out = os.path.join(os.path.dirname(b.LIB), "variants")
+os.makedirs(out, exist_ok=True)
+for spec in sys.argv[1:]:
+    name, flags = spec.split(":", 1)
+    dst = os.path.join(out, f"libhector_mi355_{name}.so")
+    cmd = [b.hipcc_path()] + b.FLAGS + flags.split() + ["-I", os.path.join(b._ROOT, "include"), "-I", os.path.join(b._PKG, "csrc"), b.SRC, "-o", dst]
+    subprocess.run(cmd, check=True)
+    print(dst)
