@@ -431,6 +431,15 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_iteration(N_BEAMS) * its * B
     achieved = bytes_per_launch / (kern_ms * 1e-3)
 
+    # HBM traffic of the dominant kernel from the committed PMC profile of THIS workload (rocprofv3 cannot run
+    # inside the timed process); null when the run is not the profiled configuration
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["gn_match_kernel"]
+        if B == BATCH_PER_GPU and args.levels == 1:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "scan-match GN iterations/sec (1081-beam, 2048^2 map)",
         "value": value, "unit": "GN it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -443,7 +452,12 @@ def main():
                    "kernel": cfg},
         "matchdata_per_s": total * args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None,
+                     "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
+                                     "correction calibrated on known-byte kernels), profiles/r01/traffic.json; the "
+                                     "algorithmic bytes are 13.5x larger because endpoints stay in VGPRs across the 6 "
+                                     "iterations and the texel plane is served from L2 -- frac > 1 is NOT an HBM "
+                                     "utilisation, the kernel is VALU-issue + texture-path bound (DESIGN.md 3.1)",
                      "kernel": "gn_match_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12},

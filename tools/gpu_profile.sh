@@ -19,6 +19,9 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_RE
   name=$(echo "$pmc" | tr ' ' '+')
   timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_$name.log" 2>&1 || echo "pmc $name failed" >> "$OUT/errors.log"
 done
+for pmc in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d "$OUT/calib_$pmc" -- python $ROOT/tools/calib_traffic.py > "$OUT/calib_$pmc.log" 2>&1
+done
 cd "$ROOT"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

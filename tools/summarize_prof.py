@@ -22,6 +22,15 @@ for f in find("stats/**/*kernel_stats.csv"):
             print(",".join(c[:70] for c in row))
 print()
 print("== PMC counters: mean per dispatch, by kernel ==")
+for f in find("calib_*/**/*counter_collection.csv"):
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            acc[row.get("Kernel_Name", "?").split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    print("# calibration (4096^2 level = 16777216 cells; expected KB: rebuild_prob R 65536 W 65536, rebuild_quad R 65536 W 262144, pack_cells R 131072 W 131072, fill_level W 458752)")
+    for k, cs in acc.items():
+        if k.startswith("hsm::"):
+            print("  ", k, {c: (round(sum(v) / len(v), 1), len(v)) for c, v in cs.items()})
 for f in find("pmc_*/**/*counter_collection.csv"):
     acc = defaultdict(lambda: defaultdict(list))
     with open(f) as fh:
@@ -30,6 +39,6 @@ for f in find("pmc_*/**/*counter_collection.csv"):
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("#", os.path.relpath(f, out))
     for k, cs in acc.items():
-        if "gn_match" not in k and "update_" not in k:
+        if "gn_match" not in k and "update_" not in k and "likelihood" not in k:
             continue
         print("  ", k, {c: (round(sum(v) / len(v), 1), len(v)) for c, v in cs.items()})
