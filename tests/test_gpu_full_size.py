@@ -106,7 +106,7 @@ def test_config4_share_4096map_pyramid(capi, oracle_mod):
     room scaled to 160 m x 120 m and a 120 m sensor so that the 204.8 m map is actually used.
     (With 0.0125 m cells instead, the 1 cm range noise spans a cell and the REFERENCE's own Gauss-Newton no
     longer settles -- it still moves 1.5 cm when restarted from its own result -- so 2 % of the scans amplify
-    last-bit differences beyond 1e-4 m; measured with tools/dev_stats.py)"""
+    last-bit differences beyond 1e-4 m; measured with tests/tools/dev_stats.py)"""
     from hector_slam_amd import synth
     sc = synth.make_scene(n_beams=1081, map_size=4096, levels=3, resolution=0.05, n_build=100, n_query=4096,
                           room=(160.0, 120.0), seed=77, range_max=120.0)

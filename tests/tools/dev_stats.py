@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Deviation statistics GPU vs oracle on a config (debug tool)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from hector_slam_amd import synth, capi
 from oracle import pyoracle
