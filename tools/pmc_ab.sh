@@ -1,8 +1,8 @@
 #!/bin/bash
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
-for v in base tile; do
-  if [ $v = tile ]; then export HSM_LIB=$ROOT/hector_slam_amd/lib/variants/libhector_mi355_tile.so; else unset HSM_LIB; fi
+for v in base ${VARIANTS:-tile}; do
+  if [ $v != base ]; then export HSM_LIB=$ROOT/hector_slam_amd/lib/variants/libhector_mi355_$v.so; else unset HSM_LIB; fi
   rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $ROOT/gpurun_out/ab_$v -- python $ROOT/bench.py --no-cpu --no-pyramid --steps 10 --warmup 2 > $ROOT/gpurun_out/ab_$v.log 2>&1
   python - <<PY
 import csv, glob, collections
