@@ -44,12 +44,13 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libhector_mi355.so (no CPU fallback exists)")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    tmp = f"{LIB}.{os.getpid()}.tmp"  # several ranks of one job may build at once: private temp, atomic rename
     cmd = [hipcc] + FLAGS + ["-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_PKG, "csrc"),
-                             SRC, "-o", LIB + ".tmp"]
+                             SRC, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 
