@@ -389,24 +389,21 @@ def main():
 
     def run(matcher, d_init, steps, warmup, gather=True):
         its = matcher.gn_iterations_per_match()
-        # HIP events on the launch stream.  Single GPU: ONE pair around the whole timed region (the launches
-        # queue back to back, so elapsed / steps is the kernel's average duration without a marker packet
-        # between consecutive kernels).  Multi GPU: one pair per step, because the all-gather sits between
-        # the matcher launches there.
-        per_step = world > 1
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(steps if per_step else 1)]
+        # HIP events on the launch stream: ONE pair around the whole timed region (the launches queue back to
+        # back, so elapsed / steps is the matcher's average duration per launch without a marker packet between
+        # consecutive kernels; the overlapped all-gather of N > 1 runs on RCCL's own stream)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def step(ev=None):
-            if ev:
-                ev[0].record(stream)
+        # N > 1: the one collective of the path -- an all-gather of the [B,3] poses -- is double buffered and
+        # asynchronous, so RCCL moves batch k's poses while the matcher already works on batch k+1
+        gatherer = sharding.AsyncRowGather(B, 3, dev) if (world > 1 and gather) else None
+
+        def step():
+            pose_buf = gatherer.next_local() if gatherer else d_pose
             matcher.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS,
-                                       d_pose.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
-            if ev:
-                ev[1].record(stream)
-            if world > 1 and gather:
-                return sharding.all_gather_rows(d_pose, total)
-            return d_pose
+                                       pose_buf.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
+            if gatherer:
+                gatherer.launch()
 
         for _ in range(warmup):
             step()
@@ -414,24 +411,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if not per_step:
-            evs[0][0].record(stream)
+        ev0.record(stream)
         for k in range(steps):
-            step(evs[k] if per_step else None)
-        if not per_step:
-            evs[0][1].record(stream)
+            step()
+        ev1.record(stream)
+        if gatherer:
+            gatherer.wait_all()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if gatherer:  # every rank holds all poses; keep this rank's own rows for the checks below
+            allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
+            d_pose.copy_(allp[rank * B:(rank + 1) * B])
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        if per_step:
-            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-        else:
-            kern_ms = evs[0][0].elapsed_time(evs[0][1]) / steps
+        kern_ms = ev0.elapsed_time(ev1) / steps
         return dt, kern_ms, its
 
     matcher = build_matcher(args.levels)

@@ -51,3 +51,55 @@ def all_gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor
         rb, re_ = shard_bounds(total, r, world)
         parts.append(out[r * m: r * m + (re_ - rb)])
     return torch.cat(parts, 0)
+
+
+class AsyncRowGather:
+    """Overlapped all-gather of equally sized per-rank result rows (the [B/G, 3] poses of a batched match).
+
+    The matcher of batch k+1 must not wait for the collective of batch k: results are written into one of
+    ``depth`` local buffers, the all-gather of that buffer is enqueued asynchronously (RCCL runs it on its own
+    stream, ordered after the compute stream's work at enqueue time), and the compute stream only waits for a
+    collective when its buffer comes up for reuse ``depth`` batches later.  With no process group initialised
+    it degenerates to handing the local buffer back.
+    """
+
+    def __init__(self, rows_per_rank: int, cols: int, device, dtype=torch.float32, depth: int = 2, group=None):
+        self.group = group
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.depth = depth
+        self.local = [torch.zeros((rows_per_rank, cols), dtype=dtype, device=device) for _ in range(depth)]
+        self.out = [torch.empty((self.world * rows_per_rank, cols), dtype=dtype, device=device) if self.dist else None
+                    for _ in range(depth)]
+        self.work = [None] * depth
+        self.k = 0
+
+    def next_local(self) -> torch.Tensor:
+        """buffer the next batch's results go into (waits, on the stream, for the collective that last used it)"""
+        slot = self.k % self.depth
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        return self.local[slot]
+
+    def launch(self) -> int:
+        """enqueue the all-gather of the buffer handed out by the last next_local(); returns its slot"""
+        slot = self.k % self.depth
+        if self.dist:
+            self.work[slot] = dist.all_gather_into_tensor(self.out[slot], self.local[slot], group=self.group,
+                                                          async_op=True)
+        self.k += 1
+        return slot
+
+    def result(self, slot: int) -> torch.Tensor:
+        """gathered [world * rows, cols] tensor of ``slot`` (waits for its collective)"""
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        return self.out[slot] if self.dist else self.local[slot]
+
+    def wait_all(self) -> None:
+        for s in range(self.depth):
+            if self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None

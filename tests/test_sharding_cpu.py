@@ -36,6 +36,55 @@ def _worker(rank, world, port, total, q):
         dist.destroy_process_group()
 
 
+def _worker_async(rank, world, port, rows, q):
+    sys.path.insert(0, ROOT)
+    from hector_slam_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sharding.AsyncRowGather(rows, 3, "cpu", depth=2)
+        ok = True
+        slots = []
+        for k in range(7):  # more batches than buffers: every slot is reused, results must never mix
+            buf = g.next_local()
+            buf.copy_(torch.full((rows, 3), float(100 * k + rank)))  # "the matcher wrote batch k"
+            slots.append((k, g.launch()))
+            if k >= 1:  # consume the previous batch while this one is in flight
+                kk, sl = slots[k - 1]
+                out = g.result(sl)
+                exp = torch.cat([torch.full((rows, 3), float(100 * kk + r)) for r in range(world)])
+                ok = ok and bool(torch.equal(out, exp))
+        g.wait_all()
+        out = g.result(slots[-1][1])
+        exp = torch.cat([torch.full((rows, 3), float(100 * 6 + r)) for r in range(world)])
+        q.put((rank, ok and bool(torch.equal(out, exp))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_async_gather_double_buffered():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, 4096, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_async_gather_without_process_group_is_identity():
+    from hector_slam_amd import sharding
+    g = sharding.AsyncRowGather(5, 3, "cpu")
+    b = g.next_local()
+    b.fill_(2.0)
+    s = g.launch()
+    assert torch.equal(g.result(s), torch.full((5, 3), 2.0))
+
+
 @pytest.mark.parametrize("total", [8, 9, 4097])
 def test_two_rank_gather_reassembles_batch(total):
     ctx = mp.get_context("spawn")
