@@ -251,6 +251,19 @@ def extra_workload(name: str, args, local_rank: int):
             pg, _ = m.matchData(init[q], scans[q])
             lat.append(time.perf_counter() - a)
         lat = np.array(lat[args.warmup:])
+        # the other half of HectorSlamProcessor::update: updateByScan on all levels + onMapUpdated, host call
+        m2 = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
+        m2.setUpdateFactorFree(0.4)
+        m2.setUpdateFactorOccupied(0.9)
+        ulat = []
+        for k in range(min(args.steps, 400) + 10):
+            q = k % len(build_scans)
+            m2.matchData(build_poses[q], build_scans[q])
+            a = time.perf_counter()
+            m2.updateByScan(build_scans[q], build_poses[q])
+            m2.onMapUpdated()
+            ulat.append(time.perf_counter() - a)
+        out["update_latency_us"] = {"median": float(np.median(ulat[10:])) * 1e6, "p90": float(np.percentile(ulat[10:], 90)) * 1e6}
         out.update({"value": its / float(np.median(lat)), "ms_per_step": float(np.median(lat)) * 1e3,
                     "config": {"workload": f"configs[1]: ONE {beams}-beam scan, {levels}-level {size}/{size // 2}/{size // 4} "
                                            f"pyramid, hsm_match host call (H2D + 1 launch + D2H), median of {args.steps}",

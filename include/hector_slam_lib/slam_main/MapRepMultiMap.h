@@ -11,9 +11,10 @@
 // and the log-odds update are HIP kernels on the GPU.  What stays on the host:
 //   * one hectorslam::GridMap per level as a MIRROR, because getGridMap() must hand out a real
 //     `const GridMap&` that the map publisher reads cell by cell from another thread
-//     (HectorMappingRos.cpp:435-481).  The mirror is refreshed inside updateByScan(), under the
-//     level's MapLockerInterface exactly where the reference writes its grid
-//     (MapProcContainer.h:103-116); only the bounding box the scan touched is downloaded.
+//     (HectorMappingRos.cpp:435-481).  The mirror is refreshed LAZILY: updateByScan() only grows a
+//     dirty cell box per level (under the level's MapLockerInterface, where the reference writes
+//     its grid, MapProcContainer.h:103-116); getGridMap() downloads that box when somebody actually
+//     asks for the grid -- the 0.5 Hz publisher, not the 40 Hz scan callback.
 //   * the DrawInterface / HectorDebugInfoInterface hooks (ScanMatcher.h:56-66,100-115): when
 //     either is non-null the match records a per-step trace on the device and the hooks are
 //     replayed from it in the reference's order.
@@ -27,6 +28,7 @@
 #include <cmath>
 #include <cstddef>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -68,6 +70,7 @@ public:
                 << " res y: " << resolution.y() << " (MI355X resident)\n";
       mirrors.push_back(new GridMap(mapResolution, resolution, Eigen::Vector2f(mid_offset_x, mid_offset_y)));
       mutexes.push_back(0);
+      dirty.push_back(DirtyBox());
       resolution /= 2;
       mapResolution *= 2.0f;
     }
@@ -87,16 +90,22 @@ public:
 
   virtual void reset()
   {
+    std::lock_guard<std::mutex> lk(mirrorMutex);
     hsm_reset(ctx);
     for (size_t i = 0; i < mirrors.size(); ++i) {
       mirrors[i]->reset();
+      dirty[i] = DirtyBox();
     }
   }
 
   virtual float getScaleToMap() const { return mirrors[0]->getScaleToMap(); }
 
   virtual int getMapLevels() const { return static_cast<int>(mirrors.size()); }
-  virtual const GridMap& getGridMap(int mapLevel) const { return *mirrors[mapLevel]; }
+  virtual const GridMap& getGridMap(int mapLevel) const
+  {
+    refreshMirror(mapLevel);
+    return *mirrors[mapLevel];
+  }
 
   virtual void addMapMutex(int i, MapLockerInterface* mapMutex)
   {
@@ -161,7 +170,7 @@ public:
       if (mutexes[i]) {
         mutexes[i]->lockMap();
       }
-      refreshMirror(static_cast<int>(i));
+      markDirty(static_cast<int>(i));
       if (mutexes[i]) {
         mutexes[i]->unlockMap();
       }
@@ -234,15 +243,40 @@ public:
   hsm_ctx* getDeviceContext() { return ctx; }
 
 protected:
-  // copy the cells the last update touched (device bounding box) into the host mirror and bump its
-  // update counter like OccGridMapBase::updateByScan does (OccGridMapBase.h:164 setUpdated())
-  void refreshMirror(int level)
+  struct DirtyBox {
+    int x0, y0, x1, y1;  // inclusive cell box changed on the device since the mirror was last refreshed
+    DirtyBox() : x0(0), y0(0), x1(-1), y1(-1) {}
+  };
+
+  // grow the level's dirty box by what the last update touched (device-side bounding box)
+  void markDirty(int level)
   {
-    GridMap& m = *mirrors[level];
+    std::lock_guard<std::mutex> lk(mirrorMutex);
     int bb[4];
     if (hsm_last_update_bbox(ctx, level, bb) == HSM_OK && bb[2] >= bb[0] && bb[3] >= bb[1]) {
-      LogOddsCell* first = &m.getCell(bb[0], bb[1]);
-      hsm_download_cells(ctx, level, bb[0], bb[1], bb[2], bb[3], first, m.getSizeX());
+      DirtyBox& d = dirty[level];
+      if (d.x1 < d.x0) {
+        d.x0 = bb[0]; d.y0 = bb[1]; d.x1 = bb[2]; d.y1 = bb[3];
+      } else {
+        if (bb[0] < d.x0) d.x0 = bb[0];
+        if (bb[1] < d.y0) d.y0 = bb[1];
+        if (bb[2] > d.x1) d.x1 = bb[2];
+        if (bb[3] > d.y1) d.y1 = bb[3];
+      }
+    }
+  }
+
+  // bring the host mirror of `level` up to date: download the dirty box as the reference's AoS cells and
+  // bump the update counter like OccGridMapBase::updateByScan does (OccGridMapBase.h:164 setUpdated())
+  void refreshMirror(int level) const
+  {
+    std::lock_guard<std::mutex> lk(mirrorMutex);
+    GridMap& m = *mirrors[level];
+    DirtyBox& d = dirty[level];
+    if (d.x1 >= d.x0 && d.y1 >= d.y0) {
+      LogOddsCell* first = &m.getCell(d.x0, d.y0);
+      hsm_download_cells(ctx, level, d.x0, d.y0, d.x1, d.y1, first, m.getSizeX());
+      d = DirtyBox();
     }
     while (m.getUpdateIndex() < hsm_update_index(ctx, level)) {
       m.setUpdated();
@@ -318,6 +352,8 @@ protected:
   hsm_ctx* ctx;
   std::vector<GridMap*> mirrors;
   std::vector<MapLockerInterface*> mutexes;
+  mutable std::vector<DirtyBox> dirty;
+  mutable std::mutex mirrorMutex;
   std::vector<float> traceBuf;
   DrawInterface* drawInterface;
   HectorDebugInfoInterface* debugInterface;
