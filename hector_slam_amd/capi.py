@@ -61,6 +61,7 @@ SIGNATURES = {
     "hsm_match_ingested": (_i, [_vp, _f32p, _f32p, _f32p]),
     "hsm_update_by_ingested": (_i, [_vp, _f32p]),
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
+    "hsm_ray_distances": (_i, [_vp, _i, _f, _f, _f, _i, _f32p, _f32p, _f32p, _f32p]),
     "hsm_likelihood_states": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -255,6 +256,29 @@ class MapRepMultiMap:
         _check(self._lib.hsm_likelihood_states(self._h, level, st.shape[0], st.reshape(-1), p, n, out),
                "hsm_likelihood_states")
         return out
+
+    def map_metadata(self, level=0):
+        """(origin_x, origin_y, resolution) as HectorMappingRos::setServiceGetMapData publishes them (:546-553)"""
+        sx, sy, cell, _ = self.level_info(level)
+        w = self.getWorldCoordsPose(level, np.zeros(3, np.float32))  # getWorldCoords(Vector2f::Zero())
+        half = np.float32(cell) * np.float32(0.5)
+        return float(np.float32(w[0]) - half), float(np.float32(w[1]) - half), float(cell)
+
+    def ray_distances(self, level, begin_world, end_world, origin_xy=None, resolution=None):
+        """DistanceMeasurementProvider::getDist for a batch of rays -> (dist[n], hit[n,2]; NaN where no hit)"""
+        b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 2)
+        e = np.ascontiguousarray(end_world, np.float32).reshape(-1, 2)
+        ox, oy, res = self.map_metadata(level)
+        if origin_xy is not None:
+            ox, oy = origin_xy
+        if resolution is not None:
+            res = resolution
+        dist = np.empty(b.shape[0], np.float32)
+        hit = np.full((b.shape[0], 2), np.nan, np.float32)
+        if b.shape[0]:
+            _check(self._lib.hsm_ray_distances(self._h, level, ox, oy, res, b.shape[0], b.reshape(-1), e.reshape(-1),
+                                               dist, hit.reshape(-1)), "hsm_ray_distances")
+        return dist, hit
 
     def occupancy_grid(self, level=0):
         """publishMap's int8 grid: -1 unknown, 0 free, 100 occupied"""

@@ -950,6 +950,50 @@ int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_
   return HSM_OK;
 }
 
+int hsm_ray_distances(hsm_ctx* h, int level, float origin_x, float origin_y, float resolution, int n,
+                      const float* begin_world_xy, const float* end_world_xy, float* out_dist, float* out_hit_xy) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (n < 0 || (n > 0 && (!begin_world_xy || !end_world_xy || !out_dist)) || !(resolution > 0.0f))
+    return fail(HSM_ERR_INVALID, "hsm_ray_distances: bad argument");
+  if (n == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  const size_t need = (size_t)n * 7 * sizeof(float);  // begin[2] end[2] dist[1] hit[2]
+  if (need > h->d_batch_cap) {
+    if (h->d_batch) HIP_TRY(hipFree(h->d_batch));
+    h->d_batch = nullptr;
+    h->d_batch_cap = 0;
+    HIP_TRY(hipMalloc(&h->d_batch, need));
+    h->d_batch_cap = need;
+  }
+  float* d = (float*)h->d_batch;
+  RayQueryParams P;
+  const Level& L = h->levels[level];
+  P.logodds = L.d_logodds;
+  P.sx = L.sx;
+  P.sy = L.sy;
+  P.origin_x = origin_x;
+  P.origin_y = origin_y;
+  P.scale = resolution;
+  P.inv_scale = 1.0f / resolution;  // CoordinateTransformer::setTransforms, HectorMapTools.h:64
+  P.begin_world = reinterpret_cast<const float2*>(d);
+  P.end_world = reinterpret_cast<const float2*>(d + 2 * (size_t)n);
+  P.out_hit = reinterpret_cast<float2*>(d + 4 * (size_t)n);
+  P.out_dist = d + 6 * (size_t)n;
+  P.n = n;
+  HIP_TRY(hipMemcpyAsync(d, begin_world_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(d + 2 * (size_t)n, end_world_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (out_hit_xy)  // in/out: rays without a hit keep the caller's values
+    HIP_TRY(hipMemcpyAsync(d + 4 * (size_t)n, out_hit_xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(ray_distance_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_dist, P.out_dist, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (out_hit_xy)
+    HIP_TRY(hipMemcpyAsync(out_hit_xy, P.out_hit, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
 int hsm_occupancy_grid(hsm_ctx* h, int level, signed char* out) {
   if (int rc = valid_level(h, level)) return rc;
   if (!out) return fail(HSM_ERR_INVALID, "hsm_occupancy_grid: out is null");

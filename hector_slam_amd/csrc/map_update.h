@@ -253,6 +253,63 @@ __global__ void occupancy_grid_kernel(const float* __restrict__ logodds, size_t 
   }
 }
 
+// f4: DistanceMeasurementProvider::getDist (hector_map_tools/.../HectorMapTools.h:133-234) for a batch of
+// rays, straight on the log-odds plane (a cell of the published grid is 100 <=> logOdds > 0).  One
+// wavefront per ray: lane k tests Bresenham steps k, k+64, ... through the closed form of the error
+// accumulator, a ballot finds the FIRST occupied step, and the search stops at that chunk -- the
+// sequential early-exit walk of the reference without walking sequentially.
+struct RayQueryParams {
+  const float* logodds;
+  int sx, sy;
+  float origin_x, origin_y, scale, inv_scale;  // CoordinateTransformer (:58-98)
+  const float2* begin_world;
+  const float2* end_world;
+  int n;
+  float* out_dist;
+  float2* out_hit;
+};
+
+__global__ void __launch_bounds__(256) ray_distance_kernel(const RayQueryParams P) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= P.n) return;
+  const float2 bw = P.begin_world[r], ew = P.end_world[r];
+  // getC2Coords(...).cast<int>(): ((world - origo) * inv_scale), truncated
+  const int x0 = (int)((bw.x - P.origin_x) * P.inv_scale), y0 = (int)((bw.y - P.origin_y) * P.inv_scale);
+  const int x1 = (int)((ew.x - P.origin_x) * P.inv_scale), y1 = (int)((ew.y - P.origin_y) * P.inv_scale);
+  float dist = -1.0f;
+  if (!((x0 < 0) || (x0 >= P.sx) || (y0 < 0) || (y0 >= P.sy)) && !((x1 < 0) || (x1 >= P.sx) || (y1 < 0) || (y1 >= P.sy))) {
+    const int dx = x1 - x0, dy = y1 - y0;
+    const unsigned int abs_dx = (unsigned int)(dx < 0 ? -dx : dx), abs_dy = (unsigned int)(dy < 0 ? -dy : dy);
+    const int offset_dx = dx > 0 ? 1 : -1;
+    const int offset_dy = (dy > 0 ? 1 : -1) * P.sx;
+    BeamLine b;
+    b.start = (unsigned int)(y0 * P.sx + x0);
+    if (abs_dx >= abs_dy) {
+      b.abs_da = abs_dx; b.abs_db = abs_dy; b.offset_a = offset_dx; b.offset_b = offset_dy;
+    } else {
+      b.abs_da = abs_dy; b.abs_db = abs_dx; b.offset_a = offset_dy; b.offset_b = offset_dx;
+    }
+    b.e0 = b.abs_da / 2;
+    const unsigned int end = b.abs_da < 5000u ? b.abs_da : 5000u;  // bresenham2D(..., max_length = 5000)
+    for (unsigned int i0 = 0; i0 < end; i0 += 64) {
+      const unsigned int i = i0 + lane;
+      const bool occ = i < end && P.logodds[line_cell(b, i)] > 0.0f;  // data[offset] == 100
+      const unsigned long long m = __ballot(occ);
+      if (m) {
+        const unsigned int ih = i0 + (unsigned int)__ffsll((long long)m) - 1u;
+        const unsigned int c = line_cell(b, ih);
+        const int ex = (int)(c % (unsigned int)P.sx), ey = (int)(c / (unsigned int)P.sx);
+        const float fx = (float)(x0 - ex), fy = (float)(y0 - ey);
+        dist = (float)(int)sqrtf(fx * fx + fy * fy);  // int distMap = (begin - end).cast<float>().norm()
+        if (lane == 0) P.out_hit[r] = make_float2(P.origin_x + ((float)ex * P.scale), P.origin_y + ((float)ey * P.scale));
+        break;
+      }
+    }
+  }
+  if (lane == 0) P.out_dist[r] = P.scale * dist;  // getC1Scale
+}
+
 // rosLaserScanToDataContainer (HectorMappingRos.cpp:483-507).  trig[i] = (cosf(angle_i), sinf(angle_i))
 // comes from the host (the running fp32 angle and the libm calls are the node's); this kernel applies
 // the range gate, the scale and the products, and compacts the survivors IN ORDER: one workgroup,

@@ -164,6 +164,14 @@ int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]);
  * Host pointers. */
 int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
                           float* out_lh);
+/* replaces: hectormaptools::DistanceMeasurementProvider::getDist (hector_map_tools/include/hector_map_tools/
+ * HectorMapTools.h:133-234, behind hector_map_server's services) for `n` rays on `level`, with the
+ * OccupancyGrid metadata the node publishes (origin = getWorldCoords(0,0) - cell/2, resolution = cell length,
+ * HectorMappingRos.cpp:546-553): out_dist[i] = resolution * (int) cell distance to the first occupied cell, or
+ * -resolution when there is none; out_hit_xy[2i..] = its world coordinates (left untouched without a hit).
+ * Host pointers; out_hit_xy may be NULL. */
+int hsm_ray_distances(hsm_ctx* h, int level, float origin_x, float origin_y, float resolution, int n,
+                      const float* begin_world_xy, const float* end_world_xy, float* out_dist, float* out_hit_xy);
 /* replaces: publishMap's cell loop (HectorMappingRos.cpp:449-468) with LogOddsCell::isFree/isOccupied
  * (GridMapLogOdds.h:76-84): -1 unknown, 0 free (logOdds < 0), 100 occupied (logOdds > 0).
  * out: host, sx*sy bytes, row major. */

@@ -652,6 +652,58 @@ void ho_likelihood_states(void* h, int level, int batch, const float* states, co
   }
 }
 
+
+// f4: DistanceMeasurementProvider::getDist / checkOccupancyBresenhami / bresenham2D
+// (hector_map_tools/include/hector_map_tools/HectorMapTools.h:133-234), CoordinateTransformer :58-98
+static int hmt_bresenham2d(const signed char* data, unsigned int abs_da, unsigned int abs_db, int error_b, int offset_a,
+                           int offset_b, unsigned int offset, unsigned int max_length) {
+  const unsigned int end = max_length < abs_da ? max_length : abs_da;
+  for (unsigned int i = 0; i < end; ++i) {
+    if (data[offset] == 100) return (int)offset;
+    offset += offset_a;
+    error_b += abs_db;
+    if ((unsigned int)error_b >= abs_da) {
+      offset += offset_b;
+      error_b -= abs_da;
+    }
+  }
+  return -1;
+}
+void ho_ray_distances(const signed char* grid, int sizeX, int sizeY, float origin_x, float origin_y, float resolution,
+                        int n, const float* bw, const float* ew, float* out_dist, float* out_hit) {
+  const float scale_ = resolution;
+  const float inv_scale_ = 1.0f / resolution;
+  for (int r = 0; r < n; ++r) {
+    // getC2Coords: ((worldCoords - origo_) * inv_scale_).cast<int>()
+    const int x0 = (int)((bw[2 * r] - origin_x) * inv_scale_), y0 = (int)((bw[2 * r + 1] - origin_y) * inv_scale_);
+    const int x1 = (int)((ew[2 * r] - origin_x) * inv_scale_), y1 = (int)((ew[2 * r + 1] - origin_y) * inv_scale_);
+    float dist = -1.0f;
+    int end_offset = -1;
+    if (!((x0 < 0) || (x0 >= sizeX) || (y0 < 0) || (y0 >= sizeY)) &&
+        !((x1 < 0) || (x1 >= sizeX) || (y1 < 0) || (y1 >= sizeY))) {
+      const int dx = x1 - x0, dy = y1 - y0;
+      const unsigned int abs_dx = abs(dx), abs_dy = abs(dy);
+      const int offset_dx = dx > 0 ? 1 : -1;
+      const int offset_dy = (dy > 0 ? 1 : -1) * sizeX;
+      const unsigned int startOffset = y0 * sizeX + x0;
+      if (abs_dx >= abs_dy) {
+        end_offset = hmt_bresenham2d(grid, abs_dx, abs_dy, abs_dx / 2, offset_dx, offset_dy, startOffset, 5000);
+      } else {
+        end_offset = hmt_bresenham2d(grid, abs_dy, abs_dx, abs_dy / 2, offset_dy, offset_dx, startOffset, 5000);
+      }
+      if (end_offset != -1) {
+        const int ex = end_offset % sizeX, ey = end_offset / sizeX;
+        const float fx = (float)(x0 - ex), fy = (float)(y0 - ey);
+        const int distMap = (int)sqrtf(fx * fx + fy * fy);  // int distMap = (...).cast<float>().norm()
+        dist = (float)distMap;
+        out_hit[2 * r] = origin_x + ((float)ex * scale_);  // getC1Coords
+        out_hit[2 * r + 1] = origin_y + ((float)ey * scale_);
+      }
+    }
+    out_dist[r] = scale_ * dist;  // getC1Scale
+  }
+}
+
 // f2: HectorMappingRos::publishMap cell loop (HM/src/HectorMappingRos.cpp:449-468) with
 // LogOddsCell::isFree / isOccupied (GridMapLogOdds.h:76-84)
 void ho_occupancy_grid(void* h, int level, signed char* out) {

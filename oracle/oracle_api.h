@@ -92,6 +92,13 @@ void ORF(occupancy_grid)(void* h, int level, signed char* out);
  * `batch` map-frame states against one level-scaled scan: out_lh[b] = 1 - residual/size */
 void ORF(likelihood_states)(void* h, int level, int batch, const float* states_map, const float* pts_level,
                             int n, float* out_lh);
+/* f4: hectormaptools::DistanceMeasurementProvider::getDist (hector_map_tools/include/hector_map_tools/
+ * HectorMapTools.h:133-234) on an int8 occupancy grid with OccupancyGrid metadata (origin, resolution):
+ * out_dist[i] = resolution * cells to the first occupied (== 100) cell on the Bresenham line, or
+ * resolution * -1 when none within min(5000, |major|) steps / an end point is outside; out_hit = world
+ * coordinates of the hit cell (written only when there is a hit). */
+void ORF(ray_distances)(const signed char* grid, int sx, int sy, float origin_x, float origin_y, float resolution,
+                        int n, const float* begin_world, const float* end_world, float* out_dist, float* out_hit);
 /* f1: rosLaserScanToDataContainer (:483-507): fp32 running angle, range gate (range_min, range_max - 0.1f),
  * float cos/sin; returns the number of endpoints written to out_pts (capacity n). */
 int ORF(laser_scan_to_container)(const float* ranges, int n, float angle_min, float angle_increment,

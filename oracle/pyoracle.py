@@ -66,6 +66,8 @@ def _load(kind: str):
         "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
         "proc_last_pose": (None, [vp, _f32p, _f32p]),
         "likelihood_states": (None, [vp, i, i, _f32p, _f32p, i, _f32p]),
+        "ray_distances": (None, [np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS"), i, i, f, f, f, i, _f32p, _f32p,
+                                 _f32p, _f32p]),
         "occupancy_grid": (None, [vp, i, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
         "laser_scan_to_container": (i, [_f32p, i, f, f, f, f, f, _f32p]),
         "normalize_angle": (f, [f]),
@@ -92,6 +94,20 @@ def _v(x, n) -> np.ndarray:
 
 
 _ZERO2 = np.zeros(2, np.float32)
+
+
+def ray_distances(kind, grid, origin_xy, resolution, begin_world, end_world):
+    """DistanceMeasurementProvider::getDist over a batch of rays -> (dist[n], hit[n,2] (NaN where no hit))"""
+    f = _load(kind)
+    g = np.ascontiguousarray(grid, np.int8)
+    b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 2)
+    e = np.ascontiguousarray(end_world, np.float32).reshape(-1, 2)
+    dist = np.empty(b.shape[0], np.float32)
+    hit = np.full((b.shape[0], 2), np.nan, np.float32)
+    f["ray_distances"](g, g.shape[1], g.shape[0], origin_xy[0], origin_xy[1], resolution, b.shape[0],
+                       b.reshape(-1) if b.size else np.zeros(2, np.float32), e.reshape(-1) if e.size else
+                       np.zeros(2, np.float32), dist, hit.reshape(-1) if b.size else np.zeros(2, np.float32))
+    return dist, hit
 
 
 class Oracle:

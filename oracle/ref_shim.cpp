@@ -210,6 +210,38 @@ void hr_likelihood_states(void* h, int level, int batch, const float* states, co
   hectorslam::DataContainer dc = make_container(pts, n, 0);
   for (int b = 0; b < batch; ++b) out[b] = r->level(level).gridMapUtil->getLikelihoodForState(v3(states + 3 * b), dc);
 }
+// f4 lives in hector_map_tools (needs nav_msgs); restatement only, same symbol set in both libraries
+void hr_ray_distances(const signed char* grid, int sx, int sy, float ox, float oy, float res, int n, const float* bw,
+                      const float* ew, float* out_dist, float* out_hit) {
+  const float inv = 1.0f / res;
+  for (int r = 0; r < n; ++r) {
+    const int x0 = (int)((bw[2 * r] - ox) * inv), y0 = (int)((bw[2 * r + 1] - oy) * inv);
+    const int x1 = (int)((ew[2 * r] - ox) * inv), y1 = (int)((ew[2 * r + 1] - oy) * inv);
+    float dist = -1.0f;
+    if (x0 >= 0 && x0 < sx && y0 >= 0 && y0 < sy && x1 >= 0 && x1 < sx && y1 >= 0 && y1 < sy) {
+      int dx = x1 - x0, dy = y1 - y0;
+      unsigned adx = abs(dx), ady = abs(dy);
+      int oa = dx > 0 ? 1 : -1, ob = (dy > 0 ? 1 : -1) * sx;
+      unsigned da = adx, db = ady;
+      if (adx < ady) { da = ady; db = adx; int t = oa; oa = ob; ob = t; }
+      unsigned off = y0 * sx + x0, end = da < 5000u ? da : 5000u;
+      int err = da / 2, hit = -1;
+      for (unsigned i = 0; i < end; ++i) {
+        if (grid[off] == 100) { hit = (int)off; break; }
+        off += oa; err += db;
+        if ((unsigned)err >= da) { off += ob; err -= da; }
+      }
+      if (hit != -1) {
+        Eigen::Vector2i b(x0, y0), e(hit % sx, hit / sx);
+        int distMap = ((b - e).cast<float>()).norm();
+        dist = distMap;
+        out_hit[2 * r] = ox + ((float)e[0] * res);
+        out_hit[2 * r + 1] = oy + ((float)e[1] * res);
+      }
+    }
+    out_dist[r] = res * dist;
+  }
+}
 // f2 through the reference's own GridMap::isFree / isOccupied (GridMapLogOdds.h:76-84)
 void hr_occupancy_grid(void* h, int level, signed char* out) {
   const RefGridMap& g = ((Ref*)h)->proc->getGridMap(level);

@@ -153,3 +153,39 @@ def test_likelihood_states_matches_reference(capi, oracle_mod, pyramid_scene):
                 assert np.abs(got - ref).max() <= 1e-5, (lvl, q, k, np.abs(got - ref).max())
             assert got[6] > got[:6].max() - 1e-3 and got[-1] == 0.0  # truth is (near) the best sigma point
     assert g.likelihood_states(0, np.zeros((0, 3), np.float32), sc.query_scans[0]).shape == (0,)
+
+
+@pytest.mark.gpu
+def test_ray_distances_bit_exact(capi, oracle_mod, pyramid_scene):
+    """f4: hector_map_tools' getDist on 20k random rays per level: distances and hit coordinates bit-exact
+    against the restatement run on the oracle's occupancy grid (integer Bresenham + one fp32 sqrt)"""
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    o = make_oracle(oracle_mod, "ho", sc)
+    rng = np.random.default_rng(12)
+    kinds = ["ho"] + (["hr"] if oracle_mod.available("hr") else [])
+    for lvl in range(sc.levels):
+        ox, oy, res = g.map_metadata(lvl)
+        grid = o.occupancy_grid(lvl)
+        n = 20000
+        begin = rng.uniform(-9, 9, (n, 2)).astype(np.float32)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        length = rng.uniform(0.0, 25.0, n)
+        end = (begin + np.stack([np.cos(ang), np.sin(ang)], 1) * length[:, None]).astype(np.float32)
+        end[:50] = begin[:50]                      # zero-length rays
+        begin[50:100] += 100.0                     # begin outside the map
+        end[100:150] += 100.0                      # end outside the map
+        end[150:200, 1] = begin[150:200, 1]        # axis-aligned
+        end[200:250, 0] = begin[200:250, 0]
+        dist, hit = g.ray_distances(lvl, begin, end)
+        for k in kinds:
+            rd, rh = oracle_mod.ray_distances(k, grid, (ox, oy), res, begin, end)
+            assert np.array_equal(bits(dist), bits(rd)), (lvl, k, (bits(dist) != bits(rd)).sum())
+            has = rd >= 0
+            assert np.array_equal(bits(hit[has]), bits(rh[has])) and np.isnan(hit[~has]).all()
+        assert 0.2 < (dist >= 0).mean() < 0.95 and (dist[:150] < 0).sum() >= 100
+    d0, h0 = g.ray_distances(0, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))
+    assert d0.shape == (0,)
