@@ -233,7 +233,10 @@ __device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
   if (LAYOUT == kLayoutQuad) {
     const unsigned index = oob ? (unsigned)L.zero_index : quad_index(ix, iy, L.tiles_x, L.sx);
     // 32-bit byte offset on a uniform base: one global_load_dwordx4 with an SGPR base address
-#if defined(HSM_EXP_NOLOAD)  // experiment: the beam body without any texel traffic
+#if defined(HSM_EXP_QUADCONTIG)  // experiment: the 4 lanes of a quad read 4 CONSECUTIVE texels (leader's cell + lane&3)
+    const unsigned lead = (unsigned)__builtin_amdgcn_update_dpp(0, (int)index, 0x00, 0xf, 0xf, true);  // quad_perm [0,0,0,0]
+    const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(((lead & ~3u) + (threadIdx.x & 3u)) << 4));
+#elif defined(HSM_EXP_NOLOAD)  // experiment: the beam body without any texel traffic
     const float4 q = make_float4(__uint_as_float(index | 0x3f000000u), 0.25f, 0.75f, __uint_as_float((index >> 3) | 0x3f000000u));
 #elif defined(HSM_EXP_SAMELINE)  // experiment: every lane reads the same texel
     const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)((index & 0u) + 4096u));
