@@ -50,6 +50,14 @@ struct Debug : public HectorDebugInfoInterface {
   virtual void addPoseLikelihood(float lh) { g_log.push_back(9); g_log.push_back(1); g_log.push_back(lh); }
 };
 
+// the processor keeps its map representation protected; the batch phase below needs it
+struct ProcAccess : public hectorslam::HectorSlamProcessor {
+  ProcAccess(float res, int sx, int sy, const Eigen::Vector2f& start, int levels, DrawInterface* d,
+             HectorDebugInfoInterface* dbg)
+      : hectorslam::HectorSlamProcessor(res, sx, sy, start, levels, d, dbg) {}
+  hectorslam::MapRepresentationInterface* rep() { return mapRep; }
+};
+
 template <typename T> T rd(FILE* f) {
   T v;
   if (fread(&v, sizeof v, 1, f) != 1) { fprintf(stderr, "slam_driver: short scenario file\n"); exit(2); }
@@ -72,8 +80,8 @@ int main(int argc, char** argv) {
   Draw draw;
   Debug debug;
   // HectorMappingRos.cpp:127-134
-  hectorslam::HectorSlamProcessor* slam = new hectorslam::HectorSlamProcessor(
-      res, size, size, Eigen::Vector2f(0.5f, 0.5f), levels, hooks ? &draw : 0, hooks ? &debug : 0);
+  ProcAccess* slam = new ProcAccess(res, size, size, Eigen::Vector2f(0.5f, 0.5f), levels, hooks ? &draw : 0,
+                                    hooks ? &debug : 0);
   slam->setUpdateFactorFree(ffree);
   slam->setUpdateFactorOccupied(focc);
   slam->setMapUpdateMinDistDiff(minDist);
@@ -82,6 +90,8 @@ int main(int argc, char** argv) {
   slam->addMapMutex(0, locker);
 
   hectorslam::DataContainer scan;
+  std::vector<hectorslam::DataContainer> kept;  // the last scans, for the batch phase
+  std::vector<Eigen::Vector3f> keptPose;
   for (int t = 0; t < steps; ++t) {
     float hint[3];
     for (int k = 0; k < 3; ++k) hint[k] = rd<float>(in);
@@ -102,6 +112,30 @@ int main(int argc, char** argv) {
     const Eigen::Matrix3f& c = slam->getLastScanMatchCovariance();
     for (int k = 0; k < 3; ++k) wr(out, p[k]);
     for (int k = 0; k < 9; ++k) wr(out, c(k % 3, k / 3));
+    if (t >= steps - 8) {
+      kept.push_back(scan);
+      keptPose.push_back(p);
+    }
+  }
+  // batch phase: the kept scans re-matched from slightly displaced starts.  Reference build: one
+  // matchData call per scan (the only form it has); MI355X build: ONE matchDataBatch launch.
+  {
+    const size_t logMark = g_log.size();  // the batch phase is not part of the hook-stream comparison
+    std::vector<Eigen::Vector3f> hints, poses(kept.size());
+    for (size_t k = 0; k < kept.size(); ++k)
+      hints.push_back(keptPose[k] + Eigen::Vector3f(0.03f, -0.02f, 0.01f));
+#ifdef HECTOR_MI355_CAPI_H
+    std::vector<const hectorslam::DataContainer*> ptrs;
+    for (size_t k = 0; k < kept.size(); ++k) ptrs.push_back(&kept[k]);
+    static_cast<hectorslam::MapRepMultiMap*>(slam->rep())->matchDataBatch(hints, ptrs, poses);
+#else
+    Eigen::Matrix3f cov;
+    for (size_t k = 0; k < kept.size(); ++k) poses[k] = slam->rep()->matchData(hints[k], kept[k], cov);
+#endif
+    g_log.resize(logMark);
+    wr(out, (int)poses.size());
+    for (size_t k = 0; k < poses.size(); ++k)
+      for (int j = 0; j < 3; ++j) wr(out, poses[k][j]);
   }
   wr(out, (int)g_log.size());
   if (!g_log.empty()) fwrite(&g_log[0], sizeof(float), g_log.size(), out);

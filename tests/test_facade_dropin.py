@@ -46,6 +46,10 @@ def read_output(path, steps):
     off = 0
     pc = np.frombuffer(buf, np.float32, steps * 12, off).reshape(steps, 12)
     off += steps * 48
+    (nb,) = struct.unpack_from("<i", buf, off)
+    off += 4
+    batch = np.frombuffer(buf, np.float32, nb * 3, off).reshape(nb, 3)
+    off += 12 * nb
     (nlog,) = struct.unpack_from("<i", buf, off)
     off += 4
     log = np.frombuffer(buf, np.float32, nlog, off)
@@ -62,7 +66,7 @@ def read_output(path, steps):
         off += 4 * sx * sy
         grids.append(dict(sx=sx, sy=sy, cell=cell, update_index=upd, occ=occ, val=val))
     assert off == len(buf)
-    return dict(pose=pc[:, :3], cov=pc[:, 3:], log=log, locks=locks, unlocks=unlocks, scale=scale, grids=grids)
+    return dict(pose=pc[:, :3], cov=pc[:, 3:], batch=batch, log=log, locks=locks, unlocks=unlocks, scale=scale, grids=grids)
 
 
 def parse_log(log):
@@ -144,6 +148,10 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
     dth = ang_diff(r["pose"][:, 2], g["pose"][:, 2]).max()
     assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
     assert np.abs(r["cov"] - g["cov"]).max() <= 1e-3 * np.abs(r["cov"]).max()
+    # the facade's batched extension (one launch) == the reference's per-scan matchData calls
+    assert g["batch"].shape == r["batch"].shape == (8, 3)
+    assert np.abs(r["batch"][:, :2].astype(np.float64) - g["batch"][:, :2]).max() <= 1e-4
+    assert ang_diff(r["batch"][:, 2], g["batch"][:, 2]).max() <= 1e-4
     assert (g["locks"], g["unlocks"]) == (r["locks"], r["unlocks"])
     assert g["scale"] == r["scale"] and len(g["grids"]) == len(r["grids"])
     for a, b in zip(r["grids"], g["grids"]):
