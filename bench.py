@@ -454,11 +454,12 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC profile of THIS workload (rocprofv3 cannot run
     # inside the timed process); null when the run is not the profiled configuration
-    traffic = None
+    traffic = floor_ms = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["gn_match_kernel"]
         if B == BATCH_PER_GPU and args.levels == 1:
             traffic = tj["hbm_bytes_per_launch"]
+            floor_ms = tj.get("valu_issue_floor_ms")
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -481,7 +482,11 @@ def main():
                                      "utilisation, the kernel is VALU-issue + texture-path bound (DESIGN.md 3.1)",
                      "kernel": "gn_match_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12},
+                     "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12,
+                     # the limit that actually binds: instruction issue of the bit-exact beam body (measured with
+                     # all lanes on one texel, profiles/r01); frac_of_valu_floor = that floor / this run's kernel time
+                     "valu_issue_floor_ms": floor_ms,
+                     "frac_of_valu_floor": (floor_ms / kern_ms) if floor_ms else None},
     }
     conv = np.abs(gpu_pose.astype(np.float64) - truth.astype(np.float64))
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
