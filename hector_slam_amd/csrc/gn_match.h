@@ -554,17 +554,22 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
 #else
         // chunks of kUnroll beams: issue all gathers of a chunk, then consume them in beam order
         // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
+        // Throughput launches (one wave per scan, 4 waves per SIMD): one beam at a time is fastest.
+        // Latency launches (WPS > 1 is only chosen when the batch cannot fill the chip, typically one wave
+        // per SIMD): nobody else hides the L2 latency, so up to 9 of the lane's gathers are issued back to
+        // back before the first is consumed (single 1081-beam scan: kernel 31.5 -> 25 us).
+        constexpr int kChunk = (WPS > 1) ? (NREG < 9 ? NREG : 9) : kUnroll;
 #pragma unroll
-        for (int k0 = 0; k0 < NREG; k0 += kUnroll) {
-          BeamSample smp[kUnroll];
-          BeamRot rot[kUnroll];
+        for (int k0 = 0; k0 < NREG; k0 += kChunk) {
+          BeamSample smp[kChunk];
+          BeamRot rot[kChunk];
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
+          for (int u = 0; u < kChunk; ++u) {
             if (k0 + u < NREG)
               smp[u] = beam_fetch<LAYOUT>(R, e2, cs, sc, pt[k0 + u], rot[u]);
           }
 #pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
+          for (int u = 0; u < kChunk; ++u) {
             if (k0 + u < NREG) beam_finish(smp[u], rot[u], acc);
           }
           // Pin the chunk: the accumulators must be final here ("+v") and no later gather may be
