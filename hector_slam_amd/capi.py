@@ -72,6 +72,7 @@ SIGNATURES = {
     "hsm_download_rows": (_i, [_vp, _i, _i, _i, _f32p]),
     "hsm_download_cells": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i]),
     "hsm_last_update_bbox": (_i, [_vp, _i, _i32p]),
+    "hsm_take_dirty_bbox": (_i, [_vp, _i, _i32p]),
     "hsm_download_prob": (_i, [_vp, _i, _f32p]),
     "hsm_hessian_derivs": (_i, [_vp, _i, _f32p, _vp, _i, _f32p, _f32p]),
     "hsm_eval_beams": (_i, [_vp, _i, _f32p, _vp, _i, _vp]),
@@ -219,6 +220,11 @@ class MapRepMultiMap:
     def last_update_bbox(self, level):
         bb = np.empty(4, np.int32)
         _check(self._lib.hsm_last_update_bbox(self._h, level, bb), "hsm_last_update_bbox")
+        return bb
+
+    def take_dirty_bbox(self, level):
+        bb = np.empty(4, np.int32)
+        _check(self._lib.hsm_take_dirty_bbox(self._h, level, bb), "hsm_take_dirty_bbox")
         return bb
 
     def download_prob(self, level):

@@ -556,9 +556,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
         // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
         // Throughput launches (one wave per scan, 4 waves per SIMD): one beam at a time is fastest.
         // Latency launches (WPS > 1 is only chosen when the batch cannot fill the chip, typically one wave
-        // per SIMD): nobody else hides the L2 latency, so up to 9 of the lane's gathers are issued back to
-        // back before the first is consumed (single 1081-beam scan: kernel 31.5 -> 25 us).
-        constexpr int kChunk = (WPS > 1) ? (NREG < 9 ? NREG : 9) : kUnroll;
+        // per SIMD): nobody else hides the L2 latency, so all (<= 9) of the lane's gathers are issued back to
+        // back before the first is consumed (single 1081-beam scan: kernel 31.5 -> 25 us; with 17 beams per
+        // lane -- a 16k-beam scan on 16 waves -- chunking loses again: 173 vs 155 us).
+        constexpr int kChunk = (WPS > 1 && NREG <= 9) ? NREG : kUnroll;
 #pragma unroll
         for (int k0 = 0; k0 < NREG; k0 += kChunk) {
           BeamSample smp[kChunk];

@@ -67,7 +67,8 @@ struct Level {
   // OccGridMapBase counters / GridMapBase::lastUpdateIndex
   int curr_update_index = 0, curr_mark_occ = -1, curr_mark_free = -1, last_update_index = -1;
   unsigned int serial = 0;  // key-plane generation (map_update.h)
-  int bbox[4] = {0, 0, -1, -1};
+  int bbox[4] = {0, 0, -1, -1};   // cell box touched by the last update
+  int dirty[4] = {0, 0, -1, -1};  // union of those boxes since hsm_take_dirty_bbox was last called
   size_t cells() const { return (size_t)sx * sy; }
   int tiles_x() const { return (sx + 3) / 4; }
   int quad_texels() const {
@@ -382,6 +383,14 @@ int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2*
       L.bbox[1] = P.y0 = y0 < byi ? y0 : byi;
       L.bbox[2] = P.x1 = x1 > bxi ? x1 : bxi;
       L.bbox[3] = P.y1 = y1 > byi ? y1 : byi;
+      if (L.dirty[2] < L.dirty[0]) {
+        for (int k = 0; k < 4; ++k) L.dirty[k] = L.bbox[k];
+      } else {
+        if (L.bbox[0] < L.dirty[0]) L.dirty[0] = L.bbox[0];
+        if (L.bbox[1] < L.dirty[1]) L.dirty[1] = L.bbox[1];
+        if (L.bbox[2] > L.dirty[2]) L.dirty[2] = L.bbox[2];
+        if (L.bbox[3] > L.dirty[3]) L.dirty[3] = L.bbox[3];
+      }
       const int grid = (n + 3) / 4;  // 4 beams (wavefronts) per 256-thread workgroup
       const size_t box = (size_t)(P.x1 - P.x0 + 2) * (size_t)(P.y1 - P.y0 + 2);
       hipLaunchKernelGGL(update_mark_occ_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, P);
@@ -533,8 +542,12 @@ int hsm_reset(hsm_ctx* h) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
-  for (Level& L : h->levels)
+  for (Level& L : h->levels) {
     if (int rc = fill_level(h, L)) return rc;
+    L.dirty[0] = L.dirty[1] = 0;  // every cell changed: the whole level is dirty for host mirrors
+    L.dirty[2] = L.sx - 1;
+    L.dirty[3] = L.sy - 1;
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }
@@ -1062,6 +1075,9 @@ int hsm_upload_level(hsm_ctx* h, int level, const float* logodds, const int* upd
   if (update_index)
     HIP_TRY(hipMemcpy(L.d_update_index, update_index, L.cells() * sizeof(int), hipMemcpyHostToDevice));
   if (int rc = rebuild_probability(h, L)) return rc;
+  L.dirty[0] = L.dirty[1] = 0;
+  L.dirty[2] = L.sx - 1;
+  L.dirty[3] = L.sy - 1;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }
@@ -1104,6 +1120,16 @@ int hsm_download_cells(hsm_ctx* h, int level, int x0, int y0, int x1, int y1, vo
 int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]) {
   if (int rc = valid_level(h, level)) return rc;
   for (int i = 0; i < 4; ++i) bbox[i] = h->levels[level].bbox[i];
+  return HSM_OK;
+}
+int hsm_take_dirty_bbox(hsm_ctx* h, int level, int bbox[4]) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!bbox) return fail(HSM_ERR_INVALID, "hsm_take_dirty_bbox: bbox is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  Level& L = h->levels[level];
+  for (int i = 0; i < 4; ++i) bbox[i] = L.dirty[i];
+  L.dirty[0] = L.dirty[1] = 0;
+  L.dirty[2] = L.dirty[3] = -1;
   return HSM_OK;
 }
 int hsm_download_prob(hsm_ctx* h, int level, float* prob) {

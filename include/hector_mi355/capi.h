@@ -144,6 +144,9 @@ int hsm_download_cells(hsm_ctx* h, int level, int x0, int y0, int x1, int y1, vo
 /* cell bounding box {x0, y0, x1, y1} (inclusive) touched by the last update of `level`;
  * x1 < x0 when nothing was touched */
 int hsm_last_update_bbox(const hsm_ctx* h, int level, int bbox[4]);
+/* union of the cell boxes touched on `level` since the previous call (reset/upload mark the whole level),
+ * then cleared: what a host mirror has to re-download.  x1 < x0 when nothing changed. */
+int hsm_take_dirty_bbox(hsm_ctx* h, int level, int bbox[4]);
 
 /* ---- the rows either side of the path; reference = the ROS node,
  *      hector_mapping/src/HectorMappingRos.cpp.  Optional: the facade does not need them. ---- */

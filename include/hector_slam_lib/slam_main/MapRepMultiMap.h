@@ -11,10 +11,10 @@
 // and the log-odds update are HIP kernels on the GPU.  What stays on the host:
 //   * one hectorslam::GridMap per level as a MIRROR, because getGridMap() must hand out a real
 //     `const GridMap&` that the map publisher reads cell by cell from another thread
-//     (HectorMappingRos.cpp:435-481).  The mirror is refreshed LAZILY: updateByScan() only grows a
-//     dirty cell box per level (under the level's MapLockerInterface, where the reference writes
-//     its grid, MapProcContainer.h:103-116); getGridMap() downloads that box when somebody actually
-//     asks for the grid -- the 0.5 Hz publisher, not the 40 Hz scan callback.
+//     (HectorMappingRos.cpp:435-481).  The mirror is refreshed LAZILY: the library accumulates the
+//     union of the touched cell boxes, and getGridMap() downloads that box when
+//     somebody actually asks for the grid -- the 0.5 Hz publisher, not the 40 Hz scan callback,
+//     whose updateByScan() therefore costs no device-to-host traffic at all.
 //   * the DrawInterface / HectorDebugInfoInterface hooks (ScanMatcher.h:56-66,100-115): when
 //     either is non-null the match records a per-step trace on the device and the hooks are
 //     replayed from it in the reference's order.
@@ -70,7 +70,7 @@ public:
                 << " res y: " << resolution.y() << " (MI355X resident)\n";
       mirrors.push_back(new GridMap(mapResolution, resolution, Eigen::Vector2f(mid_offset_x, mid_offset_y)));
       mutexes.push_back(0);
-      dirty.push_back(DirtyBox());
+      forceRefresh.push_back(false);
       resolution /= 2;
       mapResolution *= 2.0f;
     }
@@ -94,7 +94,7 @@ public:
     hsm_reset(ctx);
     for (size_t i = 0; i < mirrors.size(); ++i) {
       mirrors[i]->reset();
-      dirty[i] = DirtyBox();
+      forceRefresh[i] = true;  // hsm_reset marked the whole level dirty on the device
     }
   }
 
@@ -166,12 +166,11 @@ public:
     // guard the host mirrors, which is what the map publisher thread reads
     hsm_update_by_scan(ctx, pose, pts, n, origo);
 
+    // the lockers are honoured exactly where the reference takes them (MapProcContainer.h:103-116): readers
+    // of the host mirror see either the state before or after this update, never a refresh in between
     for (size_t i = 0; i < mirrors.size(); ++i) {
       if (mutexes[i]) {
         mutexes[i]->lockMap();
-      }
-      markDirty(static_cast<int>(i));
-      if (mutexes[i]) {
         mutexes[i]->unlockMap();
       }
     }
@@ -243,43 +242,33 @@ public:
   hsm_ctx* getDeviceContext() { return ctx; }
 
 protected:
-  struct DirtyBox {
-    int x0, y0, x1, y1;  // inclusive cell box changed on the device since the mirror was last refreshed
-    DirtyBox() : x0(0), y0(0), x1(-1), y1(-1) {}
-  };
-
-  // grow the level's dirty box by what the last update touched (device-side bounding box)
-  void markDirty(int level)
-  {
-    std::lock_guard<std::mutex> lk(mirrorMutex);
-    int bb[4];
-    if (hsm_last_update_bbox(ctx, level, bb) == HSM_OK && bb[2] >= bb[0] && bb[3] >= bb[1]) {
-      DirtyBox& d = dirty[level];
-      if (d.x1 < d.x0) {
-        d.x0 = bb[0]; d.y0 = bb[1]; d.x1 = bb[2]; d.y1 = bb[3];
-      } else {
-        if (bb[0] < d.x0) d.x0 = bb[0];
-        if (bb[1] < d.y0) d.y0 = bb[1];
-        if (bb[2] > d.x1) d.x1 = bb[2];
-        if (bb[3] > d.y1) d.y1 = bb[3];
-      }
-    }
-  }
-
-  // bring the host mirror of `level` up to date: download the dirty box as the reference's AoS cells and
-  // bump the update counter like OccGridMapBase::updateByScan does (OccGridMapBase.h:164 setUpdated())
+  // bring the host mirror of `level` up to date: fetch-and-clear the union of the cell boxes the updates
+  // touched since the last refresh, download it as the reference's AoS
+  // cells, and bump the update counter like OccGridMapBase::updateByScan does (OccGridMapBase.h:164)
   void refreshMirror(int level) const
   {
     std::lock_guard<std::mutex> lk(mirrorMutex);
     GridMap& m = *mirrors[level];
-    DirtyBox& d = dirty[level];
-    if (d.x1 >= d.x0 && d.y1 >= d.y0) {
-      LogOddsCell* first = &m.getCell(d.x0, d.y0);
-      hsm_download_cells(ctx, level, d.x0, d.y0, d.x1, d.y1, first, m.getSizeX());
-      d = DirtyBox();
+    if (m.getUpdateIndex() == hsm_update_index(ctx, level) && !forceRefresh[level]) {
+      return;  // nothing happened on the device since the last refresh
+    }
+    forceRefresh[level] = false;
+    // the mirror is written under the level's locker: a publisher thread reading cells under that lock
+    // (HectorMappingRos.cpp:453-476) never observes a refresh in progress.  getGridMap() itself is called
+    // before the publisher takes the lock (it is an argument of publishMap), so this cannot self-deadlock.
+    if (mutexes[level]) {
+      mutexes[level]->lockMap();
+    }
+    int bb[4];
+    if (hsm_take_dirty_bbox(ctx, level, bb) == HSM_OK && bb[2] >= bb[0] && bb[3] >= bb[1]) {
+      LogOddsCell* first = &m.getCell(bb[0], bb[1]);
+      hsm_download_cells(ctx, level, bb[0], bb[1], bb[2], bb[3], first, m.getSizeX());
     }
     while (m.getUpdateIndex() < hsm_update_index(ctx, level)) {
       m.setUpdated();
+    }
+    if (mutexes[level]) {
+      mutexes[level]->unlockMap();
     }
   }
 
@@ -352,7 +341,7 @@ protected:
   hsm_ctx* ctx;
   std::vector<GridMap*> mirrors;
   std::vector<MapLockerInterface*> mutexes;
-  mutable std::vector<DirtyBox> dirty;
+  mutable std::vector<bool> forceRefresh;
   mutable std::mutex mirrorMutex;
   std::vector<float> traceBuf;
   DrawInterface* drawInterface;
