@@ -556,10 +556,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
         // (the accumulation order stays k = 0, 1, 2 ... so the bits equal the memory loop's)
         // Throughput launches (one wave per scan, 4 waves per SIMD): one beam at a time is fastest.
         // Latency launches (WPS > 1 is only chosen when the batch cannot fill the chip, typically one wave
-        // per SIMD): nobody else hides the L2 latency, so all (<= 9) of the lane's gathers are issued back to
-        // back before the first is consumed (single 1081-beam scan: kernel 31.5 -> 25 us; with 17 beams per
-        // lane -- a 16k-beam scan on 16 waves -- chunking loses again: 173 vs 155 us).
-        constexpr int kChunk = (WPS > 1 && NREG <= 9) ? NREG : kUnroll;
+        // per SIMD): nobody else hides the L2 latency, so the lane's gathers are issued in chunks before the
+        // first is consumed -- all of them up to 5 beams per lane (single 1081-beam scan: kernel 31.5 -> 25 us),
+        // else 4 at a time (16k-beam scan on 16 waves: 170 / 155 / 173 us for chunks of 1 / 4 / 9).
+        constexpr int kChunk = WPS > 1 ? (NREG <= 5 ? NREG : 4) : kUnroll;
 #pragma unroll
         for (int k0 = 0; k0 < NREG; k0 += kChunk) {
           BeamSample smp[kChunk];

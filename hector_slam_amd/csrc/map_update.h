@@ -149,12 +149,28 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParam
   if (!b.valid) return;
   const unsigned int tag = P.serial << 16;
   const unsigned int key = tag | (0xFFFFu - (unsigned int)beam);
+  if ((unsigned int)lane >= b.abs_da) return;
+  // Lane k visits steps k, k+64, ...: instead of one integer division per step (line_cell), carry the
+  // quotient/remainder of (e0 + i*db) / da forward by the per-64-step increment -- two divisions per lane.
+  const unsigned int num0 = b.e0 + (unsigned int)lane * b.abs_db;
+  unsigned int q = num0 / b.abs_da, r = num0 - q * b.abs_da;
+  const unsigned int inc = 64u * b.abs_db;
+  const unsigned int q64 = inc / b.abs_da, r64 = inc - q64 * b.abs_da;
+  const unsigned int step_a = (unsigned int)(64 * b.offset_a);
+  unsigned int base = b.start + (unsigned int)(lane * b.offset_a);
   for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
-    const unsigned int c = line_cell(b, i);
+    const unsigned int c = base + (unsigned int)((int)q * b.offset_b);  // == line_cell(b, i)
     if ((P.lv.key_occ[c] >> 16) == P.serial) {
       atomicMax(&P.lv.key_free[c], key);
     } else {
       P.lv.key_free[c] = tag;
+    }
+    base += step_a;
+    q += q64;
+    r += r64;
+    if (r >= b.abs_da) {
+      r -= b.abs_da;
+      ++q;
     }
   }
 }
