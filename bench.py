@@ -127,6 +127,51 @@ def cpu_baseline(build_poses, build_scans, init, pts, offs, gpu_pose, levels: in
     }
 
 
+def cpu_baseline_all_cores(build_poses, build_scans, init, pts, offs, levels: int, budget_s: float = 4.0,
+                           max_threads: int = 64):
+    """The same reference matcher on T host threads, each with its OWN map + matcher state (the reference has no
+    threading of its own: one ROS callback, hector_mapping/src/main.cpp:40), scans split contiguously.  An
+    aggregate-throughput yardstick for the GPU/CPU ratio, reported next to the single-thread baseline."""
+    import threading
+    from oracle import pyoracle
+    kind = "hr" if pyoracle.available("hr") else "ho"
+    T = max(1, min(max_threads, (os.cpu_count() or 2) // 2))
+    B = init.shape[0]
+    its_per_match = 6 + 4 * (levels - 1)
+    bounds = [(B * t // T, B * (t + 1) // T) for t in range(T)]
+    oracles = [None] * T
+
+    def prepare(t):
+        o = pyoracle.Oracle(kind, RESOLUTION, MAP_SIZE, MAP_SIZE, levels)
+        o.set_update_factor_free(0.4)
+        o.set_update_factor_occupied(0.9)
+        o.build_map(build_poses, build_scans)
+        b, e = bounds[t]
+        o.match_many(init[b:e], pts, offs[b:e + 1])  # warm the probability cache
+        oracles[t] = o
+
+    th = [threading.Thread(target=prepare, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    done = [0] * T
+    stop = time.perf_counter() + budget_s
+
+    def work(t):
+        b, e = bounds[t]
+        while time.perf_counter() < stop:
+            oracles[t].match_many(init[b:e], pts, offs[b:e + 1])  # ctypes releases the GIL during the C loop
+            done[t] += e - b
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) * its_per_match / dt, "unit": "GN it/s", "cores": T,
+            "kind": "reference" if kind == "hr" else "port",
+            "sample": f"{sum(done)} matchData calls in {dt:.1f} s on {T} threads, one private map + matcher per thread"}
+
+
 def extra_workload(name: str, args, local_rank: int):
     """Single-GPU measurement of one of the non-headline BASELINE configs; prints one JSON line in the same
     schema (metric = GN iterations/s of that workload; roofline on its matcher launch; reference CPU leg)."""
@@ -508,6 +553,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(build_poses, build_scans, init if args.levels == 1 else init_pyr, pts,
                                            offs, gpu_pose, args.levels)
+        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(build_poses, build_scans,
+                                                               init if args.levels == 1 else init_pyr, pts, offs,
+                                                               args.levels)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
