@@ -62,6 +62,7 @@ struct Level {
   float4* d_quad = nullptr;
   unsigned int* d_key_free = nullptr;
   unsigned int* d_key_occ = nullptr;
+  unsigned int* d_occ_bits = nullptr;
   // GridMapLogOddsFunctions (GridMapLogOdds.h:200-203)
   float log_odds_free = 0.f, log_odds_occ = 0.f;
   // OccGridMapBase counters / GridMapBase::lastUpdateIndex
@@ -171,6 +172,7 @@ LevelRW level_rw(const Level& L) {
   v.quad = L.d_quad;
   v.key_free = L.d_key_free;
   v.key_occ = L.d_key_occ;
+  v.occ_bits = L.d_occ_bits;
   v.sx = L.sx;
   v.sy = L.sy;
   v.tiles_x = L.tiles_x();
@@ -223,6 +225,7 @@ void free_level(Level& L) {
   (void)hipFree(L.d_quad);
   (void)hipFree(L.d_key_free);
   (void)hipFree(L.d_key_occ);
+  (void)hipFree(L.d_occ_bits);
   L = Level();
 }
 
@@ -504,6 +507,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     CREATE_TRY(hipMalloc((void**)&L.d_key_occ, n * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, n * sizeof(unsigned int), h->stream));
     CREATE_TRY(hipMemsetAsync(L.d_key_occ, 0, n * sizeof(unsigned int), h->stream));
+    CREATE_TRY(hipMalloc((void**)&L.d_occ_bits, ((n + 31) / 32 + 1) * sizeof(unsigned int)));
+    CREATE_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((n + 31) / 32 + 1) * sizeof(unsigned int), h->stream));
     if (fill_level(h, L) != HSM_OK) {
       hsm_destroy(h);
       return HSM_ERR_HIP;

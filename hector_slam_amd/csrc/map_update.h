@@ -46,6 +46,7 @@ struct LevelRW {
   float4* quad;           // {P(x,y), P(x+1,y), P(x,y+1), P(x+1,y+1)}
   unsigned int* key_free; // first free-touching beam of the current scan
   unsigned int* key_occ;  // first end-cell beam of the current scan
+  unsigned int* occ_bits; // 1 bit per cell: "some beam of the current scan ends here" (set in pass 1a, cleared in pass 2)
   int sx, sy;
   int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
 };
@@ -130,7 +131,9 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateParams
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
   const unsigned int key = (P.serial << 16) | (0xFFFFu - (unsigned int)beam);
-  atomicMax(&P.lv.key_occ[(unsigned int)(b.y1 * P.lv.sx + b.x1)], key);
+  const unsigned int c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
+  atomicMax(&P.lv.key_occ[c], key);
+  atomicOr(&P.lv.occ_bits[c >> 5], 1u << (c & 31u));
 }
 
 // pass 1b: line cells (after 1a has completed).  WHICH beam crossed a cell first only matters
@@ -139,8 +142,8 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateParams
 // end cell gets a plain store of the bare serial tag (all writers store the same word: a benign
 // race, and stores do not serialise in L2 the way same-address atomics do next to the sensor),
 // and only end cells -- a few thousand per scan -- take the atomicMax that keeps the lowest beam
-// index.  A cell is classified by key_occ, which pass 1a finalised, so the two kinds of access
-// never mix on one word.
+// index.  A cell is classified by the end-cell bitmap, which pass 1a finalised, so the two kinds of
+// access never mix on one word.
 __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParams P) {
   const int lane = threadIdx.x & 63;
   const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParam
   unsigned int base = b.start + (unsigned int)(lane * b.offset_a);
   for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     const unsigned int c = base + (unsigned int)((int)q * b.offset_b);  // == line_cell(b, i)
-    if ((P.lv.key_occ[c] >> 16) == P.serial) {
+    if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {  // 32x denser than the key plane: stays in L2
       atomicMax(&P.lv.key_free[c], key);
     } else {
       P.lv.key_free[c] = tag;
@@ -182,6 +185,9 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateParams P)
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
     const int x = P.x0 + (int)(t % (size_t)w), y = P.y0 + (int)(t / (size_t)w);
     const size_t c = (size_t)y * P.lv.sx + x;
+    // clear the end-cell bitmap for the next scan: every set bit lies inside the box, so zeroing each word
+    // that overlaps the box (first thread of the word in this row) is exact
+    if ((c & 31u) == 0 || x == P.x0) P.lv.occ_bits[c >> 5] = 0u;
     const unsigned int kf = P.lv.key_free[c];
     const unsigned int ko = P.lv.key_occ[c];
     const bool fre = (kf >> 16) == P.serial;
