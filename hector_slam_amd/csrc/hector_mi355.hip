@@ -316,7 +316,9 @@ int valid_level(const hsm_ctx* h, int level) {
 // OccGridMapBase::updateByScan on one level (OccGridMapBase.h:121-168).  pts are LEVEL-0
 // endpoints on the device; pt_scale/origo bring them to this level.  h_pts (host copy of
 // the same points) is only used for the touched bounding box.
-int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2* d_pts,
+// Fills batch.lv[batch.nlev] (and bumps nlev) when the level has work; the launches happen once for all
+// levels in launch_update_batch().
+int update_level(hsm_ctx* h, UpdateBatch& batch, int level, const float pose_world[3], const float2* d_pts,
                  const float* h_pts, int n, float pt_scale, const float origo_level[2]) {
   Level& L = h->levels[level];
   L.curr_mark_free = L.curr_update_index + 1;
@@ -394,17 +396,31 @@ int update_level(hsm_ctx* h, int level, const float pose_world[3], const float2*
         if (L.bbox[2] > L.dirty[2]) L.dirty[2] = L.bbox[2];
         if (L.bbox[3] > L.dirty[3]) L.dirty[3] = L.bbox[3];
       }
-      const int grid = (n + 3) / 4;  // 4 beams (wavefronts) per 256-thread workgroup
-      const size_t box = (size_t)(P.x1 - P.x0 + 2) * (size_t)(P.y1 - P.y0 + 2);
-      hipLaunchKernelGGL(update_mark_occ_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, P);
-      hipLaunchKernelGGL(update_mark_free_kernel, dim3(grid), dim3(256), 0, h->stream, P);
-      hipLaunchKernelGGL(update_apply_kernel, dim3(grid_for(box)), dim3(256), 0, h->stream, P);
-      hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(box)), dim3(256), 0, h->stream, P);
-      HIP_TRY(hipGetLastError());
+      batch.lv[batch.nlev++] = P;
     }
   }
   L.last_update_index++;     // setUpdated(), GridMapBase.h:343
   L.curr_update_index += 3;  // OccGridMapBase.h:167
+  return HSM_OK;
+}
+
+// the four passes of map_update.h, each ONE launch over all levels of the batch (grid.y = level)
+int launch_update_batch(hsm_ctx* h, const UpdateBatch& batch) {
+  if (batch.nlev == 0) return HSM_OK;
+  int max_n = 0;
+  size_t max_box = 0;
+  for (int i = 0; i < batch.nlev; ++i) {
+    const UpdateParams& P = batch.lv[i];
+    if (P.n > max_n) max_n = P.n;
+    const size_t box = (size_t)(P.x1 - P.x0 + 2) * (size_t)(P.y1 - P.y0 + 2);
+    if (box > max_box) max_box = box;
+  }
+  const unsigned ny = (unsigned)batch.nlev;
+  hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
+  hipLaunchKernelGGL(update_mark_free_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);  // 4 beams (waves) per block
+  hipLaunchKernelGGL(update_apply_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
+  hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
+  HIP_TRY(hipGetLastError());
   return HSM_OK;
 }
 
@@ -813,7 +829,9 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
       HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     d_level0 = h->d_scan;
   }
-  if (int rc = update_level(h, 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
+  UpdateBatch batch;
+  batch.nlev = 0;
+  if (int rc = update_level(h, batch, 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
   // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
   const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
   if (h->levels.size() > 1) {
@@ -833,10 +851,11 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
     for (size_t l = 1; l < h->levels.size(); ++l) {
       const float factor = (float)(1.0 / pow(2.0, (double)l));
       const float ol[2] = {h->retained_origo[0] * factor, h->retained_origo[1] * factor};  // setFrom :48
-      if (int rc = update_level(h, (int)l, pose_world, d_coarse, h->retained_pts.data(), rn, factor, ol))
+      if (int rc = update_level(h, batch, (int)l, pose_world, d_coarse, h->retained_pts.data(), rn, factor, ol))
         return rc;
     }
   }
+  if (int rc = launch_update_batch(h, batch)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }
@@ -852,9 +871,12 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
   if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
   if (n > 0)
     HIP_TRY(hipMemcpyAsync(h->d_scan, pts_level_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  if (int rc = update_level(h, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
+  UpdateBatch batch;
+  batch.nlev = 0;
+  if (int rc = update_level(h, batch, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
                             origo_level ? origo_level : zero))
     return rc;
+  if (int rc = launch_update_batch(h, batch)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }

@@ -71,6 +71,13 @@ __device__ __forceinline__ float grid_probability(float log_odds) {
   return odds / (odds + 1.0f);
 }
 
+// All levels of one updateByScan in ONE launch per pass: blockIdx.y selects the level (the levels are
+// independent maps, so they run concurrently and the small coarse levels hide behind level 0).
+struct UpdateBatch {
+  UpdateParams lv[kMaxLevels];
+  int nlev;
+};
+
 struct BeamLine {
   bool valid;
   int x1, y1;
@@ -125,7 +132,8 @@ __device__ __forceinline__ unsigned int line_cell(const BeamLine& b, unsigned in
 }
 
 // pass 1a: end cells.  One thread per beam: atomicMax leaves the FIRST beam that ends in a cell.
-__global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateParams P) {
+__global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
   const int beam = blockIdx.x * blockDim.x + threadIdx.x;
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
@@ -144,7 +152,8 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateParams
 // and only end cells -- a few thousand per scan -- take the atomicMax that keeps the lowest beam
 // index.  A cell is classified by the end-cell bitmap, which pass 1a finalised, so the two kinds of
 // access never mix on one word.
-__global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParams P) {
+__global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (beam >= P.n) return;
@@ -179,7 +188,9 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateParam
 }
 
 // dense over the box [x0..x1] x [y0..y1]: bresenhamCellFree / bresenhamCellOcc (OccGridMapBase.h:216-241)
-__global__ void __launch_bounds__(256) update_apply_kernel(const UpdateParams P) {
+__global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  if (P.x1 < P.x0) return;  // this level has nothing to apply
   const int w = P.x1 - P.x0 + 1, h = P.y1 - P.y0 + 1;
   const size_t n = (size_t)w * h;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
@@ -214,7 +225,9 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateParams P)
 }
 
 // dense over the box grown by one cell towards -x/-y: texel (x,y) holds P of (x..x+1, y..y+1)
-__global__ void __launch_bounds__(256) update_texels_kernel(const UpdateParams P) {
+__global__ void __launch_bounds__(256) update_texels_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  if (P.x1 < P.x0) return;
   const int tx0 = P.x0 > 0 ? P.x0 - 1 : 0, ty0 = P.y0 > 0 ? P.y0 - 1 : 0;
   const int w = P.x1 - tx0 + 1, h = P.y1 - ty0 + 1;
   const size_t n = (size_t)w * h;
