@@ -436,3 +436,67 @@ def test_golden_pyramid(capi):
         pose, cov = g.matchData(g2["init"][q], g2[f"q{q}_pts"])
         assert_pose_close(pose, g2["pose"][q], f"golden pyramid q{q}")
         assert np.abs(cov - g2["cov"][q]).max() <= 1e-4 * np.abs(g2["cov"][q]).max()
+
+
+# ---------------------------------------------------------------- ABI robustness
+def test_capi_error_paths_fail_loudly(capi, small_scene):
+    """bad arguments come back as negative status codes with a message, never a crash or a silent no-op"""
+    import ctypes as C
+    lib = capi.load_library()
+    sc = small_scene
+    g = make_gpu(capi, sc, build=False)
+    f3 = np.zeros(3, np.float32)
+    f9 = np.zeros(9, np.float32)
+    pts = np.zeros((4, 2), np.float32)
+    assert lib.hsm_match(g._h, f3, pts.ctypes.data, -1, np.zeros(2, np.float32), f3, f9) == -1
+    assert lib.hsm_match(g._h, f3, None, 4, np.zeros(2, np.float32), f3, f9) == -1
+    assert b"bad argument" in lib.hsm_last_error()
+    assert lib.hsm_level_info(g._h, 7, None, None, None, None) == -1 and b"level" in lib.hsm_last_error()
+    assert lib.hsm_update_by_scan_level(g._h, -1, f3, pts.ctypes.data, 4, np.zeros(2, np.float32)) == -1
+    big = np.zeros((70000, 2), np.float32)
+    assert lib.hsm_update_by_scan(g._h, f3, big.ctypes.data, 70000, np.zeros(2, np.float32)) == -4  # HSM_ERR_TOO_LARGE
+    h = C.c_void_p()
+    opts = capi.HsmOpts(-1, 0, 0)
+    assert lib.hsm_create(0.05, 64, 64, 9, 0.5, 0.5, C.byref(opts), C.byref(h)) == -1      # > HSM_MAX_LEVELS
+    assert lib.hsm_create(0.05, 64, 64, 7, 0.5, 0.5, C.byref(opts), C.byref(h)) == -1      # coarsest level would be 1x1
+    assert lib.hsm_create(-1.0, 64, 64, 1, 0.5, 0.5, C.byref(opts), C.byref(h)) == -1
+    assert lib.hsm_create(0.05, 20000, 20000, 1, 0.5, 0.5, C.byref(opts), C.byref(h)) == -4  # > 2^28 cells
+    assert lib.hsm_create(0.05, 64, 64, 1, 0.5, 0.5, C.byref(capi.HsmOpts(99, 0, 0)), C.byref(h)) == -1  # no such device
+    assert lib.hsm_create(0.05, 64, 64, 1, 0.5, 0.5, C.byref(capi.HsmOpts(-1, 0, 3)), C.byref(h)) == -1  # waves_per_scan
+    with pytest.raises(capi.HsmError):
+        g.match_ingested(f3)  # nothing ingested yet
+    # after all that the context still works
+    p, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
+    assert np.isfinite(p).all()
+
+
+def test_concurrent_callers_are_serialised(capi, oracle_mod, pyramid_scene):
+    """the reference contract is one writer + one reader thread; the context's mutex must keep concurrent
+    matchData / occupancy reads on ONE context, and independent contexts in parallel, all correct"""
+    import threading
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    g = make_gpu(capi, sc)
+    g2 = make_gpu(capi, sc)
+    expect = [o.match(sc.query_init[q], sc.query_scans[q])[0] for q in range(8)]
+    errs = []
+
+    def matcher(ctx, reps):
+        for _ in range(reps):
+            for q in range(8):
+                p, _ = ctx.matchData(sc.query_init[q], sc.query_scans[q])
+                d = np.abs(p.astype(np.float64) - expect[q])
+                if d[0] > POSE_TOL_M or d[1] > POSE_TOL_M or d[2] > POSE_TOL_RAD:
+                    errs.append((q, p))
+
+    def reader(ctx, reps):
+        ref = o.occupancy_grid(0)
+        for _ in range(reps):
+            if not np.array_equal(ctx.occupancy_grid(0), ref):
+                errs.append("grid")
+
+    ts = [threading.Thread(target=matcher, args=(g, 6)), threading.Thread(target=matcher, args=(g, 6)),
+          threading.Thread(target=reader, args=(g, 20)), threading.Thread(target=matcher, args=(g2, 6))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:3]
