@@ -147,3 +147,55 @@ def test_util_helpers(oracle_mod):
         assert f_o["pose_difference_larger_than"](p1, p2, 0.4, 0.13) == f_r["pose_difference_larger_than"](p1, p2, 0.4, 0.13)
     fmax = np.full(3, np.finfo(np.float32).max, np.float32)
     assert f_o["pose_difference_larger_than"](np.zeros(3, np.float32), fmax, 0.4, 0.13) == 1
+
+
+def test_randomised_geometries_restatement_equals_reference(oracle_mod):
+    """odd map sizes, non-square maps are not supported by the constructor (sizeX, sizeY passed separately but the
+    reference squares nothing) -- so: odd sizes, 1..4 levels, off-centre start coordinates, random update factors,
+    rooms larger than the map (beams ending outside): restatement == reference, bit for bit.  (Poses that make H
+    singular are avoided on purpose: the reference then casts a NaN coordinate to an index and segfaults.)"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref not built")
+    from hector_slam_amd import synth
+    rng = np.random.default_rng(20240924)
+    for trial in range(6):
+        size = int(rng.choice([96, 125, 250, 333, 512]))
+        levels = int(rng.integers(1, 5))
+        while (size >> (levels - 1)) < 8:
+            levels -= 1
+        res = float(rng.choice([0.05, 0.1, 0.2]))
+        start = (float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.3, 0.7)))
+        free, occ = float(rng.uniform(0.3, 0.49)), float(rng.uniform(0.55, 0.95))
+        ext = size * res
+        # every other trial: a room LARGER than the map, so many beams end outside it (skipped by the update,
+        # exact zeros in the matcher)
+        grow = 1.15 if trial % 2 else 0.6
+        world = synth.World.make(ext * grow, ext * grow * 0.75, n_boxes=4, seed=int(rng.integers(1 << 30)),
+                                 keep_clear=0.5)
+        s = float(np.float32(1.0) / np.float32(res))
+        o = {k: oracle_mod.Oracle(k, res, size, size, levels, start) for k in ("ho", "hr")}
+        for k in o:
+            o[k].set_update_factor_free(free)
+            o[k].set_update_factor_occupied(occ)
+            o[k].proc_set_thresholds(0.02, 0.02)
+        n_beams = int(rng.choice([181, 400, 1081]))
+        poses = synth.loop_trajectory(world, 14, frac=0.25).astype(np.float32)
+        poses[:, 0] += (0.5 - start[0]) * ext * 0.3  # so that the map origin offset (start coords) matters
+        noise = np.random.default_rng(trial)
+        hint = {k: poses[0].copy() for k in o}
+        for t in range(14):
+            pts = synth.make_scan(world, poses[t], n_beams, s, noise, range_max=min(30.0, ext))
+            origo = rng.uniform(-2, 2, 2).astype(np.float32)
+            last = {}
+            for k in o:
+                o[k].proc_update(pts, hint[k], origo=origo, map_without_matching=(t == 5))
+                last[k] = o[k].proc_last_pose()
+            assert np.array_equal(last["ho"][0].view(np.uint32), last["hr"][0].view(np.uint32)), (trial, t)
+            assert np.array_equal(last["ho"][1].view(np.uint32), last["hr"][1].view(np.uint32)), (trial, t)
+            step = poses[min(t + 1, 13)] - poses[t]
+            for k in o:
+                hint[k] = last[k][0] + step
+        for lvl in range(levels):
+            a, b = o["ho"].download_level(lvl), o["hr"].download_level(lvl)
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), (trial, lvl)
+            assert np.array_equal(o["ho"].occupancy_grid(lvl), o["hr"].occupancy_grid(lvl))
