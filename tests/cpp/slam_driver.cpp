@@ -7,21 +7,27 @@
 // and tests/test_facade_dropin.py compares what the two print.  Nothing here knows which one it is.
 //
 // scenario file (little endian): float res; int size, levels; float free, occ, minDist, minAng;
-//   int hooks, n_steps; then per step: float hint[3]; int use_last_pose, map_without_matching;
+//   int hooks (bit 0: draw/debug hooks, bit 1: concurrent publisher thread), n_steps; then per step: float hint[3]; int use_last_pose, map_without_matching;
 //   float origo[2]; int n; float pts[2n]
 // output file: per step float pose[3], cov[9]; then hook log; then per level the mirror grid.
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "slam_main/HectorSlamProcessor.h"
 
 namespace {
 
+// like hector_mapping/src/HectorMapMutex.h (a boost::mutex there): a real lock, plus call counters
 struct Locker : public MapLockerInterface {
-  int locks = 0, unlocks = 0;
-  virtual void lockMap() { ++locks; }
-  virtual void unlockMap() { ++unlocks; }
+  std::mutex m;
+  std::atomic<int> locks{0}, unlocks{0};
+  virtual void lockMap() { m.lock(); ++locks; }
+  virtual void unlockMap() { ++unlocks; m.unlock(); }
 };
 
 std::vector<float> g_log;  // flat record of every hook call: tag, argc, args...
@@ -80,14 +86,36 @@ int main(int argc, char** argv) {
   Draw draw;
   Debug debug;
   // HectorMappingRos.cpp:127-134
-  ProcAccess* slam = new ProcAccess(res, size, size, Eigen::Vector2f(0.5f, 0.5f), levels, hooks ? &draw : 0,
-                                    hooks ? &debug : 0);
+  ProcAccess* slam = new ProcAccess(res, size, size, Eigen::Vector2f(0.5f, 0.5f), levels, (hooks & 1) ? &draw : 0,
+                                    (hooks & 1) ? &debug : 0);
   slam->setUpdateFactorFree(ffree);
   slam->setUpdateFactorOccupied(focc);
   slam->setMapUpdateMinDistDiff(minDist);
   slam->setMapUpdateMinAngleDiff(minAng);
   Locker* locker = new Locker();  // owned by the map representation from here on
   slam->addMapMutex(0, locker);
+
+  // optional map-publisher thread like HectorMappingRos::publishMapLoop (:577-595): fetch the grid, then read
+  // every cell under the map mutex, while the main thread keeps matching and updating
+  std::atomic<bool> stop(false);
+  std::atomic<long> published(0), occupiedSeen(0);
+  std::thread publisher;
+  if (hooks & 2) {
+    publisher = std::thread([&]() {
+      while (!stop.load()) {
+        const hectorslam::GridMap& g = slam->getGridMap(0);
+        MapLockerInterface* mtx = slam->getMapMutex(0);
+        mtx->lockMap();
+        long occ = 0;
+        const int cells = g.getSizeX() * g.getSizeY();
+        for (int i = 0; i < cells; ++i) occ += g.isOccupied(i) ? 1 : 0;
+        mtx->unlockMap();
+        occupiedSeen = occ;
+        ++published;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+    });
+  }
 
   hectorslam::DataContainer scan;
   std::vector<hectorslam::DataContainer> kept;  // the last scans, for the batch phase
@@ -117,6 +145,11 @@ int main(int argc, char** argv) {
       keptPose.push_back(p);
     }
   }
+  if (publisher.joinable()) {
+    while (published.load() < 3) std::this_thread::sleep_for(std::chrono::milliseconds(1));  // at least 3 full reads
+    stop = true;
+    publisher.join();
+  }
   // batch phase: the kept scans re-matched from slightly displaced starts.  Reference build: one
   // matchData call per scan (the only form it has); MI355X build: ONE matchDataBatch launch.
   {
@@ -139,8 +172,8 @@ int main(int argc, char** argv) {
   }
   wr(out, (int)g_log.size());
   if (!g_log.empty()) fwrite(&g_log[0], sizeof(float), g_log.size(), out);
-  wr(out, locker->locks);
-  wr(out, locker->unlocks);
+  wr(out, (int)locker->locks.load());
+  wr(out, (int)locker->unlocks.load());
   wr(out, slam->getScaleToMap());
   wr(out, slam->getMapLevels());
   // publishMap (HectorMappingRos.cpp:435-481): read every cell of every level through getGridMap()
