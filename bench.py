@@ -530,6 +530,7 @@ def main():
                      "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12,
                      # the limit that actually binds: instruction issue of the bit-exact beam body (measured with
                      # all lanes on one texel, profiles/r01); frac_of_valu_floor = that floor / this run's kernel time
+                     "hbm_gbps_from_pmc_traffic": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
                      "valu_issue_floor_ms": floor_ms,
                      "frac_of_valu_floor": (floor_ms / kern_ms) if floor_ms else None},
     }
