@@ -112,7 +112,9 @@ def cpu_baseline(build_poses, build_scans, init, pts, offs, gpu_pose, levels: in
                 break
     except OSError:
         pass
-    par = {"parity_sample": n_par, "max_abs_dxy_m": float(d[:, :2].max()), "max_abs_dtheta_rad": float(dth.max()),
+    same = (cpu_pose.view(np.uint32) == np.ascontiguousarray(gpu_pose[:n_par], np.float32).view(np.uint32)).all(1)
+    par = {"parity_sample": n_par, "bit_identical_pose_fraction": float(same.mean()),
+           "max_abs_dxy_m": float(d[:, :2].max()), "max_abs_dtheta_rad": float(dth.max()),
            "median_abs_dxy_m": float(np.median(d[:, :2])), "tolerance": "1e-4 m / 1e-4 rad"}
     if budget_s <= 0:
         return par
