@@ -170,12 +170,25 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
   const unsigned int q64 = inc / b.abs_da, r64 = inc - q64 * b.abs_da;
   const unsigned int step_a = (unsigned int)(64 * b.offset_a);
   unsigned int base = b.start + (unsigned int)(lane * b.offset_a);
+  // Duplicate suppression.  Neighbouring beams of a dense scan run through the SAME cells for their first
+  // hundreds of steps (all lines start in the same cell and separate by less than a cell until 1/dtheta
+  // cells out).  If beam-1 is valid, lies in the same octant and visits the same cell at step i, it writes
+  // the same tag there -- or, on an end cell, a LARGER key (lower beam index) -- so this beam's access is
+  // redundant and is skipped; by induction the lowest-indexed beam of each run does the write.
+  const BeamLine pb = beam > 0 ? beam_line(P, beam - 1) : b;
+  const bool dedup = beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
+  const unsigned int pnum0 = pb.e0 + (unsigned int)lane * pb.abs_db;
+  unsigned int pq = dedup ? pnum0 / pb.abs_da : 0u, pr = dedup ? pnum0 - pq * pb.abs_da : 0u;
+  const unsigned int pinc = 64u * pb.abs_db;
+  const unsigned int pq64 = dedup ? pinc / pb.abs_da : 0u, pr64 = dedup ? pinc - pq64 * pb.abs_da : 0u;
   for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
-    const unsigned int c = base + (unsigned int)((int)q * b.offset_b);  // == line_cell(b, i)
-    if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {  // 32x denser than the key plane: stays in L2
-      atomicMax(&P.lv.key_free[c], key);
-    } else {
-      P.lv.key_free[c] = tag;
+    if (!(dedup && i < pb.abs_da && pq == q)) {
+      const unsigned int c = base + (unsigned int)((int)q * b.offset_b);  // == line_cell(b, i)
+      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {  // 32x denser than the key plane: stays in L2
+        atomicMax(&P.lv.key_free[c], key);
+      } else {
+        P.lv.key_free[c] = tag;
+      }
     }
     base += step_a;
     q += q64;
@@ -183,6 +196,12 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
     if (r >= b.abs_da) {
       r -= b.abs_da;
       ++q;
+    }
+    pq += pq64;
+    pr += pr64;
+    if (dedup && pr >= pb.abs_da) {
+      pr -= pb.abs_da;
+      ++pq;
     }
   }
 }
