@@ -208,7 +208,9 @@ def extra_workload(name: str, args, local_rank: int):
         allp = synth.loop_trajectory(world, 40 * (T + n_init))[: T + n_init + 1].astype(np.float32)  # ~0.4 m apart
         alls = [synth.make_scan(world, p, beams, sfac, rng_noise, range_max=rmax) for p in allp]
         poses, scans = allp[n_init:], alls[n_init:]
-        m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
+        # update-heavy single-scan use: the plane layout (4 gathers per beam, no texel plane to maintain)
+        lay = capi.LAYOUT_QUAD if os.environ.get("HSM_LAYOUT") == "quad" else capi.LAYOUT_PLANE
+        m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank, layout=lay)
         m.setUpdateFactorFree(0.4)
         m.setUpdateFactorOccupied(0.9)
         for k in range(n_init + 1):

@@ -213,7 +213,8 @@ int fill_level(hsm_ctx* h, Level& L) {  // GridMapBase::clear + LogOddsCell::res
 
 int rebuild_probability(hsm_ctx* h, Level& L) {
   hipLaunchKernelGGL(rebuild_prob_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L));
-  hipLaunchKernelGGL(rebuild_quad_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L));
+  if (L.d_quad)
+    hipLaunchKernelGGL(rebuild_quad_kernel, dim3(grid_for(L.cells())), dim3(256), 0, h->stream, level_rw(L));
   HIP_TRY(hipGetLastError());
   return HSM_OK;
 }
@@ -419,7 +420,8 @@ int launch_update_batch(hsm_ctx* h, const UpdateBatch& batch) {
   hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
   hipLaunchKernelGGL(update_mark_free_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);  // 4 beams (waves) per block
   hipLaunchKernelGGL(update_apply_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
-  hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
+  if (h->layout == kLayoutQuad)
+    hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
   HIP_TRY(hipGetLastError());
   return HSM_OK;
 }
@@ -516,9 +518,14 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     // the samplers point out-of-map beams at an all-zero footprint stored BEHIND the planes
     // (gn_match.h sample_fetch): one extra texel, resp. sizeX + 2 extra cells, zeroed once here
     CREATE_TRY(hipMalloc((void**)&L.d_prob, (n + (size_t)rx + 2) * sizeof(float)));
-    CREATE_TRY(hipMalloc((void**)&L.d_quad, ((size_t)L.quad_texels() + 1) * sizeof(float4)));
     CREATE_TRY(hipMemsetAsync(L.d_prob + n, 0, ((size_t)rx + 2) * sizeof(float), h->stream));
-    CREATE_TRY(hipMemsetAsync(L.d_quad + L.quad_texels(), 0, sizeof(float4), h->stream));
+    if (h->layout == kLayoutQuad) {
+      // HSM_LAYOUT_PLANE samples the probability plane directly (4 gathers per beam) and keeps NO texel plane:
+      // 16 B/cell less memory and one dense pass less per update -- the better trade for update-heavy use
+      // (single dense scans); the quad layout is the better one for batched matching
+      CREATE_TRY(hipMalloc((void**)&L.d_quad, ((size_t)L.quad_texels() + 1) * sizeof(float4)));
+      CREATE_TRY(hipMemsetAsync(L.d_quad + L.quad_texels(), 0, sizeof(float4), h->stream));
+    }
     CREATE_TRY(hipMalloc((void**)&L.d_key_free, n * sizeof(unsigned int)));
     CREATE_TRY(hipMalloc((void**)&L.d_key_occ, n * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, n * sizeof(unsigned int), h->stream));

@@ -271,9 +271,11 @@ __global__ void fill_level_kernel(LevelRW L, float logodds, int update_index) {
     L.prob[i] = p;
   }
   // every texel of the tiled plane, including the padding of partial edge tiles
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)L.quad_texels;
-       i += (size_t)gridDim.x * blockDim.x) {
-    L.quad[i] = make_float4(p, p, p, p);
+  if (L.quad) {  // the plane layout keeps no texel plane
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)L.quad_texels;
+         i += (size_t)gridDim.x * blockDim.x) {
+      L.quad[i] = make_float4(p, p, p, p);
+    }
   }
 }
 

@@ -43,7 +43,10 @@ enum {
 #define HSM_MAX_LEVELS 8
 #define HSM_MAX_UPDATE_BEAMS 65535
 
-/* probability sampling layout used by the GN kernel (DESIGN.md "data layout") */
+/* probability sampling layout used by the GN kernel (DESIGN.md "data layout"):
+ *   QUAD  float4 texel plane {P(x,y),P(x+1,y),P(x,y+1),P(x+1,y+1)}: one 16-byte gather per beam; best for batched matching
+ *   PLANE the fp32 probability plane itself, four 4-byte gathers per beam; no texel plane is kept (16 B/cell less
+ *         memory, one dense pass less per update): best for update-heavy single dense scans */
 enum { HSM_LAYOUT_AUTO = 0, HSM_LAYOUT_QUAD = 1, HSM_LAYOUT_PLANE = 2 };
 
 typedef struct hsm_opts {
