@@ -33,6 +33,7 @@
 // the reference calls through the float overloads).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 
 namespace hsm {
 
@@ -614,6 +615,110 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
     P.out_pose[3 * scan + 2] = pw2;
     if (P.out_cov) {  // covMatrix = H of the last evaluation (ScanMatcher.h:184), column major
       float* c = P.out_cov + 9 * scan;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
+    }
+  }
+}
+
+// ---- one DENSE scan on many CUs --------------------------------------------------------------------
+// gn_match_kernel keeps a scan inside one workgroup (<= 16 waves on ONE CU): right for batches, but a
+// single 16k-beam scan then uses 1/256 of the chip (11 us per GN step).  This variant spreads the beams of
+// ONE scan over K <= 64 workgroups of 256 lanes and keeps the 14-step chain inside one cooperative launch:
+// per GN step every workgroup reduces its beams to 9 partials, publishes them, the grid synchronises
+// (cooperative groups: all K workgroups are co-resident by construction, the runtime refuses the launch
+// otherwise), and every workgroup sums the K partials in the same fixed order -- wave 0, lane l takes
+// workgroup l, then the DPP/permlane tree -- so all of them take the identical GN step.  Partials are double
+// buffered by step parity: one grid sync per step.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P, float* __restrict__ partials) {
+  namespace cg = cooperative_groups;
+  cg::grid_group grid = cg::this_grid();
+  __shared__ float red[4][9];
+  __shared__ float tot[9];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int K = (int)gridDim.x;
+  const int n = P.shared_n;
+  const float2* __restrict__ pts = P.pts;
+  float pw0 = P.begin_inline[0], pw1 = P.begin_inline[1], pw2 = P.begin_inline[2];
+  const int g0 = blockIdx.x * 256 + threadIdx.x, stride = K * 256;
+  Acc9 acc;
+  acc.zero();
+  int step = 0;
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<LAYOUT>(L);
+    for (int it = 0; it < gn_steps; ++it, ++step) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      acc.zero();
+      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      for (int i = g0; i < n; i += stride) {
+        const float2 p = pts[i];
+        BeamRot r;
+        const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+        beam_finish(b, r, acc);
+      }
+      // workgroup partial: wave all-reduce, 4 waves through LDS (fixed order)
+      wave_allreduce9(acc);
+      if (lane == 0) {
+        float* r = red[wave];
+        r[0] = acc.d01.x; r[1] = acc.d01.y; r[2] = acc.d2;
+        r[3] = acc.hd.x; r[4] = acc.hd.y; r[5] = acc.h22;
+        r[6] = acc.h01; r[7] = acc.hr.x; r[8] = acc.hr.y;
+      }
+      __syncthreads();
+      float* mine = partials + ((size_t)(step & 1) * K + blockIdx.x) * 9;
+      if (threadIdx.x < 9) mine[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      grid.sync();
+      // every workgroup: the same K partials in the same order
+      if (wave == 0) {
+        const float* src = partials + ((size_t)(step & 1) * K + lane) * 9;
+        Acc9 t;
+        t.zero();
+        if (lane < K) {
+          t.d01 = f2{src[0], src[1]}; t.d2 = src[2];
+          t.hd = f2{src[3], src[4]}; t.h22 = src[5];
+          t.h01 = src[6]; t.hr = f2{src[7], src[8]};
+        }
+        wave_allreduce9(t);
+        if (lane == 0) {
+          tot[0] = t.d01.x; tot[1] = t.d01.y; tot[2] = t.d2;
+          tot[3] = t.hd.x; tot[4] = t.hd.y; tot[5] = t.h22;
+          tot[6] = t.h01; tot[7] = t.hr.x; tot[8] = t.hr.y;
+        }
+      }
+      __syncthreads();
+      acc.d01 = f2{tot[0], tot[1]}; acc.d2 = tot[2];
+      acc.hd = f2{tot[3], tot[4]}; acc.h22 = tot[5];
+      acc.h01 = tot[6]; acc.hr = f2{tot[7], tot[8]};
+      gn_solve_and_step(acc, ex, ey, eth);
+      if (P.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+        float* t = P.trace + 12 * step;
+        t[0] = ex; t[1] = ey; t[2] = eth;
+        t[3] = acc.hd.x; t[4] = acc.h01; t[5] = acc.hr.x;
+        t[6] = acc.h01; t[7] = acc.hd.y; t[8] = acc.hr.y;
+        t[9] = acc.hr.x; t[10] = acc.hr.y; t[11] = acc.h22;
+      }
+      __syncthreads();  // tot[] / red[] are rewritten in the next step
+    }
+    eth = normalize_angle(eth);
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+    pw2 = eth;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.out_pose[0] = pw0;
+    P.out_pose[1] = pw1;
+    P.out_pose[2] = pw2;
+    if (P.out_cov) {
+      float* c = P.out_cov;
       c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;

@@ -120,6 +120,8 @@ struct hsm_ctx {
   int trig_n = -1;
   signed char* d_occ = nullptr;     // occupancy export staging
   size_t d_occ_cap = 0;
+  float* d_partials = nullptr;  // [2][64][9] per-workgroup partial sums of gn_match_coop_kernel
+  int coop_min_beams = 4096;    // single scans at least this long take the multi-workgroup matcher (env HSM_COOP_MIN)
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
@@ -480,6 +482,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   }
   h->wps_override = wps;
   if (const char* env = getenv("HSM_BPL")) h->bpl_override = atoi(env) == 0 ? 0 : -1;
+  if (const char* env = getenv("HSM_COOP_MIN")) h->coop_min_beams = atoi(env);
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -494,6 +497,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   CREATE_TRY(hipSetDevice(h->device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
+  CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 9 * sizeof(float)));
   CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float), hipHostMallocMapped));
 
   // MapRepMultiMap ctor (MapRepMultiMap.h:48-72)
@@ -556,6 +560,7 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);
   (void)hipFree(h->d_cells);
+  (void)hipFree(h->d_partials);
   (void)hipFree(h->d_ranges);
   (void)hipFree(h->d_trig);
   (void)hipFree(h->d_ingest);
@@ -712,7 +717,25 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.out_pose = hs_dev + 3;
   P.out_cov = hs_dev + 6;
   P.trace = trace_steps > 0 ? hs_dev + kTraceOff : nullptr;
-  if (int rc = launch_match(h, P, n, h->stream)) return rc;
+  if (n >= h->coop_min_beams && h->wps_override == 0) {
+    // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h)
+    int K = (n + 1023) / 1024;  // ~4 beams per lane
+    if (const char* env = getenv("HSM_COOP_K")) K = atoi(env);
+    if (K > 64) K = 64;
+    if (K < 2) K = 2;
+    float* partials = h->d_partials;
+    void* args[] = {(void*)&P, (void*)&partials};
+    const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane>
+                                                : (const void*)gn_match_coop_kernel<kLayoutQuad>;
+    HIP_TRY(hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream));
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = -K;  // negative: K cooperating workgroups instead of waves per scan
+    h->last_cfg[2] = 256;
+    h->last_cfg[3] = K;
+    h->last_cfg[4] = 0;
+  } else if (int rc = launch_match(h, P, n, h->stream)) {
+    return rc;
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
@@ -726,7 +749,8 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
 // stage a host scan where the matcher can read it: pinned mapped host memory when it will be read
 // once (register resident), device memory otherwise
 static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, size_t& d_cap, const float2** out) {
-  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0) {
+  // (a dense scan for the multi-workgroup matcher is re-read every GN step: it must live in device memory)
+  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && (n < h->coop_min_beams || h->wps_override != 0)) {
     if ((size_t)n > h->h_scan_pinned_cap) {
       if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
       h->h_scan_pinned = nullptr;

@@ -142,7 +142,8 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
         assert e[0] <= TOL_M and e[1] <= TOL_RAD, (t, e)
         step = sc.build_poses[t + 1] - sc.build_poses[t]
         hint_o, hint_g = po + step, pg + step
-    assert p.mapRep.last_launch_config()["waves_per_scan"] == 16
+    cfg = p.mapRep.last_launch_config()
+    assert cfg["waves_per_scan"] == -16 and cfg["grid"] == 16  # 16 cooperating workgroups (multi-CU dense matcher)
     for lvl in range(sc.levels):
         lo_g, _ = p.mapRep.download_level(lvl)
         lo_o, _ = o.download_level(lvl)
