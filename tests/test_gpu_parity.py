@@ -573,3 +573,45 @@ def test_randomised_geometries(capi, oracle_mod):
             assert np.array_equal(g.occupancy_grid(lvl), o.occupancy_grid(lvl))
     assert settled_total >= 0.4 * steps_total, (settled_total, steps_total)
     print(f"settled + well-determined: {settled_total}/{steps_total}")
+
+
+def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene):
+    """single scans >= 4096 beams take the multi-workgroup cooperative matcher (gn_match_coop_kernel): same poses
+    as the one-workgroup kernel and as the oracle, for both layouts, incl. the hook trace"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    rng = np.random.default_rng(77)
+    for layout in (capi.LAYOUT_QUAD, capi.LAYOUT_PLANE):
+        g = make_gpu(capi, sc, build=False, layout=layout)
+        g16 = make_gpu(capi, sc, build=False, layout=layout, waves_per_scan=16)  # forces the one-workgroup kernel
+        for lvl in range(sc.levels):
+            lo, ui = o.download_level(lvl)
+            g.upload_level(lvl, lo, ui)
+            g16.upload_level(lvl, lo, ui)
+        for n_beams in (4096, 8192, 16384):
+            for q in range(3):
+                truth = sc.query_truth[q]
+                pts = synth.make_scan(sc.world, truth, n_beams, s, rng)
+                init = sc.query_init[q]
+                pc, cc = g.matchData(init, pts)
+                cfg = g.last_launch_config()
+                assert cfg["waves_per_scan"] < 0 and cfg["grid"] == (pts.shape[0] + 1023) // 1024, cfg
+                p1, c1 = g16.matchData(init, pts)
+                assert g16.last_launch_config()["waves_per_scan"] == 16
+                po, co = o.match(init, pts)
+                assert_pose_close(pc, po, f"coop vs oracle n={n_beams} q={q}")
+                assert_pose_close(pc, p1, f"coop vs one-workgroup n={n_beams} q={q}")
+                assert np.abs(cc - co).max() <= 1e-4 * np.abs(co).max()
+    # hook trace through the cooperative kernel: 14 records, last H == returned cov
+    import ctypes as C
+    lib = capi.load_library()
+    pts = np.ascontiguousarray(synth.make_scan(sc.world, sc.query_truth[0], 8192, s, rng), np.float32)
+    trace = np.zeros(14 * 12, np.float32)
+    pose, cov, steps = np.zeros(3, np.float32), np.zeros(9, np.float32), C.c_int()
+    capi._check(lib.hsm_match_trace(g._h, sc.query_init[0], pts.ctypes.data, pts.shape[0], np.zeros(2, np.float32), pose,
+                                    cov, trace, 14, C.byref(steps)), "hsm_match_trace")
+    assert steps.value == 14 and np.array_equal(bits(trace[13 * 12 + 3:14 * 12]), bits(cov))
+    po, _ = o.match(sc.query_init[0], pts)
+    assert_pose_close(pose, po, "trace path")
