@@ -863,6 +863,12 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   UpdateBatch batch;
   batch.nlev = 0;
   if (int rc = update_level(h, batch, 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
+  if (n >= 4096) {
+    // dense scan: start level 0 (the longest) right away; the host-side bounding boxes of the coarse levels
+    // are then computed while the GPU is busy.  Small scans keep all levels in one launch per pass (latency).
+    if (int rc = launch_update_batch(h, batch)) return rc;
+    batch.nlev = 0;
+  }
   // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
   const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
   if (h->levels.size() > 1) {
