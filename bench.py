@@ -1,21 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- scan-match Gauss-Newton iterations/sec on MI355X (BASELINE.json metric).
 
-A "step" is one batched matchData over B = 4096 independent 1081-beam scans per GPU on a 2048^2
-map (BASELINE.json configs[2]: "batch=4096 concurrent 1081-beam scans, 2048^2 map, 1 GPU"), i.e.
-B x 6 Gauss-Newton iterations (1 + 5, ScanMatcher.h:74,94-97) in ONE kernel launch, with scans,
-start poses and the map already resident in HBM.  With --gpus N every rank holds a replica of
-the map and its own 4096 scans (weak scaling); the step ends with the single RCCL all-gather of
-the poses.  Rank 0 prints ONE JSON line (see the driver contract in the task description).
+A "step" is one batched matchData over B = 4096 independent 1081-beam scans per GPU on a 2048^2 map
+(BASELINE.json configs[2]: "batch=4096 concurrent 1081-beam scans, 2048^2 map, 1 GPU"), i.e. B x 6 Gauss-Newton
+iterations (1 + 5, ScanMatcher.h:74,94-97) in ONE kernel launch, with scans, start poses and the map already
+resident in HBM.  With --gpus N every rank holds a replica of the map and its own 4096 scans (weak scaling); the
+one collective of the path -- an RCCL all-gather of the [B,3] poses -- is double buffered and asynchronous.  Rank 0
+prints ONE JSON line (see the driver contract in the task description).
 
 Extra evidence in the same line:
-  roofline      dominant kernel (gn_match_kernel) timed with HIP events on its own stream;
-                achieved = algorithmic bytes per launch ((24*N + 60) B per GN iteration,
-                SURVEY.md 8(d)) / mean kernel time; peak = 8 TB/s HBM3E
-  cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and
-                scans, single thread (the reference is single threaded), bounded sample, plus the
-                GPU-vs-CPU pose deviation on that sample (parity evidence, tolerance 1e-4)
+  roofline      dominant kernel (gn_match_kernel), one HIP event pair on its stream around the timed region;
+                achieved = algorithmic bytes per launch ((24*N + 60) B per GN iteration) / mean
+                launch time; peak = 8 TB/s HBM3E; traffic = PMC-measured HBM bytes per launch (profiles/r01);
+                plus the limit that actually binds (VALU-issue floor) -- DESIGN.md 3.1
+  cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and scans, single
+                thread (the reference is single threaded), bounded sample, plus the GPU-vs-CPU pose deviation on
+                that sample (parity evidence, tolerance 1e-4) and the fraction of bit-identical poses;
+                cpu_baseline_all_cores: the same on up to 64 host threads
   pyramid       the same batch through the full 3-level 2048/1024/512 schedule (14 iterations)
+
+--workload config2|config3pyr|config4|config5 measures the other BASELINE configs on one GPU (latency of a single
+scan, 3-level batch, 4096^2 pyramid, dense 16k-beam match+update loop), same JSON schema.
 """
 from __future__ import annotations
 
