@@ -727,12 +727,18 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     void* args[] = {(void*)&P, (void*)&partials};
     const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane>
                                                 : (const void*)gn_match_coop_kernel<kLayoutQuad>;
-    HIP_TRY(hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream));
-    h->last_cfg[0] = h->layout;
-    h->last_cfg[1] = -K;  // negative: K cooperating workgroups instead of waves per scan
-    h->last_cfg[2] = 256;
-    h->last_cfg[3] = K;
-    h->last_cfg[4] = 0;
+    if (hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream) == hipSuccess) {
+      h->last_cfg[0] = h->layout;
+      h->last_cfg[1] = -K;  // negative: K cooperating workgroups instead of waves per scan
+      h->last_cfg[2] = 256;
+      h->last_cfg[3] = K;
+      h->last_cfg[4] = 0;
+    } else {
+      // the runtime could not guarantee co-residency (device busy with other work): the one-workgroup
+      // matcher computes the same thing on one CU
+      (void)hipGetLastError();
+      if (int rc = launch_match(h, P, n, h->stream)) return rc;
+    }
   } else if (int rc = launch_match(h, P, n, h->stream)) {
     return rc;
   }
