@@ -163,3 +163,50 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
     for lvl in range(sc.levels):
         a, b = g2.download_level(lvl), o2.download_level(lvl)
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
+
+
+def test_parity_sweep_32768_scans(capi, oracle_mod):
+    """configs[3]'s full batch -- 32768 scans -- through the 3-level 2048/1024/512 matchData in 8 launches of 4096
+    (what the 8 GPUs do in parallel), EVERY pose compared with the oracle (threads over the host cores, one private
+    oracle each).  Reports the bit-identical fraction; the tolerance must hold on >= 99.8 % of all scans and on
+    every scan whose reference result is settled."""
+    import threading
+    from hector_slam_amd import synth
+    B, G = 4096, 8
+    sc = synth.make_scene(n_beams=1081, map_size=2048, levels=3, resolution=0.05, n_build=120, n_query=B * G,
+                          room=(40.0, 30.0), seed=4242)
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    gpu = np.concatenate([g.match_batch(sc.query_init[k * B:(k + 1) * B],
+                                        pts[offs[k * B]:offs[(k + 1) * B]],
+                                        offs[k * B:(k + 1) * B + 1] - offs[k * B], want_cov=False)[0]
+                          for k in range(G)])
+    T = 16
+    cpu = np.empty_like(gpu)
+    cpu2 = np.empty_like(gpu)
+
+    def work(t):
+        o = make_oracle(oracle_mod, "ho", sc)
+        b, e = (B * G) * t // T, (B * G) * (t + 1) // T
+        o_pts, o_offs = pts[offs[b]:offs[e]], offs[b:e + 1] - offs[b]
+        cpu[b:e] = o.match_many(sc.query_init[b:e], o_pts, o_offs)
+        cpu2[b:e] = o.match_many(cpu[b:e], o_pts, o_offs)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    d = np.abs(gpu.astype(np.float64) - cpu)
+    dth = ang_diff(gpu[:, 2], cpu[:, 2])
+    ok = (d[:, 0] <= TOL_M) & (d[:, 1] <= TOL_M) & (dth <= TOL_RAD)
+    same = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(1)
+    settled = np.abs(cpu2.astype(np.float64) - cpu)[:, :2].max(1) <= 1e-3
+    print(f"32768 scans: bit-identical {same.mean():.4f}, within tolerance {ok.mean():.5f}, settled {settled.mean():.4f}, "
+          f"max dev on settled {d[settled, :2].max():.2e} m, worst overall {d[:, :2].max():.2e} m")
+    assert ok.mean() >= 0.998
+    assert same.mean() >= 0.95
+    # a settled reference result may still sit next to a second fixed point of the piecewise-bilinear cost
+    # (DESIGN.md section 4): allow a handful of those, nothing beyond a millimetre
+    assert (~ok & settled).sum() <= 8 and d[settled, :2].max() <= 1e-3
