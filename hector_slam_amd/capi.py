@@ -77,6 +77,7 @@ SIGNATURES = {
     "hsm_hessian_derivs": (_i, [_vp, _i, _f32p, _vp, _i, _f32p, _f32p]),
     "hsm_eval_beams": (_i, [_vp, _i, _f32p, _vp, _i, _vp]),
     "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
+    "hsm_debug_set_update_serial": (_i, [_vp, _i, C.c_uint]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),

@@ -1259,6 +1259,13 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
   return HSM_OK;
 }
 
+int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial) {
+  if (int rc = valid_level(h, level)) return rc;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->levels[level].serial = serial;
+  return HSM_OK;
+}
+
 int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c) {
   if (!h || n < 0 || (n > 0 && (!x || !s || !c))) return fail(HSM_ERR_INVALID, "hsm_debug_sincos: bad argument");
   if (n == 0) return HSM_OK;

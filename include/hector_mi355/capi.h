@@ -197,6 +197,9 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
 int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy,
                     int n, int max_iterations, float out_pose_world[3], float cov[9]);
 
+/* test hook: set the 16-bit per-scan generation counter of `level`'s key planes (it wraps every 65535
+ * updates -- 27 minutes at 40 Hz -- and the wrap path has to be exercised without running that long) */
+int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial);
 /* device sin/cos (fp64-evaluated, rounded once to fp32) of n angles -- numerics test hook */
 int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
 

@@ -615,3 +615,29 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene):
     assert steps.value == 14 and np.array_equal(bits(trace[13 * 12 + 3:14 * 12]), bits(cov))
     po, _ = o.match(sc.query_init[0], pts)
     assert_pose_close(pose, po, "trace path")
+
+
+def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene):
+    """the key planes carry a 16-bit per-scan generation; after 65535 updates (27 min at 40 Hz) it wraps and the
+    planes are cleared once.  Updates straddling the wrap -- with stale keys of generation 65533..65535 left in the
+    planes -- must still be bit-exact."""
+    sc = pyramid_scene
+    g = make_gpu(capi, sc, build=False)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    lib = capi.load_library()
+    for t in range(24):
+        if t == 6:
+            for lvl in range(sc.levels):
+                capi._check(lib.hsm_debug_set_update_serial(g._h, lvl, 65533 - lvl), "set serial")  # wraps at t = 8..10
+        o.match(sc.build_poses[t], sc.build_scans[t])
+        g.matchData(sc.build_poses[t], sc.build_scans[t])
+        o.update_by_scan(sc.build_poses[t], sc.build_scans[t])
+        g.updateByScan(sc.build_scans[t], sc.build_poses[t])
+        o.on_map_updated()
+    for lvl in range(sc.levels):
+        a, b = g.download_level(lvl), o.download_level(lvl)
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
+        assert np.array_equal(g.occupancy_grid(lvl), o.occupancy_grid(lvl))
+    pg, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
+    po, _ = o.match(sc.query_init[0], sc.query_scans[0])
+    assert_pose_close(pg, po, "after the wrap")
