@@ -10,7 +10,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from hector_slam_amd import capi
-import ctypes as C
 S = 4096
 m = capi.MapRepMultiMap(0.05, S, S, 1)
 lo = np.random.default_rng(0).normal(0, 2, (S, S)).astype(np.float32)
