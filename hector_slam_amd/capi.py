@@ -63,6 +63,14 @@ SIGNATURES = {
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
     "hsm_ray_distances": (_i, [_vp, _i, _f, _f, _f, _i, _f32p, _f32p, _f32p, _f32p]),
     "hsm_likelihood_states": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p]),
+    "hsm_group_create": (_i, [_f, _i, _i, C.c_uint, _f, _f, _i32p, _i, C.POINTER(_vp)]),
+    "hsm_group_destroy": (None, [_vp]),
+    "hsm_group_size": (_i, [_vp]),
+    "hsm_group_member": (_vp, [_vp, _i]),
+    "hsm_group_set_update_factors": (_i, [_vp, _f, _f]),
+    "hsm_group_process_scan": (_i, [_vp, _f32p, _vp, _i, _f32p, _i, _f32p, _f32p]),
+    "hsm_group_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
+    "hsm_retain_scan": (_i, [_vp, _vp, _i, _f32p]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
     "hsm_world_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -365,6 +373,62 @@ class MapRepMultiMap:
                 self.update_by_scan_level(lvl, pose, np.asarray(pts, np.float32) * f,
                                           np.asarray(origo, np.float32) * f)
             self.onMapUpdated()
+
+
+class MapRepGroup:
+    """single-process multi-GPU group (hsm_group_*): one pyramid replica per listed device"""
+
+    def __init__(self, mapResolution, mapSizeX, mapSizeY, numDepth, devices, startCoords=(0.5, 0.5)):
+        self._lib = load_library()
+        self._g = _vp()
+        dev = np.ascontiguousarray(devices, np.int32)
+        _check(self._lib.hsm_group_create(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords[0], startCoords[1],
+                                          dev, dev.size, C.byref(self._g)), "hsm_group_create")
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.hsm_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self._lib.hsm_group_size(self._g)
+
+    def member(self, i):
+        """borrowed view of replica i (do not close it)"""
+        m = MapRepMultiMap.__new__(MapRepMultiMap)
+        m._lib = self._lib
+        m._h = _vp(self._lib.hsm_group_member(self._g, i))
+        m.close = lambda: None
+        return m
+
+    def set_update_factors(self, free, occ):
+        _check(self._lib.hsm_group_set_update_factors(self._g, free, occ), "hsm_group_set_update_factors")
+
+    def process_scan(self, hint_world, pts, origo=_ZERO2, do_update=True, cov=None):
+        a, p, n = _pts(pts)
+        out = np.empty(3, np.float32)
+        c = np.zeros(9, np.float32) if cov is None else _v(cov, 9).copy()
+        _check(self._lib.hsm_group_process_scan(self._g, _v(hint_world, 3), p, n, _v(origo, 2), 1 if do_update else 0,
+                                                out, c), "hsm_group_process_scan")
+        return out, c
+
+    def match_batch(self, begin_world, pts, offsets=None, want_cov=True):
+        b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 3)
+        a, p, n = _pts(pts)
+        out = np.empty_like(b)
+        cov = np.zeros((b.shape[0], 9), np.float32) if want_cov else None
+        offs = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        _check(self._lib.hsm_group_match_batch(self._g, b.shape[0], b.reshape(-1), p,
+                                               None if offs is None else offs.ctypes.data, n if offs is None else 0,
+                                               out.reshape(-1), None if cov is None else cov.ctypes.data),
+               "hsm_group_match_batch")
+        return out, cov
 
 
 def pose_difference_larger_than(p1, p2, dist_thresh, ang_thresh) -> bool:

@@ -16,6 +16,7 @@
 
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gn_match.h"
@@ -1096,6 +1097,122 @@ int hsm_occupancy_grid(hsm_ctx* h, int level, signed char* out) {
   HIP_TRY(hipMemcpyAsync(out, h->d_occ, L.cells(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
+}
+
+int hsm_retain_scan(hsm_ctx* h, const float* pts_xy, int n, const float origo[2]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (n < 0 || (n > 0 && !pts_xy)) return fail(HSM_ERR_INVALID, "hsm_retain_scan: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->levels.size() > 1) {
+    h->retained_pts.assign(pts_xy, pts_xy + 2 * (size_t)n);
+    h->retained_origo[0] = origo ? origo[0] : 0.0f;
+    h->retained_origo[1] = origo ? origo[1] : 0.0f;
+    h->retained_valid = true;
+    h->d_retained_current = false;
+  }
+  return HSM_OK;
+}
+
+}  // extern "C"
+
+struct hsm_group {
+  std::vector<hsm_ctx*> members;
+};
+
+// run fn(replica index) on one host thread per replica; first non-zero status wins
+template <typename F>
+static int group_parallel(hsm_group* g, F fn) {
+  const int R = (int)g->members.size();
+  std::vector<int> rc(R, HSM_OK);
+  std::vector<std::string> err(R);
+  std::vector<std::thread> th;
+  for (int r = 1; r < R; ++r)
+    th.emplace_back([&, r]() {
+      rc[r] = fn(r);
+      if (rc[r] != HSM_OK) err[r] = hsm_last_error();  // thread-local text: carry it to the caller's thread
+    });
+  rc[0] = fn(0);
+  for (std::thread& t : th) t.join();
+  for (int r = 0; r < R; ++r)
+    if (rc[r] != HSM_OK) return r == 0 ? rc[r] : fail(rc[r], err[r].c_str());
+  return HSM_OK;
+}
+
+
+extern "C" {
+
+int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
+                     const int* devices, int n_devices, hsm_group** out) {
+  if (!out || !devices || n_devices < 1) return fail(HSM_ERR_INVALID, "hsm_group_create: bad argument");
+  *out = nullptr;
+  hsm_group* g = new hsm_group();
+  for (int i = 0; i < n_devices; ++i) {
+    hsm_opts o;
+    o.device = devices[i];
+    o.layout = HSM_LAYOUT_AUTO;
+    o.waves_per_scan = 0;
+    hsm_ctx* h = nullptr;
+    const int rc = hsm_create(map_resolution, size_x, size_y, levels, start_x, start_y, &o, &h);
+    if (rc != HSM_OK) {
+      hsm_group_destroy(g);
+      return rc;
+    }
+    g->members.push_back(h);
+  }
+  *out = g;
+  return HSM_OK;
+}
+
+void hsm_group_destroy(hsm_group* g) {
+  if (!g) return;
+  for (hsm_ctx* h : g->members) hsm_destroy(h);
+  delete g;
+}
+
+int hsm_group_size(const hsm_group* g) { return g ? (int)g->members.size() : 0; }
+
+hsm_ctx* hsm_group_member(hsm_group* g, int i) {
+  return (g && i >= 0 && i < (int)g->members.size()) ? g->members[i] : nullptr;
+}
+
+int hsm_group_set_update_factors(hsm_group* g, float free_factor, float occupied_factor) {
+  if (!g) return fail(HSM_ERR_INVALID, "null group");
+  for (hsm_ctx* h : g->members) {
+    if (int rc = hsm_set_update_factor_free(h, free_factor)) return rc;
+    if (int rc = hsm_set_update_factor_occupied(h, occupied_factor)) return rc;
+  }
+  return HSM_OK;
+}
+
+int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float* pts_xy, int n, const float origo[2],
+                           int do_update, float out_pose_world[3], float cov[9]) {
+  if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
+  if (int rc = hsm_match(g->members[0], hint_world, pts_xy, n, origo, out_pose_world, cov)) return rc;
+  if (!do_update) return HSM_OK;
+  return group_parallel(g, [&](int r) -> int {
+    hsm_ctx* h = g->members[r];
+    if (r != 0)
+      if (int rc = hsm_retain_scan(h, pts_xy, n, origo)) return rc;
+    return hsm_update_by_scan(h, out_pose_world, pts_xy, n, origo);
+  });
+}
+
+int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, const float* pts_xy,
+                          const int* scan_offsets, int shared_n, float* out_pose, float* out_cov) {
+  if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
+  if (batch < 0 || !begin_world || !out_pose) return fail(HSM_ERR_INVALID, "hsm_group_match_batch: bad argument");
+  const int R = (int)g->members.size();
+  return group_parallel(g, [&](int r) -> int {
+    const int b = (int)((long long)batch * r / R), e = (int)((long long)batch * (r + 1) / R);
+    if (e == b) return HSM_OK;
+    if (!scan_offsets)  // pose hypotheses of ONE shared scan
+      return hsm_match_batch(g->members[r], e - b, begin_world + 3 * (size_t)b, pts_xy, nullptr, shared_n,
+                             out_pose + 3 * (size_t)b, out_cov ? out_cov + 9 * (size_t)b : nullptr);
+    std::vector<int> offs((size_t)(e - b) + 1);  // CSR offsets rebased to the shard
+    for (int i = b; i <= e; ++i) offs[(size_t)(i - b)] = scan_offsets[i] - scan_offsets[b];
+    return hsm_match_batch(g->members[r], e - b, begin_world + 3 * (size_t)b, pts_xy + 2 * (size_t)scan_offsets[b],
+                           offs.data(), 0, out_pose + 3 * (size_t)b, out_cov ? out_cov + 9 * (size_t)b : nullptr);
+  });
 }
 
 int hsm_level_info(const hsm_ctx* h, int level, int* sx, int* sy, float* cell, float* scale) {

@@ -124,6 +124,29 @@ int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_x
 int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
                              const float* pts_level_xy, int n, const float origo_level[2]);
 
+/* ---- single-process multi-GPU group (extension; the reference has no multi-device path) ------------------
+ * One replica of the pyramid per listed device (a device may be listed more than once).  Batched matching is
+ * sharded contiguously over the replicas, one host thread per replica, results written straight into the
+ * caller's arrays (the "gather" of the poses is the D2H copy of each shard); map updates are replayed on every
+ * replica -- updateByScan is deterministic, so the replicas stay bit-identical.  (bench.py uses the other
+ * deployment shape: one process per GPU and an RCCL all-gather of device-resident poses.) */
+typedef struct hsm_group hsm_group;
+int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
+                     const int* devices, int n_devices, hsm_group** out);
+void hsm_group_destroy(hsm_group* g);
+int hsm_group_size(const hsm_group* g);
+hsm_ctx* hsm_group_member(hsm_group* g, int i); /* replica i: uploads, downloads, queries */
+int hsm_group_set_update_factors(hsm_group* g, float free_factor, float occupied_factor);
+/* HectorSlamProcessor::update's two halves for ONE scan: matchData on replica 0, then -- if do_update --
+ * updateByScan with the matched pose on EVERY replica (each retains the scan first, like its own matchData would) */
+int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float* pts_xy, int n, const float origo[2],
+                           int do_update, float out_pose_world[3], float cov[9]);
+/* hsm_match_batch over all replicas: scans [B*r/R, B*(r+1)/R) go to replica r */
+int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, const float* pts_xy,
+                          const int* scan_offsets, int shared_n, float* out_pose, float* out_cov);
+/* what hsm_match does to the coarse-level containers, without matching (MapRepMultiMap.h:127) */
+int hsm_retain_scan(hsm_ctx* h, const float* pts_xy, int n, const float origo[2]);
+
 /* ---- host mirror support: replaces getGridMap(level) cell access --------------
  * HSL/slam_main/MapRepMultiMap.h:95, HSL/map/GridMapBase.h:141-159 */
 int hsm_level_info(const hsm_ctx* h, int level, int* size_x, int* size_y, float* cell_length,

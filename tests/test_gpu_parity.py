@@ -641,3 +641,48 @@ def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene):
     pg, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
     po, _ = o.match(sc.query_init[0], sc.query_scans[0])
     assert_pose_close(pg, po, "after the wrap")
+
+
+def test_single_process_device_group(capi, oracle_mod, pyramid_scene):
+    """hsm_group_*: R replicas in one process (here all on device 0 -- the sharding, threading and replica
+    consistency logic is the same as with R devices).  Batched matching over the group == one context, bit for
+    bit and in order; the SLAM cycle keeps every replica's map identical to a single context's and to the oracle's"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, [0, 0, 0])
+    assert grp.size() == 3
+    grp.set_update_factors(0.4, 0.9)
+    one = make_gpu(capi, sc, build=False)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o.proc_set_thresholds(0.0, 0.0)
+    origo = np.array([0.2, -0.1], np.float32) * np.float32(sc.scale_to_map)
+    hint = sc.build_poses[0].copy()
+    cov = np.zeros(9, np.float32)
+    for t in range(20):
+        pg, cov = grp.process_scan(hint, sc.build_scans[t], origo, True, cov)
+        o.proc_update(sc.build_scans[t], hint, origo=origo)
+        p1, _ = one.matchData(hint, sc.build_scans[t], None, origo)
+        one.updateByScan(sc.build_scans[t], p1, origo)
+        po, _ = o.proc_last_pose()
+        assert np.array_equal(bits(pg), bits(p1))
+        assert_pose_close(pg, po, f"group t={t}")
+        hint = pg + (sc.build_poses[t + 1] - sc.build_poses[t])
+    for lvl in range(sc.levels):
+        ref = one.download_level(lvl)
+        for r in range(3):
+            got = grp.member(r).download_level(lvl)
+            assert np.array_equal(bits(got[0]), bits(ref[0])) and np.array_equal(got[1], ref[1]), (lvl, r)
+    # batched matching: 16 scans over 3 replicas (uneven shards 5/5/6) == one context
+    pts, offs = synth.pack_scans(sc.query_scans)
+    pa, ca = grp.match_batch(sc.query_init, pts, offs)
+    pb, cb = one.match_batch(sc.query_init, pts, offs)
+    assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(ca), bits(cb))
+    hyp = np.repeat(sc.query_init[3:4], 10, 0) + np.linspace(-0.05, 0.05, 10, dtype=np.float32)[:, None]
+    ha, _ = grp.match_batch(hyp, sc.query_scans[3], None)
+    hb, _ = one.match_batch(hyp, sc.query_scans[3], None)
+    assert np.array_equal(bits(ha), bits(hb))
+    # fewer scans than replicas, and none
+    p2, _ = grp.match_batch(sc.query_init[:2], *synth.pack_scans(sc.query_scans[:2]))
+    assert np.array_equal(bits(p2), bits(pb[:2]))
+    assert grp.match_batch(np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), np.zeros(1, np.int32))[0].shape == (0, 3)
+    grp.close()
