@@ -16,14 +16,20 @@
 //     neighbouring lanes sample neighbouring map cells;
 //   * the occupancy pyramid is sampled from a texture-like "quad" plane: texel
 //     (x,y) = float4{P(x,y), P(x+1,y), P(x,y+1), P(x+1,y+1)} -> ONE 16-byte gather
-//     per beam instead of four 4-byte gathers on two rows (HSM_LAYOUT_PLANE keeps
-//     the 4-gather form for A/B measurements);
+//     per beam instead of four 4-byte gathers on two rows (HSM_LAYOUT_PLANE samples
+//     the probability plane directly and keeps no texel plane: less memory, one pass
+//     less per map update);
 //   * the 6 unique H terms + 3 dTr terms are lane-local fp32 partial sums, reduced
-//     with a wavefront butterfly (__shfl_xor), then -- when WPS > 1 -- staged
-//     through LDS (double buffered, one barrier per GN step);
+//     with a wavefront all-reduce (4 DPP row steps + v_permlane16/32_swap, no LDS),
+//     then -- when WPS > 1 -- staged through LDS (double buffered, one barrier per
+//     GN step);
 //   * every lane ends up with bit-identical totals and solves the 3x3 system
-//     redundantly: no broadcast, no divergence.
+//     redundantly: no broadcast, no divergence;
+//   * a single DENSE scan (>= 4096 beams) is spread over up to 64 workgroups of one
+//     cooperative launch instead (gn_match_coop_kernel, one grid sync per GN step).
 //   No MFMA: this is a bilinear gather plus a 9-term reduction, not a contraction.
+//   Measured limits (profiles/r01/README.md): VALU issue (62 instructions per beam) and
+//   the texture path of the divergent 16-byte gathers -- not HBM.
 //
 // Numerics: built with -ffp-contract=off.  Every per-beam value (M, dM/dx, dM/dy,
 // rotDeriv and the nine products) is the same IEEE fp32 expression, in the same
