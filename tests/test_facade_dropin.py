@@ -198,3 +198,26 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
                 assert np.abs(x[:2] - y[:2]).max() <= 2e-4
             else:
                 assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_dropin_dense_scans_take_the_cooperative_matcher(tmp_path):
+    """8192-beam scans through the C++ facade: the library switches to the multi-workgroup cooperative matcher
+    (and the standalone driver runs on the system HIP runtime, not torch's) -- same comparison as above"""
+    if not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)):
+        pytest.skip("oracle/_ref drivers not prebuilt")
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=8192, map_size=512, levels=3, resolution=0.05, n_build=16, n_query=2,
+                          room=(20.0, 15.0), seed=123)
+    steps = 12
+    scen = str(tmp_path / "s.bin")
+    write_scenario(scen, sc, steps, hooks=0, mwm_at=())
+    run(REF_BIN, scen, str(tmp_path / "ref.bin"))
+    run(GPU_BIN, scen, str(tmp_path / "gpu.bin"))
+    r, g = read_output(str(tmp_path / "ref.bin"), steps), read_output(str(tmp_path / "gpu.bin"), steps)
+    assert np.abs(r["pose"][:, :2].astype(np.float64) - g["pose"][:, :2]).max() <= 1e-4
+    assert ang_diff(r["pose"][:, 2], g["pose"][:, 2]).max() <= 1e-4
+    assert np.abs(r["batch"].astype(np.float64) - g["batch"]).max() <= 1e-4
+    for a, b in zip(r["grids"], g["grids"]):
+        touched = (a["val"] != 0).sum()
+        assert touched > 1000 and (a["val"].view(np.uint32) != b["val"].view(np.uint32)).sum() <= 0.002 * touched
