@@ -54,3 +54,14 @@ def test_product_never_references_the_oracle():
                     if re.search(r"\bimport\s+oracle|from\s+oracle|oracle/|libhector_oracle|libhector_ref|pyoracle", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: the header must compile as C (what cgo / JNI / ctypes-style bindings consume)"""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "hector_mi355/capi.h"\n'
+                   'int main(void) { hsm_ctx* h = 0; hsm_opts o = {-1, HSM_LAYOUT_AUTO, 0}; (void)o;\n'
+                   '  return hsm_create(0.05f, 64, 64, 1u, 0.5f, 0.5f, &o, &h) == HSM_OK ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-I",
+                    os.path.join(ROOT, "include"), "-o", str(tmp_path / "use.o")], check=True)
