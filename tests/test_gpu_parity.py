@@ -740,3 +740,29 @@ def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, l
         a, b = g.download_level(lvl), o.download_level(lvl)
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
         assert g.getUpdateIndex(lvl) == 35  # reset() does not rewind the update counter (GridMapBase::reset)
+
+
+def test_ragged_batch_with_empty_and_tiny_scans(capi, pyr, pyramid_scene):
+    """CSR batch mixing empty scans, 1..70-beam fragments and full scans: every entry equals its single-scan call
+    (same team width), empty scans pass their start pose through and leave cov untouched"""
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    g1 = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)
+    for lvl in range(sc.levels):
+        g1.upload_level(lvl, *o.download_level(lvl))
+    full = sc.query_scans[0]
+    sizes = [0, 1081 if full.shape[0] >= 1081 else full.shape[0], 1, 0, 70, 64, 2, 500, 0]
+    scans = [full[np.linspace(0, full.shape[0] - 1, n).astype(int)] if n else np.zeros((0, 2), np.float32) for n in sizes]
+    init = np.repeat(sc.query_init[0:1], len(sizes), 0) + np.arange(len(sizes), dtype=np.float32)[:, None] * 1e-3
+    pts, offs = synth.pack_scans(scans)
+    pose, cov = g1.match_batch(init, pts, offs)
+    for i, n in enumerate(sizes):
+        if n == 0:
+            assert np.array_equal(bits(pose[i]), bits(init[i])) and not cov[i].any()
+        else:
+            ps, cs = g1.matchData(init[i], scans[i])
+            assert np.array_equal(bits(ps), bits(pose[i])) and np.array_equal(bits(cs), bits(cov[i])), (i, n)
+            if n >= 500:
+                po, _ = o.match(init[i], scans[i])
+                assert_pose_close(pose[i], po, f"ragged {i}")
