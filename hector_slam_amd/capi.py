@@ -58,6 +58,9 @@ SIGNATURES = {
     "hsm_update_by_scan": (_i, [_vp, _f32p, _vp, _i, _f32p]),
     "hsm_update_by_scan_level": (_i, [_vp, _i, _f32p, _vp, _i, _f32p]),
     "hsm_ingest_laser_scan": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _f, _vp, C.POINTER(_i)]),
+    "hsm_ingest_point_cloud": (_i, [_vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _vp, C.POINTER(_i), _vp]),
+    "hsm_ingest_laser_scan_tf": (_i, [_vp, _vp, _i, _f, _f, _f, _f, C.c_double, _vp, _f, _f, _f, _f, _f, _vp,
+                                      C.POINTER(_i), _vp]),
     "hsm_match_ingested": (_i, [_vp, _f32p, _f32p, _f32p]),
     "hsm_update_by_ingested": (_i, [_vp, _f32p]),
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
@@ -253,6 +256,38 @@ class MapRepMultiMap:
                                                angle_increment, range_min, range_max, s, out.ctypes.data,
                                                C.byref(m)), "hsm_ingest_laser_scan")
         return out[:m.value].copy()
+
+    def ingest_point_cloud(self, pts_xyz, tf_rows, sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min,
+                           laser_z_max, scale_to_map=None):
+        """rosPointCloudToDataContainer on the device; tf_rows = laser->base transform, 12 doubles [R | t]
+        row major.  Returns (endpoints (m, 2), origo (2,))."""
+        p = np.ascontiguousarray(pts_xyz, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(tf_rows, np.float64).reshape(12)
+        out = np.empty((max(p.shape[0], 1), 2), np.float32)
+        origo = np.empty(2, np.float32)
+        m = _i()
+        s = self.getScaleToMap() if scale_to_map is None else scale_to_map
+        _check(self._lib.hsm_ingest_point_cloud(self._h, p.ctypes.data if p.size else None, p.shape[0],
+                                                T.ctypes.data, sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min,
+                                                laser_z_max, s, out.ctypes.data, C.byref(m), origo.ctypes.data),
+               "hsm_ingest_point_cloud")
+        return out[:m.value].copy(), origo
+
+    def ingest_laser_scan_tf(self, ranges, angle_min, angle_increment, range_min, range_max, range_cutoff, tf_rows,
+                             sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min, laser_z_max, scale_to_map=None):
+        """projectLaser + rosPointCloudToDataContainer fused on the device (the node's default path)"""
+        r = np.ascontiguousarray(ranges, np.float32).reshape(-1)
+        T = np.ascontiguousarray(tf_rows, np.float64).reshape(12)
+        out = np.empty((max(r.size, 1), 2), np.float32)
+        origo = np.empty(2, np.float32)
+        m = _i()
+        s = self.getScaleToMap() if scale_to_map is None else scale_to_map
+        _check(self._lib.hsm_ingest_laser_scan_tf(self._h, r.ctypes.data if r.size else None, r.size, angle_min,
+                                                  angle_increment, range_min, range_max, range_cutoff, T.ctypes.data,
+                                                  sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min, laser_z_max,
+                                                  s, out.ctypes.data, C.byref(m), origo.ctypes.data),
+               "hsm_ingest_laser_scan_tf")
+        return out[:m.value].copy(), origo
 
     def match_ingested(self, beginEstimateWorld, covMatrix=None):
         out = np.empty(3, np.float32)

@@ -112,7 +112,9 @@ struct hsm_ctx {
   size_t h_scan_pinned_cap = 0;
   // ingested scan (hsm_ingest_laser_scan): device container + host copy, sensor trig table cache
   float* d_ranges = nullptr;
-  float2* d_trig = nullptr;
+  void* d_trig = nullptr;           // float2 (running-angle table) or double2 (laser_geometry unit vectors)
+  int trig_kind = -1;
+  float ingest_origo[2] = {0.f, 0.f};
   float2* d_ingest = nullptr;
   size_t ingest_cap = 0;
   std::vector<float> h_ingest;      // endpoints as the matcher/updater see them (host copy)
@@ -925,6 +927,42 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
   return HSM_OK;
 }
 
+// device buffers of the ingestion entries: raw input (3 floats per element covers ranges and Point32
+// clouds; the int behind it is the survivor count), the sensor-geometry table (16 B per beam covers the
+// float2 and the double2 variant) and the container
+static int ensure_ingest_capacity(hsm_ctx* h, int n) {
+  if (h->d_ranges && (size_t)n <= h->ingest_cap) return HSM_OK;
+  (void)hipFree(h->d_ranges);
+  (void)hipFree(h->d_trig);
+  (void)hipFree(h->d_ingest);
+  h->d_ranges = nullptr;
+  h->d_trig = nullptr;
+  h->d_ingest = nullptr;
+  h->ingest_cap = 0;
+  h->trig_n = -1;
+  const size_t want = n < 2048 ? 2048 : (size_t)n + n / 2;
+  HIP_TRY(hipMalloc((void**)&h->d_ranges, 3 * want * sizeof(float) + sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&h->d_trig, want * sizeof(double2)));
+  HIP_TRY(hipMalloc((void**)&h->d_ingest, want * sizeof(float2)));
+  h->ingest_cap = want;
+  return HSM_OK;
+}
+
+static int* ingest_count_ptr(hsm_ctx* h) { return reinterpret_cast<int*>(h->d_ranges + 3 * h->ingest_cap); }
+
+// fetch the survivor count + the container the kernel on h->stream just produced
+static int finish_ingest(hsm_ctx* h, float* out_pts_xy, int* out_n) {
+  int m = 0;
+  HIP_TRY(hipMemcpyAsync(&m, ingest_count_ptr(h), sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->h_ingest.resize(2 * (size_t)m);
+  if (m > 0) HIP_TRY(hipMemcpy(h->h_ingest.data(), h->d_ingest, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost));
+  h->ingest_n = m;
+  if (out_pts_xy && m > 0) memcpy(out_pts_xy, h->h_ingest.data(), (size_t)m * sizeof(float2));
+  if (out_n) *out_n = m;
+  return HSM_OK;
+}
+
 int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
                           float range_min, float range_max, float scale_to_map, float* out_pts_xy, int* out_n) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
@@ -932,22 +970,8 @@ int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_mi
     return fail(HSM_ERR_INVALID, "hsm_ingest_laser_scan: bad argument");
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
-  if ((size_t)n > h->ingest_cap) {
-    (void)hipFree(h->d_ranges);
-    (void)hipFree(h->d_trig);
-    (void)hipFree(h->d_ingest);
-    h->d_ranges = nullptr;
-    h->d_trig = nullptr;
-    h->d_ingest = nullptr;
-    h->ingest_cap = 0;
-    h->trig_n = -1;
-    const size_t want = n < 2048 ? 2048 : (size_t)n + n / 2;
-    HIP_TRY(hipMalloc((void**)&h->d_ranges, want * sizeof(float) + sizeof(int)));  // + the count
-    HIP_TRY(hipMalloc((void**)&h->d_trig, want * sizeof(float2)));
-    HIP_TRY(hipMalloc((void**)&h->d_ingest, want * sizeof(float2)));
-    h->ingest_cap = want;
-  }
-  if (h->trig_n != n || h->trig_a0 != angle_min || h->trig_inc != angle_increment) {
+  if (int rc = ensure_ingest_capacity(h, n)) return rc;
+  if (h->trig_kind != 0 || h->trig_n != n || h->trig_a0 != angle_min || h->trig_inc != angle_increment) {
     // the node's running fp32 angle and its float cos/sin (HectorMappingRos.cpp:487,502,505): sensor
     // constants, evaluated once per geometry on the host exactly as the node does
     std::vector<float> t(2 * (size_t)n);
@@ -958,44 +982,114 @@ int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_mi
       angle += angle_increment;
     }
     if (n > 0) HIP_TRY(hipMemcpy(h->d_trig, t.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+    h->trig_kind = 0;
     h->trig_n = n;
     h->trig_a0 = angle_min;
     h->trig_inc = angle_increment;
   }
-  int* d_count = reinterpret_cast<int*>(h->d_ranges + h->ingest_cap);
   if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_ranges, ranges, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const float maxRangeForContainer = range_max - 0.1f;  // :493
-  hipLaunchKernelGGL(ingest_laser_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_ranges, h->d_trig, n,
-                     range_min, maxRangeForContainer, scale_to_map, h->d_ingest, d_count);
+  hipLaunchKernelGGL(ingest_laser_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_ranges,
+                     reinterpret_cast<const float2*>(h->d_trig), n, range_min, maxRangeForContainer, scale_to_map,
+                     h->d_ingest, ingest_count_ptr(h));
   HIP_TRY(hipGetLastError());
-  int m = 0;
-  HIP_TRY(hipMemcpyAsync(&m, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->h_ingest.resize(2 * (size_t)m);
-  if (m > 0) HIP_TRY(hipMemcpy(h->h_ingest.data(), h->d_ingest, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost));
-  h->ingest_n = m;
-  if (out_pts_xy && m > 0) memcpy(out_pts_xy, h->h_ingest.data(), (size_t)m * sizeof(float2));
-  if (out_n) *out_n = m;
-  return HSM_OK;
+  h->ingest_origo[0] = h->ingest_origo[1] = 0.0f;  // dataContainer.setOrigo(Vector2f::Zero()), :491
+  return finish_ingest(h, out_pts_xy, out_n);
+}
+
+// shared tail of the two point-cloud entries
+static int ingest_cloud(hsm_ctx* h, CloudIngestParams& P, const double tf_rows[12], float sqr_min, float sqr_max,
+                        float z_min, float z_max, float scale_to_map, float* out_pts_xy, int* out_n,
+                        float out_origo[2]) {
+  for (int k = 0; k < 12; ++k) P.T[k] = tf_rows[k];
+  P.sqr_min = sqr_min;
+  P.sqr_max = sqr_max;
+  P.z_min = z_min;
+  P.z_max = z_max;
+  P.scale = scale_to_map;
+  P.out = h->d_ingest;
+  P.out_n = ingest_count_ptr(h);
+  hipLaunchKernelGGL(ingest_point_cloud_kernel, dim3(1), dim3(1024), 0, h->stream, P);
+  HIP_TRY(hipGetLastError());
+  // dataContainer.setOrigo(Eigen::Vector2f(laserPos.x(), laserPos.y()) * scaleToMap)  (:517)
+  h->ingest_origo[0] = (float)tf_rows[3] * scale_to_map;
+  h->ingest_origo[1] = (float)tf_rows[7] * scale_to_map;
+  if (out_origo) {
+    out_origo[0] = h->ingest_origo[0];
+    out_origo[1] = h->ingest_origo[1];
+  }
+  return finish_ingest(h, out_pts_xy, out_n);
+}
+
+int hsm_ingest_point_cloud(hsm_ctx* h, const float* pts_xyz, int n, const double tf_rows[12], float sqr_laser_min_dist,
+                           float sqr_laser_max_dist, float laser_z_min, float laser_z_max, float scale_to_map,
+                           float* out_pts_xy, int* out_n, float out_origo[2]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (n < 0 || (n > 0 && !pts_xyz) || !tf_rows || n > HSM_MAX_UPDATE_BEAMS)
+    return fail(HSM_ERR_INVALID, "hsm_ingest_point_cloud: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_ingest_capacity(h, n)) return rc;
+  if (n > 0)
+    HIP_TRY(hipMemcpyAsync(h->d_ranges, pts_xyz, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CloudIngestParams P{};
+  P.pts_xyz = h->d_ranges;
+  P.n = n;
+  return ingest_cloud(h, P, tf_rows, sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min, laser_z_max, scale_to_map,
+                      out_pts_xy, out_n, out_origo);
+}
+
+int hsm_ingest_laser_scan_tf(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
+                             float range_min, float range_max, double range_cutoff, const double tf_rows[12],
+                             float sqr_laser_min_dist, float sqr_laser_max_dist, float laser_z_min, float laser_z_max,
+                             float scale_to_map, float* out_pts_xy, int* out_n, float out_origo[2]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (n < 0 || (n > 0 && !ranges) || !tf_rows || n > HSM_MAX_UPDATE_BEAMS)
+    return fail(HSM_ERR_INVALID, "hsm_ingest_laser_scan_tf: bad argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_ingest_capacity(h, n)) return rc;
+  if (h->trig_kind != 1 || h->trig_n != n || h->trig_a0 != angle_min || h->trig_inc != angle_increment) {
+    // laser_geometry's unit vectors (getUnitVectors_): double cos/sin(angle_min + (double)i * angle_increment),
+    // cached per sensor geometry there as well
+    std::vector<double> t(2 * (size_t)n);
+    const double a0 = angle_min, inc = angle_increment;
+    for (int i = 0; i < n; ++i) {
+      t[2 * i] = cos(a0 + (double)i * inc);
+      t[2 * i + 1] = sin(a0 + (double)i * inc);
+    }
+    if (n > 0) HIP_TRY(hipMemcpy(h->d_trig, t.data(), (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
+    h->trig_kind = 1;
+    h->trig_n = n;
+    h->trig_a0 = angle_min;
+    h->trig_inc = angle_increment;
+  }
+  if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_ranges, ranges, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CloudIngestParams P{};
+  P.ranges = h->d_ranges;
+  P.unit = reinterpret_cast<const double2*>(h->d_trig);
+  P.n = n;
+  P.range_min = range_min;
+  P.range_cutoff = range_cutoff < 0 ? (double)range_max : range_cutoff;
+  return ingest_cloud(h, P, tf_rows, sqr_laser_min_dist, sqr_laser_max_dist, laser_z_min, laser_z_max, scale_to_map,
+                      out_pts_xy, out_n, out_origo);
 }
 
 int hsm_match_ingested(hsm_ctx* h, const float begin_world[3], float out_pose_world[3], float cov[9]) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   if (h->ingest_n < 0) return fail(HSM_ERR_INVALID, "hsm_match_ingested: no scan ingested");
-  const float origo[2] = {0.0f, 0.0f};  // dataContainer.setOrigo(Vector2f::Zero()), HectorMappingRos.cpp:491
   static const float dummy[2] = {0.0f, 0.0f};
   const float* hp = h->ingest_n > 0 ? h->h_ingest.data() : dummy;
-  return match_impl(h, begin_world, hp, h->ingest_n, origo, out_pose_world, cov, nullptr, 0, h->d_ingest);
+  return match_impl(h, begin_world, hp, h->ingest_n, h->ingest_origo, out_pose_world, cov, nullptr, 0, h->d_ingest);
 }
 
 int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   if (!pose_world || h->ingest_n < 0) return fail(HSM_ERR_INVALID, "hsm_update_by_ingested: no scan ingested");
   std::lock_guard<std::mutex> lk(h->mu);
-  const float origo[2] = {0.0f, 0.0f};
   static const float dummy[2] = {0.0f, 0.0f};
   const float* hp = h->ingest_n > 0 ? h->h_ingest.data() : dummy;
-  return update_impl(h, pose_world, hp, h->ingest_n, origo, h->d_ingest);
+  return update_impl(h, pose_world, hp, h->ingest_n, h->ingest_origo, h->d_ingest);
 }
 
 int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,

@@ -405,6 +405,79 @@ __global__ void __launch_bounds__(1024) ingest_laser_scan_kernel(const float* __
   if (threadIdx.x == 0) *out_n = base;
 }
 
+// rosPointCloudToDataContainer (HectorMappingRos.cpp:509-542), optionally preceded by
+// laser_geometry's projectLaser (the node's default path, :273-282; third party, algorithm stated in
+// include/hector_mi355/capi.h): one pass, ordered compaction like the kernel above.  tf arithmetic is fp64
+// (tfScalar), the gates and the products fp32, exactly the node's types.
+struct CloudIngestParams {
+  const float* pts_xyz;  // [n,3] geometry_msgs::Point32, or nullptr when projecting from ranges
+  const float* ranges;   // projectLaser input, or nullptr
+  const double2* unit;   // (cos, sin)(angle_min + (double)i * angle_increment): sensor constants from the host
+  int n;
+  float range_min;       // projectLaser gate: range < range_cutoff (double compare) && range >= range_min
+  double range_cutoff;
+  double T[12];          // laser -> base transform, rows [R | t]
+  float sqr_min, sqr_max, z_min, z_max, scale;
+  float2* out;
+  int* out_n;
+};
+
+__global__ void __launch_bounds__(1024) ingest_point_cloud_kernel(CloudIngestParams P) {
+  __shared__ int wave_count[16];
+  __shared__ int base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < P.n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    bool keep = false;
+    float2 e = make_float2(0.0f, 0.0f);
+    if (i < P.n) {
+      float px, py, pz;
+      bool valid = true;
+      if (P.ranges) {
+        const float range = P.ranges[i];
+        const double r = (double)range;
+        const double2 u = P.unit[i];
+        px = (float)(r * u.x);
+        py = (float)(r * u.y);
+        pz = 0.0f;
+        valid = ((double)range < P.range_cutoff) && (range >= P.range_min);
+      } else {
+        px = P.pts_xyz[3 * (size_t)i];
+        py = P.pts_xyz[3 * (size_t)i + 1];
+        pz = P.pts_xyz[3 * (size_t)i + 2];
+      }
+      const float dist_sqr = px * px + py * py;
+      if (valid && (dist_sqr > P.sqr_min) && (dist_sqr < P.sqr_max) && !((px < 0.0f) && (dist_sqr < 0.50f))) {
+        const double vx = px, vy = py, vz = pz;
+        const double bx = (P.T[0] * vx + P.T[1] * vy + P.T[2] * vz) + P.T[3];
+        const double by = (P.T[4] * vx + P.T[5] * vy + P.T[6] * vz) + P.T[7];
+        const double bz = (P.T[8] * vx + P.T[9] * vy + P.T[10] * vz) + P.T[11];
+        const float zl = (float)(bz - P.T[11]);
+        if (zl > P.z_min && zl < P.z_max) {
+          keep = true;
+          e = make_float2((float)bx * P.scale, (float)by * P.scale);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_count[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_count[w];
+    if (keep) P.out[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_count[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *P.out_n = base;
+}
+
 __global__ void rebuild_prob_kernel(LevelRW L) {
   const size_t n = (size_t)L.sx * L.sy;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -184,7 +184,27 @@ int hsm_take_dirty_bbox(hsm_ctx* h, int level, int bbox[4]);
  * out_pts_xy (host, capacity 2*n floats, may be NULL) receives the endpoints, *out_n their count. */
 int hsm_ingest_laser_scan(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
                           float range_min, float range_max, float scale_to_map, float* out_pts_xy, int* out_n);
-/* hsm_match / hsm_update_by_scan on the ingested scan (no endpoint upload) */
+/* replaces: rosPointCloudToDataContainer (HectorMappingRos.cpp:509-542), the node's DEFAULT ingestion
+ * (use_tf_scan_transformation = true, :82,:257-282): n geometry_msgs::Point32 {x,y,z} floats in the laser
+ * frame + the laser->base tf::Transform as 12 doubles, rows [R | t] (tfScalar is double).  Gates as the node:
+ * x*x+y*y in (sqr_laser_min_dist, sqr_laser_max_dist), x < 0 && dist_sqr < 0.5 dropped, base-frame z minus
+ * t_z in (laser_z_min, laser_z_max); endpoint = float(base x,y) * scale_to_map, ordered compaction.  The
+ * container stays on the device with origo = float(t_x, t_y) * scale_to_map (also written to out_origo,
+ * may be NULL); out_pts_xy capacity 2*n floats, may be NULL. */
+int hsm_ingest_point_cloud(hsm_ctx* h, const float* pts_xyz, int n, const double tf_rows[12],
+                           float sqr_laser_min_dist, float sqr_laser_max_dist, float laser_z_min, float laser_z_max,
+                           float scale_to_map, float* out_pts_xy, int* out_n, float out_origo[2]);
+/* the same with the step before it fused in: laser_geometry::LaserProjection::projectLaser(scan, cloud,
+ * range_cutoff) (HectorMappingRos.cpp:273; third-party package, not in the reference tree -- restated from
+ * its published algorithm: point = float((double)range * (cos, sin)(angle_min + (double)i * angle_increment)),
+ * kept when range < range_cutoff && range >= range_min; range_cutoff < 0 means range_max), so raw
+ * LaserScan.ranges[] (4 B/beam) is the wire format on the tf path as well. */
+int hsm_ingest_laser_scan_tf(hsm_ctx* h, const float* ranges, int n, float angle_min, float angle_increment,
+                             float range_min, float range_max, double range_cutoff, const double tf_rows[12],
+                             float sqr_laser_min_dist, float sqr_laser_max_dist, float laser_z_min,
+                             float laser_z_max, float scale_to_map, float* out_pts_xy, int* out_n,
+                             float out_origo[2]);
+/* hsm_match / hsm_update_by_scan on the ingested scan (no endpoint upload; origo as ingested) */
 int hsm_match_ingested(hsm_ctx* h, const float begin_world[3], float out_pose_world[3], float cov[9]);
 int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]);
 /* replaces: OccGridMapUtil::getLikelihoodForState (HSL/map/OccGridMapUtil.h:184-214) evaluated for

@@ -740,6 +740,55 @@ int ho_laser_scan_to_container(const float* ranges, int n, float angle_min, floa
   return m;
 }
 
+int ho_point_cloud_to_container(const float* pts, int n, const double T[12], float sqr_min, float sqr_max, float z_min,
+                                float z_max, float scaleToMap, float* out_pts, float out_origo[2]) {
+  // HectorMappingRos.cpp:509-542.  laserPos = laserTransform.getOrigin() (doubles)
+  const double lx = T[3], ly = T[7], lz = T[11];
+  out_origo[0] = (float)lx * scaleToMap;  // Eigen::Vector2f(laserPos.x(), laserPos.y()) * scaleToMap  (:517)
+  out_origo[1] = (float)ly * scaleToMap;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const float dist_sqr = px * px + py * py;  // :524
+    if ((dist_sqr > sqr_min) && (dist_sqr < sqr_max)) {
+      if ((px < 0.0f) && (dist_sqr < 0.50f)) continue;  // :528
+      // tf::Transform * tf::Vector3: m_basis[r].dot(v) + m_origin[r], all double
+      const double vx = px, vy = py, vz = pz;
+      const double bx = (T[0] * vx + T[1] * vy + T[2] * vz) + lx;
+      const double by = (T[4] * vx + T[5] * vy + T[6] * vz) + ly;
+      const double bz = (T[8] * vx + T[9] * vy + T[10] * vz) + lz;
+      const float pointPosLaserFrameZ = (float)(bz - lz);  // :534
+      if (pointPosLaserFrameZ > z_min && pointPosLaserFrameZ < z_max) {
+        out_pts[2 * m] = (float)bx * scaleToMap;  // Eigen::Vector2f(x, y) * scaleToMap  (:538)
+        out_pts[2 * m + 1] = (float)by * scaleToMap;
+        ++m;
+      }
+    }
+  }
+  return m;
+}
+
+int ho_project_laser(const float* ranges, int n, float angle_min, float angle_increment, float range_min,
+                     float range_max, double range_cutoff, float* out_xyz) {
+  // laser_geometry 1.6.x LaserProjection::projectLaser_ / getUnitVectors_ (third party, restated)
+  if (range_cutoff < 0) range_cutoff = range_max;
+  const double a0 = angle_min, inc = angle_increment;
+  int count = 0;
+  for (int i = 0; i < n; ++i) {
+    const double r = (double)ranges[i];
+    const double ox = r * cos(a0 + (double)i * inc);
+    const double oy = r * sin(a0 + (double)i * inc);
+    const float range = (float)r;
+    if ((range < range_cutoff) && (range >= range_min)) {
+      out_xyz[3 * count] = (float)ox;
+      out_xyz[3 * count + 1] = (float)oy;
+      out_xyz[3 * count + 2] = 0.0f;
+      ++count;
+    }
+  }
+  return count;
+}
+
 float ho_normalize_angle(float a) { return normalize_angle(a); }
 int ho_pose_difference_larger_than(const float p1[3], const float p2[3], float d, float a) {
   return pose_difference_larger_than(p1, p2, d, a) ? 1 : 0;

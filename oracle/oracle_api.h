@@ -104,6 +104,22 @@ void ORF(ray_distances)(const signed char* grid, int sx, int sy, float origin_x,
 int ORF(laser_scan_to_container)(const float* ranges, int n, float angle_min, float angle_increment,
                                  float range_min, float range_max, float scale_to_map, float* out_pts);
 
+/* f1b: rosPointCloudToDataContainer (:509-542): Point32 cloud (n x {x,y,z} floats) + the laser->base
+ * tf::Transform given as 12 doubles, row major [R | t] (tfScalar = double; tf::Transform::operator()
+ * = row.dot(v) + origin, dot = x*x' + y*y' + z*z' left to right).  Gates: float dist_sqr in
+ * (sqr_min, sqr_max); x < 0 && dist_sqr < 0.5 skipped; float(z_base - t_z) in (z_min, z_max).
+ * out_origo = Vector2f(t_x, t_y) * scale_to_map.  Returns the number of endpoints. */
+int ORF(point_cloud_to_container)(const float* pts_xyz, int n, const double tf_rows[12], float sqr_min, float sqr_max,
+                                  float z_min, float z_max, float scale_to_map, float* out_pts, float out_origo[2]);
+/* step before f1b in the node's default configuration (use_tf_scan_transformation = true, :273):
+ * laser_geometry::LaserProjection::projectLaser(scan, cloud, range_cutoff) -- THIRD PARTY, absent from
+ * the reference tree (package.xml: laser_geometry, unpinned; Noetic ships 1.6.7).  Restated from its
+ * published algorithm: double unit vectors cos/sin(angle_min + (double)i * angle_increment), point =
+ * float((double)range * unit), kept when range < range_cutoff (double compare; cutoff < 0 => range_max)
+ * and range >= range_min, z = 0.  Parity for THIS step is pinned only to the restatement. */
+int ORF(project_laser)(const float* ranges, int n, float angle_min, float angle_increment, float range_min,
+                       float range_max, double range_cutoff, float* out_xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,9 @@ def _load(kind: str):
                                  _f32p, _f32p]),
         "occupancy_grid": (None, [vp, i, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
         "laser_scan_to_container": (i, [_f32p, i, f, f, f, f, f, _f32p]),
+        "point_cloud_to_container": (i, [_f32p, i, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"),
+                                         f, f, f, f, f, _f32p, _f32p]),
+        "project_laser": (i, [_f32p, i, f, f, f, f, C.c_double, _f32p]),
         "normalize_angle": (f, [f]),
         "pose_difference_larger_than": (i, [_f32p, _f32p, f, f]),
     }
@@ -243,6 +246,22 @@ class Oracle:
         m = self.f["laser_scan_to_container"](r, r.size, angle_min, angle_increment, range_min, range_max,
                                               scale_to_map, out)
         return out[:2 * m].reshape(m, 2).copy()
+
+    def point_cloud_to_container(self, pts_xyz, tf_rows, sqr_min, sqr_max, z_min, z_max, scale_to_map):
+        """-> (endpoints [m,2], origo [2])"""
+        p = np.ascontiguousarray(pts_xyz, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(tf_rows, np.float64).reshape(12)
+        out = np.empty(2 * max(p.shape[0], 1), np.float32)
+        origo = np.empty(2, np.float32)
+        m = self.f["point_cloud_to_container"](p.reshape(-1), p.shape[0], T, sqr_min, sqr_max, z_min, z_max,
+                                               scale_to_map, out, origo)
+        return out[:2 * m].reshape(m, 2).copy(), origo
+
+    def project_laser(self, ranges, angle_min, angle_increment, range_min, range_max, range_cutoff):
+        r = np.ascontiguousarray(ranges, np.float32)
+        out = np.empty(3 * max(r.size, 1), np.float32)
+        m = self.f["project_laser"](r, r.size, angle_min, angle_increment, range_min, range_max, range_cutoff, out)
+        return out[:3 * m].reshape(m, 3).copy()
 
     def normalize_angle(self, a) -> float:
         return self.f["normalize_angle"](float(a))

@@ -1,5 +1,6 @@
 """Rows next to the hot path: LaserScan ingestion (rosLaserScanToDataContainer,
-hector_mapping/src/HectorMappingRos.cpp:483-507) and occupancy export (publishMap's cell loop, :449-468).
+hector_mapping/src/HectorMappingRos.cpp:483-507), PointCloud ingestion (rosPointCloudToDataContainer, :509-542,
+the node's default with use_tf_scan_transformation) and occupancy export (publishMap's cell loop, :449-468).
 Integer / byte / index work: BIT-EXACT against the oracle."""
 import numpy as np
 import pytest
@@ -36,6 +37,80 @@ def test_oracle_node_rows_restatement_matches_reference_types(oracle_mod, small_
         if n:
             keep = (r > np.float32(0.4)) & (r < np.float32(30.0) - np.float32(0.1))
             assert pa.shape[0] == keep.sum()
+
+
+def rigid_rows(rng, tilt=0.05, shift=0.3):
+    """a laser->base tf::Transform as 12 doubles [R | t] (small roll/pitch, any yaw)"""
+    r, p, y = rng.uniform(-tilt, tilt), rng.uniform(-tilt, tilt), rng.uniform(-np.pi, np.pi)
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    R = np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                  [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                  [-sp, cp * sr, cp * cr]])
+    t = rng.uniform(-shift, shift, 3)
+    return np.concatenate([R, t[:, None]], 1).reshape(12).astype(np.float64)
+
+
+def synthetic_cloud(rng, n):
+    c = np.zeros((n, 3), np.float32)
+    rad = rng.uniform(0.0, 35.0, n)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    c[:, 0], c[:, 1] = rad * np.cos(ang), rad * np.sin(ang)
+    c[:, 2] = rng.normal(0, 0.4, n)
+    if n >= 10:
+        idx = rng.choice(n, size=max(n // 10, 4), replace=False)
+        c[idx[0::4], 0] = np.nan
+        c[idx[1::4], 1] = np.inf
+        c[idx[2::4], :2] = rng.uniform(-0.7, 0.7, (len(idx[2::4]), 2))  # the x<0 && d2<0.5 rule
+        c[idx[3::4], 2] = rng.choice([-1.0, 1.0, 2.5, -3.0], len(idx[3::4]))  # exactly on / beyond the z gate
+    return c
+
+
+def numpy_point_cloud_to_container(c, T, smin, smax, zmin, zmax, scale):
+    """independent vectorised statement of HectorMappingRos.cpp:509-542 (float gates, double tf)"""
+    c = c.astype(np.float32)
+    T = T.reshape(3, 4)
+    with np.errstate(invalid="ignore", over="ignore"):
+        d2 = c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]
+        keep = (d2 > np.float32(smin)) & (d2 < np.float32(smax)) & ~((c[:, 0] < 0) & (d2 < np.float32(0.5)))
+        v = c.astype(np.float64)
+        b = ((T[:, 0] * v[:, 0:1] + T[:, 1] * v[:, 1:2]) + T[:, 2] * v[:, 2:3]) + T[:, 3]
+        zl = (b[:, 2] - T[2, 3]).astype(np.float32)
+        keep &= (zl > np.float32(zmin)) & (zl < np.float32(zmax))
+        out = b[keep, :2].astype(np.float32) * np.float32(scale)
+    return out, (T[:2, 3].astype(np.float32) * np.float32(scale))
+
+
+def test_oracle_point_cloud_restatement_is_pinned(oracle_mod):
+    """CPU: ho == hr == an independent numpy statement of :509-542; identity tf + flat cloud + open gates
+    reproduces the cloud; projectLaser + cloud ingestion agrees with the LaserScan ingestion (:483-507) to
+    float rounding (double vs float trig)"""
+    kinds = [k for k in ("ho", "hr") if oracle_mod.available(k)]
+    os_ = [oracle_mod.Oracle(k, 0.05, 64, 64, 1) for k in kinds]
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 10, 1081, 5000):
+        c = synthetic_cloud(rng, n)
+        T = rigid_rows(rng)
+        want, worigo = numpy_point_cloud_to_container(c, T, 0.16, 900.0, -1.0, 1.0, 20.0)
+        for o in os_:
+            got, origo = o.point_cloud_to_container(c, T, 0.16, 900.0, -1.0, 1.0, 20.0)
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), n
+            assert np.array_equal(bits(origo), bits(worigo))
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    c = synthetic_cloud(rng, 300)
+    c[:, 2] = 0
+    c = c[np.isfinite(c).all(1)]
+    got, origo = os_[0].point_cloud_to_container(c, ident, -1.0, 1e9, -1.0, 1.0, 1.0)
+    sel = ~((c[:, 0] < 0) & (c[:, 0] ** 2 + c[:, 1] ** 2 < 0.5))
+    assert np.array_equal(bits(got), bits(c[sel, :2])) and not origo.any()
+    r = rng.uniform(0.8, 29.0, 1081).astype(np.float32)  # beyond the x<0 && d2<0.5 rule
+    a0, inc = -2.35619449, 0.00436332
+    cloud = os_[0].project_laser(r, a0, inc, 0.1, 30.0, 30.0)
+    assert cloud.shape == (1081, 3) and not cloud[:, 2].any()
+    via_cloud, _ = os_[0].point_cloud_to_container(cloud, ident, 0.16, 900.0, -1.0, 1.0, 20.0)
+    direct = os_[0].laser_scan_to_container(r, a0, inc, 0.4, 30.1, 20.0)
+    assert via_cloud.shape == direct.shape and np.abs(via_cloud - direct).max() < 2e-2  # running fp32 angle drifts
+    for o in os_:
+        assert np.array_equal(bits(o.project_laser(r, a0, inc, 0.1, 30.0, -1.0)), bits(cloud))
 
 
 @pytest.fixture(scope="module")
@@ -99,6 +174,80 @@ def test_ingested_scan_drives_match_and_update_identically(capi, oracle_mod, pyr
         la, lb = a.download_level(lvl), b.download_level(lvl)
         assert (la[0] != 0).sum() > 500
         assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1])
+
+
+@pytest.mark.gpu
+def test_ingest_point_cloud_bit_exact(capi, oracle_mod, pyramid_scene):
+    """rosPointCloudToDataContainer (+ fused projectLaser) on the device == the restatement, bit for bit"""
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    rng = np.random.default_rng(21)
+    s = g.getScaleToMap()
+    gates = (np.float32(0.4 * 0.4), np.float32(30.0 * 30.0), -1.0, 1.0)  # the node's defaults (:98-108)
+    for n in (0, 1, 63, 64, 65, 1023, 1024, 1025, 1081, 16384):
+        for trial in range(2):
+            c, T = synthetic_cloud(rng, n), rigid_rows(rng)
+            got, go = g.ingest_point_cloud(c, T, *gates)
+            ref, ro = o.point_cloud_to_container(c, T, *gates, s)
+            assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (n, trial)
+            assert np.array_equal(bits(go), bits(ro))
+            if n >= 1000:
+                assert 0.3 * n < ref.shape[0] < n
+    for a0, inc, n in [(-2.35619449, 0.00436332, 1081), (-3.1415927, 0.00038349519, 16384), (0.3, -0.01, 700)]:
+        for cutoff in (30.0, -1.0, 12.5):
+            r, T = synthetic_ranges(rng, n), rigid_rows(rng)
+            got, go = g.ingest_laser_scan_tf(r, a0, inc, 0.1, 30.0, cutoff, T, *gates)
+            cloud = o.project_laser(r, a0, inc, 0.1, 30.0, cutoff)
+            ref, ro = o.point_cloud_to_container(cloud, T, *gates, s)
+            assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (n, cutoff)
+            assert np.array_equal(bits(go), bits(ro)) and ref.shape[0] > n // 4
+    # alternating entries share the geometry-table cache: the float2 and double2 tables must not be confused
+    r = synthetic_ranges(rng, 1081)
+    T = rigid_rows(rng)
+    for _ in range(2):
+        a = g.ingest_laser_scan(r, -2.35619449, 0.00436332, 0.4, 30.0)
+        assert np.array_equal(bits(a), bits(o.laser_scan_to_container(r, -2.35619449, 0.00436332, 0.4, 30.0, s)))
+        b, _o = g.ingest_laser_scan_tf(r, -2.35619449, 0.00436332, 0.1, 30.0, 30.0, T, *gates)
+        cloud = o.project_laser(r, -2.35619449, 0.00436332, 0.1, 30.0, 30.0)
+        assert np.array_equal(bits(b), bits(o.point_cloud_to_container(cloud, T, *gates, s)[0]))
+
+
+@pytest.mark.gpu
+def test_ingested_cloud_keeps_its_origo_through_match_and_update(capi, oracle_mod, pyramid_scene):
+    """tf path: the container's origo is the laser position (:517); the device-resident container updates the
+    map exactly like updateByScan fed with the host endpoints + that origo, and like the oracle"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    a = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    b = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    o = oracle_mod.Oracle("ho", sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    for m in (a, b, o):
+        (m.setUpdateFactorFree if hasattr(m, "setUpdateFactorFree") else m.set_update_factor_free)(0.4)
+        (m.setUpdateFactorOccupied if hasattr(m, "setUpdateFactorOccupied") else m.set_update_factor_occupied)(0.9)
+    ang = synth.beam_angles(1081)
+    a0, inc = float(ang[0]), float(np.float32(synth.SCAN_SHAPES[1081][1]))
+    T = np.array([1, 0, 0, 0.12, 0, 1, 0, -0.05, 0, 0, 1, 0.3], np.float64)  # laser 12 cm ahead of base_link
+    gates = (np.float32(0.16), np.float32(900.0), -1.0, 1.0)
+    rng = np.random.default_rng(5)
+    for t in range(10):
+        r = sc.world.raycast(sc.build_poses[t], ang).astype(np.float32)
+        r = (r + rng.normal(0, 0.01, r.shape)).astype(np.float32)
+        pts, origo = a.ingest_laser_scan_tf(r, a0, inc, 0.1, 30.0, 30.0, T, *gates)
+        assert pts.shape[0] > 900 and origo[0] != 0
+        pa, ca = a.match_ingested(sc.build_poses[t])
+        pb, cb = b.matchData(sc.build_poses[t], pts, origo=origo)
+        assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(ca), bits(cb))
+        o.match(sc.build_poses[t], pts, origo)  # retains the coarse containers like the reference
+        a.update_by_ingested(sc.build_poses[t])
+        b.updateByScan(pts, sc.build_poses[t], origo=origo)
+        o.update_by_scan(sc.build_poses[t], pts, origo)
+        o.on_map_updated()
+    for lvl in range(sc.levels):
+        la, lb, lo = a.download_level(lvl), b.download_level(lvl), o.download_level(lvl)
+        assert (la[0] != 0).sum() > 500
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1])
+        assert np.array_equal(bits(la[0]), bits(lo[0])) and np.array_equal(la[1], lo[1])
 
 
 @pytest.mark.gpu
