@@ -66,6 +66,8 @@ SIGNATURES = {
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
     "hsm_ray_distances": (_i, [_vp, _i, _f, _f, _f, _i, _f32p, _f32p, _f32p, _f32p]),
     "hsm_likelihood_states": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p]),
+    "hsm_residual_states": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p]),
+    "hsm_covariance_for_poses": (_i, [_vp, _i, _i, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
     "hsm_group_create": (_i, [_f, _i, _i, C.c_uint, _f, _f, _i32p, _i, C.POINTER(_vp)]),
     "hsm_group_destroy": (None, [_vp]),
     "hsm_group_size": (_i, [_vp]),
@@ -306,6 +308,26 @@ class MapRepMultiMap:
         _check(self._lib.hsm_likelihood_states(self._h, level, st.shape[0], st.reshape(-1), p, n, out),
                "hsm_likelihood_states")
         return out
+
+    def residual_states(self, level, states_map, pts):
+        """OccGridMapUtil::getResidualForState for a batch of map-frame states"""
+        st = np.ascontiguousarray(states_map, np.float32).reshape(-1, 3)
+        a, p, n = _pts(pts)
+        out = np.empty(st.shape[0], np.float32)
+        _check(self._lib.hsm_residual_states(self._h, level, st.shape[0], st.reshape(-1), p, n, out),
+               "hsm_residual_states")
+        return out
+
+    def covariance_for_poses(self, level, poses_map, pts):
+        """OccGridMapUtil::getCovarianceForPose + getCovMatrixWorldCoords for a batch of map-frame poses
+        -> (cov_map [B,9], cov_world [B,9], likelihoods [B,7]); matrices column major"""
+        st = np.ascontiguousarray(poses_map, np.float32).reshape(-1, 3)
+        a, p, n = _pts(pts)
+        B = st.shape[0]
+        cm, cw, lh = (np.zeros((B, 9), np.float32), np.zeros((B, 9), np.float32), np.zeros((B, 7), np.float32))
+        _check(self._lib.hsm_covariance_for_poses(self._h, level, B, st.reshape(-1), p, n, cm.reshape(-1),
+                                                  cw.reshape(-1), lh.reshape(-1)), "hsm_covariance_for_poses")
+        return cm, cw, lh
 
     def map_metadata(self, level=0):
         """(origin_x, origin_y, resolution) as HectorMappingRos::setServiceGetMapData publishes them (:546-553)"""

@@ -793,7 +793,8 @@ __global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict
 template <int LAYOUT>
 __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, const float* __restrict__ states,
                                                          int batch, const float2* __restrict__ pts, int n,
-                                                         float pt_scale, float* __restrict__ out_lh) {
+                                                         float pt_scale, float* __restrict__ out_lh,
+                                                         float* __restrict__ out_residual) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= batch) return;
@@ -811,7 +812,83 @@ __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, cons
     residual += 1.0f - M;
   }
   residual = wave_allreduce(residual);
-  if (lane == 0) out_lh[b] = 1 - (residual / (float)n);
+  if (lane == 0) {
+    if (out_lh) out_lh[b] = 1 - (residual / (float)n);
+    if (out_residual) out_residual[b] = residual;  // getResidualForState (:205-221)
+  }
+}
+
+// OccGridMapUtil::getCovarianceForPose (HSL/map/OccGridMapUtil.h:106-160) + getCovMatrixWorldCoords
+// (:162-188): 7 sigma points around a MAP-frame pose (+-1.5 cells, +-0.05 rad, the pose itself), their
+// likelihoods weight a sample mean and a 3x3 sample covariance.  One workgroup per pose, wave w scores
+// sigma point w (same sampler as above), thread 0 does the 7-term statistics in the source's order.
+template <int LAYOUT>
+__global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L, const float* __restrict__ poses,
+                                                              int batch, const float2* __restrict__ pts, int n,
+                                                              float pt_scale, float cell_length,
+                                                              float* __restrict__ out_cov_map,
+                                                              float* __restrict__ out_cov_world,
+                                                              float* __restrict__ out_lh7) {
+  __shared__ float lh[7];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const float deltaTransX = 1.5f, deltaTransY = 1.5f, deltaAng = 0.05f;
+  const float x = poses[3 * b], y = poses[3 * b + 1], ang = poses[3 * b + 2];
+  float sp[7][3] = {{x + deltaTransX, y, ang}, {x - deltaTransX, y, ang}, {x, y + deltaTransY, ang},
+                    {x, y - deltaTransY, ang}, {x, y, ang + deltaAng},    {x, y, ang - deltaAng}, {x, y, ang}};
+  {
+    float ex = sp[0][0], ey = sp[0][1], ea = sp[0][2];
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+      if (w == k) ex = sp[k][0], ey = sp[k][1], ea = sp[k][2];
+    float sinRot, cosRot;
+    sincos_f32(ea, sinRot, cosRot);
+    const LevelRegs R = level_regs<LAYOUT>(L);
+    const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+    float residual = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+      const float2 p = pts[i];
+      BeamRot r;
+      const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+      const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+      residual += 1.0f - M;
+    }
+    residual = wave_allreduce(residual);
+    if (lane == 0) lh[w] = 1 - (residual / (float)n);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // likelihoods.sum(): fixed-size 7-vector, unrolled halves (0..2) + (3..6)
+  const float sum = ((lh[0] + (lh[1] + lh[2])) + ((lh[3] + lh[4]) + (lh[5] + lh[6])));
+  const float invLhNormalizer = 1 / sum;
+  float mean[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < 7; ++i)
+    for (int r = 0; r < 3; ++r) mean[r] += sp[i][r] * lh[i];
+  for (int r = 0; r < 3; ++r) mean[r] *= invLhNormalizer;
+  float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // column major
+  for (int i = 0; i < 7; ++i) {
+    const float d[3] = {sp[i][0] - mean[0], sp[i][1] - mean[1], sp[i][2] - mean[2]};
+    const float wgt = lh[i] * invLhNormalizer;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) cov[c * 3 + r] += wgt * (d[r] * d[c]);
+  }
+  if (out_lh7)
+    for (int i = 0; i < 7; ++i) out_lh7[7 * b + i] = lh[i];
+  if (out_cov_map)
+    for (int i = 0; i < 9; ++i) out_cov_map[9 * b + i] = cov[i];
+  if (out_cov_world) {
+    const float scaleTrans = cell_length, scaleTransSq = scaleTrans * scaleTrans;
+    float* W = out_cov_world + 9 * b;  // (r,c) at c*3+r
+    W[0] = cov[0] * scaleTransSq;
+    W[4] = cov[4] * scaleTransSq;
+    W[1] = cov[1] * scaleTransSq;  // (1,0)
+    W[3] = W[1];
+    W[2] = cov[2] * scaleTrans;  // (2,0)
+    W[6] = W[2];
+    W[5] = cov[5] * scaleTrans;  // (2,1)
+    W[7] = W[5];
+    W[8] = cov[8];
+  }
 }
 
 // device sin/cos sweep for the parity tests

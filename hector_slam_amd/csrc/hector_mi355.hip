@@ -1092,38 +1092,92 @@ int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]) {
   return update_impl(h, pose_world, hp, h->ingest_n, h->ingest_origo, h->d_ingest);
 }
 
-int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
-                          float* out_lh) {
+static int ensure_batch_bytes(hsm_ctx* h, size_t need) {
+  if (need <= h->d_batch_cap) return HSM_OK;
+  if (h->d_batch) HIP_TRY(hipFree(h->d_batch));
+  h->d_batch = nullptr;
+  h->d_batch_cap = 0;
+  HIP_TRY(hipMalloc(&h->d_batch, need));
+  h->d_batch_cap = need;
+  return HSM_OK;
+}
+
+static int score_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                        float* out_lh, float* out_residual, const char* who) {
   if (int rc = valid_level(h, level)) return rc;
-  if (batch < 0 || n < 0 || (batch > 0 && (!states_map || !out_lh)) || (n > 0 && !pts_xy))
-    return fail(HSM_ERR_INVALID, "hsm_likelihood_states: bad argument");
+  if (batch < 0 || n < 0 || (batch > 0 && (!states_map || !(out_lh || out_residual))) || (n > 0 && !pts_xy))
+    return fail(HSM_ERR_INVALID, who);
   if (batch == 0) return HSM_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
   if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
   if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-  const size_t need = (size_t)batch * 4 * sizeof(float);
-  if (need > h->d_batch_cap) {
-    if (h->d_batch) HIP_TRY(hipFree(h->d_batch));
-    h->d_batch = nullptr;
-    h->d_batch_cap = 0;
-    HIP_TRY(hipMalloc(&h->d_batch, need));
-    h->d_batch_cap = need;
-  }
+  if (int rc = ensure_batch_bytes(h, (size_t)batch * 5 * sizeof(float))) return rc;
   float* d_states = (float*)h->d_batch;
-  float* d_out = d_states + 3 * (size_t)batch;
+  float* d_lh = d_states + 3 * (size_t)batch;
+  float* d_res = d_lh + (size_t)batch;
   HIP_TRY(hipMemcpyAsync(d_states, states_map, (size_t)batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const float factor = (float)(1.0 / pow(2.0, (double)level));
   const LevelView v = level_view(h->levels[level], factor, 1);
   const int grid = (batch + 3) / 4;
   if (h->layout == kLayoutPlane)
     hipLaunchKernelGGL((likelihood_kernel<kLayoutPlane>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
-                       n, factor, d_out);
+                       n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr);
   else
     hipLaunchKernelGGL((likelihood_kernel<kLayoutQuad>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
-                       n, factor, d_out);
+                       n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out_lh, d_out, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (out_lh) HIP_TRY(hipMemcpyAsync(out_lh, d_lh, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (out_residual)
+    HIP_TRY(hipMemcpyAsync(out_residual, d_res, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                          float* out_lh) {
+  return score_states(h, level, batch, states_map, pts_xy, n, out_lh, nullptr, "hsm_likelihood_states: bad argument");
+}
+
+int hsm_residual_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                        float* out_residual) {
+  return score_states(h, level, batch, states_map, pts_xy, n, nullptr, out_residual,
+                      "hsm_residual_states: bad argument");
+}
+
+int hsm_covariance_for_poses(hsm_ctx* h, int level, int batch, const float* poses_map, const float* pts_xy, int n,
+                             float* out_cov_map, float* out_cov_world, float* out_lh7) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (batch < 0 || n < 0 || (batch > 0 && (!poses_map || !(out_cov_map || out_cov_world || out_lh7))) ||
+      (n > 0 && !pts_xy))
+    return fail(HSM_ERR_INVALID, "hsm_covariance_for_poses: bad argument");
+  if (batch == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+  if (int rc = ensure_batch_bytes(h, (size_t)batch * (3 + 9 + 9 + 7) * sizeof(float))) return rc;
+  float* d_poses = (float*)h->d_batch;
+  float* d_map = d_poses + 3 * (size_t)batch;
+  float* d_world = d_map + 9 * (size_t)batch;
+  float* d_lh7 = d_world + 9 * (size_t)batch;
+  HIP_TRY(hipMemcpyAsync(d_poses, poses_map, (size_t)batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const float factor = (float)(1.0 / pow(2.0, (double)level));
+  const Level& Lv = h->levels[level];
+  const LevelView v = level_view(Lv, factor, 1);
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((pose_covariance_kernel<kLayoutPlane>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch,
+                       h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7);
+  else
+    hipLaunchKernelGGL((pose_covariance_kernel<kLayoutQuad>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch,
+                       h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7);
+  HIP_TRY(hipGetLastError());
+  if (out_cov_map)
+    HIP_TRY(hipMemcpyAsync(out_cov_map, d_map, (size_t)batch * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (out_cov_world)
+    HIP_TRY(hipMemcpyAsync(out_cov_world, d_world, (size_t)batch * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (out_lh7)
+    HIP_TRY(hipMemcpyAsync(out_lh7, d_lh7, (size_t)batch * 7 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }

@@ -213,6 +213,18 @@ int hsm_update_by_ingested(hsm_ctx* h, const float pose_world[3]);
  * Host pointers. */
 int hsm_likelihood_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
                           float* out_lh);
+/* replaces: OccGridMapUtil::getResidualForState (HSL/map/OccGridMapUtil.h:205-221): out_residual[b] =
+ * sum_i (1 - M_i), same arguments as hsm_likelihood_states. */
+int hsm_residual_states(hsm_ctx* h, int level, int batch, const float* states_map, const float* pts_xy, int n,
+                        float* out_residual);
+/* replaces: OccGridMapUtil::getCovarianceForPose (HSL/map/OccGridMapUtil.h:106-160) and
+ * getCovMatrixWorldCoords (:162-188) for `batch` MAP-frame poses of `level`: seven sigma points per pose
+ * (x +- 1.5 cells, y +- 1.5 cells, angle +- 0.05 rad, the pose), likelihood-weighted sample covariance.
+ * out_cov_map / out_cov_world: batch x 9 floats, column major; out_lh7: batch x 7 likelihoods in the
+ * reference's sigma-point order.  Any of the three may be NULL.  (The reference prints the likelihoods to
+ * stdout on every call, :136; this entry does not.) */
+int hsm_covariance_for_poses(hsm_ctx* h, int level, int batch, const float* poses_map, const float* pts_xy, int n,
+                             float* out_cov_map, float* out_cov_world, float* out_lh7);
 /* replaces: hectormaptools::DistanceMeasurementProvider::getDist (hector_map_tools/include/hector_map_tools/
  * HectorMapTools.h:133-234, behind hector_map_server's services) for `n` rays on `level`, with the
  * OccupancyGrid metadata the node publishes (origin = getWorldCoords(0,0) - cell/2, resolution = cell length,

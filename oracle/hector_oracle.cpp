@@ -652,6 +652,70 @@ void ho_likelihood_states(void* h, int level, int batch, const float* states, co
   }
 }
 
+// getResidualForState (OccGridMapUtil.h:205-221)
+static float residual_for_state(Level& L, const float st[3], const float* pts, int n) {
+  const Affine2 T = pose_transform(st[0], st[1], st[2]);
+  float residual = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    float tx, ty;
+    affine_apply(T, pts[2 * i], pts[2 * i + 1], tx, ty);
+    const float funval = 1.0f - interp_map_value(L, tx, ty);
+    residual += funval;
+  }
+  return residual;
+}
+
+void ho_residual_states(void* h, int level, int batch, const float* states, const float* pts, int n, float* out) {
+  Level& L = ((Ctx*)h)->levels[level];
+  for (int b = 0; b < batch; ++b) out[b] = residual_for_state(L, states + 3 * b, pts, n);
+}
+
+// getCovarianceForPose (OccGridMapUtil.h:106-160), getCovMatrixWorldCoords (:162-188)
+void ho_covariance_for_poses(void* h, int level, int batch, const float* poses, const float* pts, int n,
+                             float* out_map, float* out_world, float* out_lh7) {
+  Level& L = ((Ctx*)h)->levels[level];
+  for (int b = 0; b < batch; ++b) {
+    const float deltaTransX = 1.5f, deltaTransY = 1.5f, deltaAng = 0.05f;
+    const float x = poses[3 * b], y = poses[3 * b + 1], ang = poses[3 * b + 2];
+    const float sp[7][3] = {{x + deltaTransX, y, ang}, {x - deltaTransX, y, ang}, {x, y + deltaTransY, ang},
+                            {x, y - deltaTransY, ang}, {x, y, ang + deltaAng},    {x, y, ang - deltaAng}, {x, y, ang}};
+    float lh[7];
+    for (int i = 0; i < 7; ++i) {
+      const float resid = residual_for_state(L, sp[i], pts, n);
+      const float sizef = (float)n;
+      lh[i] = 1 - (resid / sizef);
+    }
+    // likelihoods.sum() of a fixed 7-vector: no packet fits, completely unrolled halves (0..2) + (3..6)
+    const float sum = ((lh[0] + (lh[1] + lh[2])) + ((lh[3] + lh[4]) + (lh[5] + lh[6])));
+    const float invLhNormalizer = 1 / sum;
+    float mean[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 7; ++i)
+      for (int r = 0; r < 3; ++r) mean[r] += sp[i][r] * lh[i];
+    for (int r = 0; r < 3; ++r) mean[r] *= invLhNormalizer;
+    float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 7; ++i) {
+      const float d[3] = {sp[i][0] - mean[0], sp[i][1] - mean[1], sp[i][2] - mean[2]};
+      const float w = lh[i] * invLhNormalizer;
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) cov[c * 3 + r] += w * (d[r] * d[c]);
+    }
+    if (out_lh7) memcpy(out_lh7 + 7 * b, lh, sizeof lh);
+    if (out_map) memcpy(out_map + 9 * b, cov, sizeof cov);
+    if (out_world) {
+      const float scaleTrans = L.cellLength, scaleTransSq = scaleTrans * scaleTrans;
+      float* W = out_world + 9 * b;
+      W[0] = cov[0] * scaleTransSq;
+      W[4] = cov[4] * scaleTransSq;
+      W[1] = cov[1] * scaleTransSq;
+      W[3] = W[1];
+      W[2] = cov[2] * scaleTrans;
+      W[6] = W[2];
+      W[5] = cov[5] * scaleTrans;
+      W[7] = W[5];
+      W[8] = cov[8];
+    }
+  }
+}
 
 // f4: DistanceMeasurementProvider::getDist / checkOccupancyBresenhami / bresenham2D
 // (hector_map_tools/include/hector_map_tools/HectorMapTools.h:133-234), CoordinateTransformer :58-98

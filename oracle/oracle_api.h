@@ -92,6 +92,13 @@ void ORF(occupancy_grid)(void* h, int level, signed char* out);
  * `batch` map-frame states against one level-scaled scan: out_lh[b] = 1 - residual/size */
 void ORF(likelihood_states)(void* h, int level, int batch, const float* states_map, const float* pts_level,
                             int n, float* out_lh);
+/* f3: getResidualForState (:205-221) */
+void ORF(residual_states)(void* h, int level, int batch, const float* states_map, const float* pts_level, int n,
+                          float* out_residual);
+/* f3: getCovarianceForPose (:106-160) then getCovMatrixWorldCoords (:162-188) per map-frame pose; 9 floats
+ * column major each, 7 likelihoods in sigma-point order */
+void ORF(covariance_for_poses)(void* h, int level, int batch, const float* poses_map, const float* pts_level, int n,
+                               float* out_cov_map, float* out_cov_world, float* out_lh7);
 /* f4: hectormaptools::DistanceMeasurementProvider::getDist (hector_map_tools/include/hector_map_tools/
  * HectorMapTools.h:133-234) on an int8 occupancy grid with OccupancyGrid metadata (origin, resolution):
  * out_dist[i] = resolution * cells to the first occupied (== 100) cell on the Bresenham line, or

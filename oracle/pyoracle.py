@@ -66,6 +66,8 @@ def _load(kind: str):
         "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
         "proc_last_pose": (None, [vp, _f32p, _f32p]),
         "likelihood_states": (None, [vp, i, i, _f32p, _f32p, i, _f32p]),
+        "residual_states": (None, [vp, i, i, _f32p, _f32p, i, _f32p]),
+        "covariance_for_poses": (None, [vp, i, i, _f32p, _f32p, i, _f32p, _f32p, _f32p]),
         "ray_distances": (None, [np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS"), i, i, f, f, f, i, _f32p, _f32p,
                                  _f32p, _f32p]),
         "occupancy_grid": (None, [vp, i, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")]),
@@ -233,6 +235,25 @@ class Oracle:
         self.f["likelihood_states"](self.h, level, st.shape[0], st.reshape(-1), p.reshape(-1) if p.size else
                                     np.zeros(2, np.float32), p.shape[0], out)
         return out
+
+    def residual_states(self, level, states_map, pts_level):
+        st = np.ascontiguousarray(states_map, np.float32).reshape(-1, 3)
+        p = _pts(pts_level)
+        out = np.empty(st.shape[0], np.float32)
+        self.f["residual_states"](self.h, level, st.shape[0], st.reshape(-1), p.reshape(-1) if p.size else
+                                  np.zeros(2, np.float32), p.shape[0], out)
+        return out
+
+    def covariance_for_poses(self, level, poses_map, pts_level):
+        """-> (cov_map [B,9], cov_world [B,9], likelihoods [B,7]); column major"""
+        st = np.ascontiguousarray(poses_map, np.float32).reshape(-1, 3)
+        p = _pts(pts_level)
+        B = st.shape[0]
+        cm, cw, lh = np.zeros((B, 9), np.float32), np.zeros((B, 9), np.float32), np.zeros((B, 7), np.float32)
+        self.f["covariance_for_poses"](self.h, level, B, st.reshape(-1), p.reshape(-1) if p.size else
+                                       np.zeros(2, np.float32), p.shape[0], cm.reshape(-1), cw.reshape(-1),
+                                       lh.reshape(-1))
+        return cm, cw, lh
 
     def occupancy_grid(self, level):
         sx, sy, _, _ = self.level_info(level)

@@ -210,6 +210,34 @@ void hr_likelihood_states(void* h, int level, int batch, const float* states, co
   hectorslam::DataContainer dc = make_container(pts, n, 0);
   for (int b = 0; b < batch; ++b) out[b] = r->level(level).gridMapUtil->getLikelihoodForState(v3(states + 3 * b), dc);
 }
+void hr_residual_states(void* h, int level, int batch, const float* states, const float* pts, int n, float* out) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, 0);
+  for (int b = 0; b < batch; ++b) out[b] = r->level(level).gridMapUtil->getResidualForState(v3(states + 3 * b), dc);
+}
+// the reference's own getCovarianceForPose / getCovMatrixWorldCoords; its per-call print (:136) goes to a sink
+void hr_covariance_for_poses(void* h, int level, int batch, const float* poses, const float* pts, int n, float* out_map,
+                             float* out_world, float* out_lh7) {
+  Ref* r = (Ref*)h;
+  hectorslam::DataContainer dc = make_container(pts, n, 0);
+  std::ostringstream sink;
+  std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
+  for (int b = 0; b < batch; ++b) {
+    auto* util = r->level(level).gridMapUtil;
+    const Eigen::Vector3f p = v3(poses + 3 * b);
+    const Eigen::Matrix3f cm = util->getCovarianceForPose(p, dc);
+    const Eigen::Matrix3f cw = util->getCovMatrixWorldCoords(cm);
+    if (out_map) memcpy(out_map + 9 * b, cm.data(), 9 * sizeof(float));
+    if (out_world) memcpy(out_world + 9 * b, cw.data(), 9 * sizeof(float));
+    if (out_lh7) {
+      const float x = p[0], y = p[1], a = p[2];
+      const float sp[7][3] = {{x + 1.5f, y, a}, {x - 1.5f, y, a}, {x, y + 1.5f, a}, {x, y - 1.5f, a},
+                              {x, y, a + 0.05f}, {x, y, a - 0.05f}, {x, y, a}};
+      for (int i = 0; i < 7; ++i) out_lh7[7 * b + i] = util->getLikelihoodForState(v3(sp[i]), dc);
+    }
+  }
+  std::cout.rdbuf(old);
+}
 // f4 lives in hector_map_tools (needs nav_msgs); restatement only, same symbol set in both libraries
 void hr_ray_distances(const signed char* grid, int sx, int sy, float ox, float oy, float res, int n, const float* bw,
                       const float* ew, float* out_dist, float* out_hit) {

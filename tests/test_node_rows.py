@@ -304,6 +304,97 @@ def test_likelihood_states_matches_reference(capi, oracle_mod, pyramid_scene):
     assert g.likelihood_states(0, np.zeros((0, 3), np.float32), sc.query_scans[0]).shape == (0,)
 
 
+def sigma_statistics_f32(pose, lh):
+    """the 7-term statistics of getCovarianceForPose (:138-154) in scalar fp32, source order"""
+    F = np.float32
+    x, y, a = (F(v) for v in pose)
+    sp = [[x + F(1.5), y, a], [x - F(1.5), y, a], [x, y + F(1.5), a], [x, y - F(1.5), a], [x, y, a + F(0.05)],
+          [x, y, a - F(0.05)], [x, y, a]]
+    lh = [F(v) for v in lh]
+    inv = F(1) / ((lh[0] + (lh[1] + lh[2])) + ((lh[3] + lh[4]) + (lh[5] + lh[6])))
+    mean = [F(0)] * 3
+    for i in range(7):
+        for r in range(3):
+            mean[r] = mean[r] + sp[i][r] * lh[i]
+    mean = [m * inv for m in mean]
+    cov = np.zeros(9, np.float32)
+    for i in range(7):
+        d = [sp[i][r] - mean[r] for r in range(3)]
+        w = lh[i] * inv
+        for c in range(3):
+            for r in range(3):
+                cov[c * 3 + r] = cov[c * 3 + r] + w * (d[r] * d[c])
+    return cov
+
+
+def test_oracle_pose_covariance_restatement_vs_reference(oracle_mod, small_scene):
+    """CPU: the restatement of getResidualForState / getCovarianceForPose / getCovMatrixWorldCoords against the
+    reference's own functions (hr): likelihoods and residuals bit-identical, covariances to 2 ulp-ish (Eigen
+    may associate scalar * (d d^T) either way), symmetric, positive semi-definite, world = map scaled"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref not built")
+    sc = small_scene
+    a, b = make_oracle(oracle_mod, "ho", sc), make_oracle(oracle_mod, "hr", sc)
+    poses = np.stack([a.map_coords_pose(0, sc.query_truth[q]) for q in range(6)]).astype(np.float32)
+    poses[3:] += np.float32([0.7, -0.4, 0.02])
+    for q in range(3):
+        ra, rb = (o.residual_states(0, poses, sc.query_scans[q]) for o in (a, b))
+        assert np.array_equal(bits(ra), bits(rb)) and (ra > 0).all()
+        (ma, wa, la), (mb, wb, lb) = (o.covariance_for_poses(0, poses, sc.query_scans[q]) for o in (a, b))
+        assert np.array_equal(bits(la), bits(lb))
+        assert np.allclose(ma, mb, rtol=1e-5, atol=1e-7) and np.allclose(wa, wb, rtol=1e-5, atol=1e-9)
+        for i in range(poses.shape[0]):
+            assert np.array_equal(bits(ma[i]), bits(sigma_statistics_f32(poses[i], la[i])))
+            M = ma[i].reshape(3, 3)
+            assert np.array_equal(M, M.T) and np.linalg.eigvalsh(M.astype(np.float64)).min() > -1e-6
+            assert 0.3 < M[0, 0] < 2.25 and 0.3 < M[1, 1] < 2.25 and 1e-4 < M[2, 2] < 0.0025
+        c = np.float32(sc.resolution)
+        assert np.array_equal(bits(wa[:, 0]), bits(ma[:, 0] * (c * c))) and np.array_equal(bits(wa[:, 8]), bits(ma[:, 8]))
+        assert np.array_equal(bits(wa[:, 2]), bits(ma[:, 2] * c)) and np.array_equal(bits(wa[:, 6]), bits(wa[:, 2]))
+
+
+@pytest.mark.gpu
+def test_pose_covariance_and_residual_match_reference(capi, oracle_mod, pyramid_scene):
+    """f3: getResidualForState and getCovarianceForPose (+ world scaling) for batches of poses on every level.
+    The 7 likelihoods differ from the reference only by summation order (<= 1e-5); the 7-term statistics on
+    top of them are bit-exact (checked by feeding the device's own likelihoods to a scalar fp32 restatement),
+    so the covariances agree to the propagated 1e-5."""
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    kinds = ["ho"] + (["hr"] if oracle_mod.available("hr") else [])
+    orc = {k: make_oracle(oracle_mod, k, sc) for k in kinds}
+    rng = np.random.default_rng(19)
+    for lvl in range(sc.levels):
+        f = np.float32(1.0 / 2 ** lvl)
+        cell = np.float32(g.level_info(lvl)[2])
+        for q in range(3):
+            pm = orc["ho"].map_coords_pose(lvl, sc.query_truth[q])
+            poses = (pm[None, :] + rng.normal(0, [1.0, 1.0, 0.03], (33, 3))).astype(np.float32)
+            poses[0] = pm
+            cm, cw, lh = g.covariance_for_poses(lvl, poses, sc.query_scans[q])
+            res = g.residual_states(lvl, poses, sc.query_scans[q])
+            n = sc.query_scans[q].shape[0]
+            for i in range(poses.shape[0]):
+                assert np.array_equal(bits(cm[i]), bits(sigma_statistics_f32(poses[i], lh[i]))), (lvl, q, i)
+            assert np.array_equal(bits(cw[:, 0]), bits(cm[:, 0] * (cell * cell)))
+            assert np.array_equal(bits(cw[:, 5]), bits(cm[:, 5] * cell)) and np.array_equal(bits(cw[:, 7]), bits(cw[:, 5]))
+            assert np.array_equal(bits(cw[:, 3]), bits(cw[:, 1])) and np.array_equal(bits(cw[:, 8]), bits(cm[:, 8]))
+            assert np.array_equal(bits(lh[:, 6]), bits(g.likelihood_states(lvl, poses, sc.query_scans[q])))
+            for k in kinds:
+                rm, rw, rl = orc[k].covariance_for_poses(lvl, poses, sc.query_scans[q] * f)
+                rr = orc[k].residual_states(lvl, poses, sc.query_scans[q] * f)
+                assert np.abs(lh - rl).max() <= 1e-5, (lvl, q, k)
+                assert np.abs(res - rr).max() <= 1e-5 * n, (lvl, q, k, np.abs(res - rr).max())
+                assert np.abs(cm - rm).max() <= 5e-5 and np.abs(cw - rw).max() <= 5e-5, (lvl, q, k, np.abs(cm - rm).max())
+    cm, cw, lh = g.covariance_for_poses(0, np.zeros((0, 3), np.float32), sc.query_scans[0])
+    assert cm.shape == (0, 9)
+    with pytest.raises(capi.HsmError):
+        g.covariance_for_poses(sc.levels, np.zeros((1, 3), np.float32), sc.query_scans[0])
+
+
 @pytest.mark.gpu
 def test_ray_distances_bit_exact(capi, oracle_mod, pyramid_scene):
     """f4: hector_map_tools' getDist on 20k random rays per level: distances and hit coordinates bit-exact
