@@ -222,25 +222,29 @@ def extra_workload(name: str, args, local_rank: int):
             m.matchData(allp[k], alls[k])      # retains the coarse-level containers (result unused)
             m.updateByScan(alls[k], allp[k])
             m.onMapUpdated()
-        t_match = t_upd = 0.0
         pose = poses[0]
         gpu_poses = []
         for t in range(1, T + 1):
             if t == args.warmup + 1:
-                torch.cuda.synchronize()
-                t_match = t_upd = 0.0
+                m.synchronize()
                 t0 = time.perf_counter()
             hint = pose + (poses[t] - poses[t - 1])
-            a = time.perf_counter()
             pose, _ = m.matchData(hint, scans[t])
-            b = time.perf_counter()
-            m.updateByScan(scans[t], pose)
+            m.updateByScan(scans[t], pose)     # returns when queued; the next matchData waits behind it
             m.onMapUpdated()
-            c = time.perf_counter()
-            t_match += b - a
-            t_upd += c - b
             gpu_poses.append(pose)
+        m.synchronize()  # the last update is only queued when updateByScan returns
         dt = time.perf_counter() - t0
+        # attribution: matchData alone on the finished map (device idle before each call); the update's share
+        # of a step is the rest
+        tm = []
+        for t in range(max(1, T - 9), T + 1):
+            m.synchronize()
+            a = time.perf_counter()
+            m.matchData(gpu_poses[t - 1], scans[t])
+            tm.append(time.perf_counter() - a)
+        t_match = float(np.median(tm)) * args.steps
+        t_upd = dt - t_match
         nb = float(np.mean([s_.shape[0] for s_ in scans[1:]]))
         out.update({"value": args.steps * its / dt, "ms_per_step": dt / args.steps * 1e3,
                     "config": {"workload": f"configs[4] (one replica): dense {beams}-beam scans (mean {nb:.0f} valid), "
@@ -309,15 +313,34 @@ def extra_workload(name: str, args, local_rank: int):
         m2 = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
         m2.setUpdateFactorFree(0.4)
         m2.setUpdateFactorOccupied(0.9)
-        ulat = []
-        for k in range(min(args.steps, 400) + 10):
+        # updateByScan returns once its kernels are queued; the next call on the context waits behind them.
+        # "call" = host time of updateByScan + onMapUpdated, "complete" = the same + hsm_synchronize,
+        # "cycle" = one full HectorSlamProcessor::update (matchData + updateByScan + onMapUpdated) back to back
+        ulat, ucomp, cyc = [], [], []
+        nrep = min(args.steps, 400) + 10
+        for k in range(nrep):
             q = k % len(build_scans)
             m2.matchData(build_poses[q], build_scans[q])
             a = time.perf_counter()
             m2.updateByScan(build_scans[q], build_poses[q])
             m2.onMapUpdated()
-            ulat.append(time.perf_counter() - a)
-        out["update_latency_us"] = {"median": float(np.median(ulat[10:])) * 1e6, "p90": float(np.percentile(ulat[10:], 90)) * 1e6}
+            b = time.perf_counter()
+            m2.synchronize()
+            ulat.append(b - a)
+            ucomp.append(time.perf_counter() - a)
+        m2.synchronize()
+        for k in range(nrep):
+            q = k % len(build_scans)
+            a = time.perf_counter()
+            m2.matchData(build_poses[q], build_scans[q])
+            m2.updateByScan(build_scans[q], build_poses[q])
+            m2.onMapUpdated()
+            cyc.append(time.perf_counter() - a)
+        m2.synchronize()
+        stat = lambda v: {"median": float(np.median(v[10:])) * 1e6, "p90": float(np.percentile(v[10:], 90)) * 1e6}
+        out["update_latency_us"] = stat(ulat)
+        out["update_complete_us"] = stat(ucomp)
+        out["slam_cycle_us"] = stat(cyc)
         out.update({"value": its / float(np.median(lat)), "ms_per_step": float(np.median(lat)) * 1e3,
                     "config": {"workload": f"configs[1]: ONE {beams}-beam scan, {levels}-level {size}/{size // 2}/{size // 4} "
                                            f"pyramid, hsm_match host call (H2D + 1 launch + D2H), median of {args.steps}",

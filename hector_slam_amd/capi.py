@@ -61,6 +61,7 @@ SIGNATURES = {
     "hsm_ingest_point_cloud": (_i, [_vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _vp, C.POINTER(_i), _vp]),
     "hsm_ingest_laser_scan_tf": (_i, [_vp, _vp, _i, _f, _f, _f, _f, C.c_double, _vp, _f, _f, _f, _f, _f, _vp,
                                       C.POINTER(_i), _vp]),
+    "hsm_synchronize": (_i, [_vp]),
     "hsm_match_ingested": (_i, [_vp, _f32p, _f32p, _f32p]),
     "hsm_update_by_ingested": (_i, [_vp, _f32p]),
     "hsm_occupancy_grid": (_i, [_vp, _i, _vp]),
@@ -190,6 +191,10 @@ class MapRepMultiMap:
         a, p, n = _pts(dataContainer)
         _check(self._lib.hsm_update_by_scan(self._h, _v(robotPoseWorld, 3), p, n, _v(origo, 2)),
                "hsm_update_by_scan")
+
+    def synchronize(self):
+        """wait for queued device work (updateByScan returns once its kernels are queued)"""
+        _check(self._lib.hsm_synchronize(self._h), "hsm_synchronize")
 
     # ---- GridMap accessors (host mirror support) ---------------------------------------
     def level_info(self, level: int):

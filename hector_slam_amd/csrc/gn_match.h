@@ -91,7 +91,14 @@ struct MatchParams {
   float* out_cov;            // [B*9] or nullptr
   float* trace;              // nullptr, or [steps*12] per-GN-step record of scan 0 (draw/debug hooks):
                              // {map-frame estimate after the step [3], H of that step [9] col-major}
+  unsigned* done_flag;       // nullptr, or a host-visible word that receives done_seq (system-scope release)
+  unsigned done_seq;         // after the single-scan results are written: the host polls it instead of
+                             // waiting for the end-of-kernel signal
 };
+
+__device__ __forceinline__ void publish_done(const MatchParams& P) {
+  if (P.done_flag) __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Texel address of cell (x, y) in the quad plane.
 // HSM_QUAD_TILE == 0 (default): row major, index = y*sizeX + x like the reference's grid -- one
@@ -491,6 +498,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       P.out_pose[3 * scan + 0] = pw0;
       P.out_pose[3 * scan + 1] = pw1;
       P.out_pose[3 * scan + 2] = pw2;
+      if (scan == 0) publish_done(P);
     }
     return;
   }
@@ -625,6 +633,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
     }
+    if (scan == 0) publish_done(P);
   }
 }
 
@@ -729,6 +738,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
     }
+    publish_done(P);
   }
 }
 

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -48,6 +50,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // d_small / h_small layout (floats): [0,3) begin pose | [3,6) out pose | [6,15) out cov |
 // [16,28) eval H,dTr | [kTraceOff, kTraceOff + 12 * max steps) per-step trace
 constexpr int kTraceOff = 64;
+constexpr int kDoneFlagOff = 32;  // one word of the pinned block: single-scan completion sequence number
 constexpr int kMaxTraceSteps = 6 + 4 * (HSM_MAX_LEVELS - 1);
 constexpr int kSmallFloats = kTraceOff + 12 * kMaxTraceSteps;
 
@@ -88,6 +91,18 @@ struct hsm_ctx {
   int device = 0;
   int layout = kLayoutQuad;
   int wps_override = 0;
+  // updateByScan returns when its kernels are QUEUED (env HSM_ASYNC_UPDATE=0: wait for them): everything
+  // that reads the map afterwards is ordered behind them on `stream`.  Host endpoints are staged in one of
+  // two pinned blocks, each guarded by the event of the update that last read it.
+  bool async_update = true;
+  int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
+  float2* h_upd_pinned[2] = {nullptr, nullptr};
+  size_t h_upd_cap[2] = {0, 0};
+  hipEvent_t upd_evt[2] = {nullptr, nullptr};
+  bool upd_busy[2] = {false, false};
+  int upd_slot = 0;
+  bool spin_wait = true;       // single-scan matches: poll the kernel's completion word (env HSM_SPIN_WAIT=0: off)
+  unsigned done_seq = 0;
   std::vector<Level> levels;
   std::mutex mu;
   hipStream_t stream = nullptr;
@@ -486,6 +501,9 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   h->wps_override = wps;
   if (const char* env = getenv("HSM_BPL")) h->bpl_override = atoi(env) == 0 ? 0 : -1;
   if (const char* env = getenv("HSM_COOP_MIN")) h->coop_min_beams = atoi(env);
+  if (const char* env = getenv("HSM_SPIN_WAIT")) h->spin_wait = atoi(env) != 0;
+  if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
+  if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -501,7 +519,9 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
   CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 9 * sizeof(float)));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float), hipHostMallocMapped));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float),
+                           hipHostMallocMapped | hipHostMallocCoherent));
+  memset(h->h_small, 0, kSmallFloats * sizeof(float));
 
   // MapRepMultiMap ctor (MapRepMultiMap.h:48-72)
   int rx = size_x, ry = size_y;
@@ -570,6 +590,10 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_occ);
   if (h->h_scan_pinned) (void)hipHostFree(h->h_scan_pinned);
   if (h->h_small) (void)hipHostFree(h->h_small);
+  for (int k = 0; k < 2; ++k) {
+    if (h->h_upd_pinned[k]) (void)hipHostFree(h->h_upd_pinned[k]);
+    if (h->upd_evt[k]) (void)hipEventDestroy(h->upd_evt[k]);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -704,6 +728,29 @@ constexpr int kMaxRegisterResidentBeams = 16 * 64 * 17;
 // mapped host memory), level-0 units.  Latency path of the ROS node: ONE kernel launch and one stream
 // synchronise -- the start estimate travels in the kernel arguments and the kernel writes pose, H and
 // the optional hook trace straight into the pinned h_small block.
+// Completion of a single-scan match.  The kernel's last act is a system-scope release store of `seq` into
+// the pinned result block, AFTER pose / cov / trace: polling that word returns the results a few
+// microseconds before the end-of-kernel signal would (the queue's completion interrupt path is most of
+// what hipStreamSynchronize waits for on a 25 us kernel).  Bounded: after 2 ms without the word the normal
+// stream synchronisation takes over, which also surfaces a faulted kernel.  Later work on the stream
+// stays ordered behind the kernel as usual.
+static int wait_single_scan(hsm_ctx* h, unsigned seq) {
+  if (h->spin_wait) {
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(h->h_small + kDoneFlagOff);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1;; ++it) {
+      if (*flag == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return HSM_OK;
+      }
+      __builtin_ia32_pause();
+      if ((it & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
 static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], const float2* pts, int n,
                         float out_pose_world[3], float cov[9], float* trace = nullptr, int trace_steps = 0) {
   float* hs = h->h_small;
@@ -720,6 +767,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.out_pose = hs_dev + 3;
   P.out_cov = hs_dev + 6;
   P.trace = trace_steps > 0 ? hs_dev + kTraceOff : nullptr;
+  const unsigned seq = ++h->done_seq;
+  P.done_flag = h->spin_wait ? reinterpret_cast<unsigned*>(hs_dev + kDoneFlagOff) : nullptr;
+  P.done_seq = seq;
   if (n >= h->coop_min_beams && h->wps_override == 0) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h)
     int K = (n + 1023) / 1024;  // ~4 beams per lane
@@ -745,7 +795,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   } else if (int rc = launch_match(h, P, n, h->stream)) {
     return rc;
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = wait_single_scan(h, seq)) return rc;
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
   out_pose_world[1] = hs[4];
@@ -863,7 +913,38 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   const float* o = origo ? origo : zero;
   // level 0: the caller's container
   const float2* d_level0 = d_prestaged;
-  if (!d_level0) {
+  int slot = -1;
+  if (!d_level0 && h->async_update) {
+    // stage the endpoints in pinned memory (a pageable hipMemcpyAsync would block the host until the copy
+    // -- and everything queued before it -- has completed); small scans are then read in place over PCIe
+    // (each endpoint is read twice), dense ones copied to the device by a copy the host does not wait for
+    slot = h->upd_slot;
+    h->upd_slot ^= 1;
+    if (h->upd_busy[slot]) {
+      HIP_TRY(hipEventSynchronize(h->upd_evt[slot]));
+      h->upd_busy[slot] = false;
+    }
+    if ((size_t)n > h->h_upd_cap[slot]) {
+      if (h->h_upd_pinned[slot]) HIP_TRY(hipHostFree(h->h_upd_pinned[slot]));
+      h->h_upd_pinned[slot] = nullptr;
+      h->h_upd_cap[slot] = 0;
+      const size_t want = n < 4096 ? 4096 : (size_t)n + n / 2;
+      HIP_TRY(hipHostMalloc((void**)&h->h_upd_pinned[slot], want * sizeof(float2), hipHostMallocMapped));
+      h->h_upd_cap[slot] = want;
+    }
+    if (!h->upd_evt[slot]) HIP_TRY(hipEventCreateWithFlags(&h->upd_evt[slot], hipEventDisableTiming));
+    if (n > 0) memcpy(h->h_upd_pinned[slot], pts_xy, (size_t)n * sizeof(float2));
+    if (n <= h->update_zero_copy_max) {
+      float2* dev = nullptr;
+      if (n > 0) HIP_TRY(hipHostGetDevicePointer((void**)&dev, h->h_upd_pinned[slot], 0));
+      d_level0 = n > 0 ? dev : h->d_scan;
+    } else {
+      if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
+      HIP_TRY(hipMemcpyAsync(h->d_scan, h->h_upd_pinned[slot], (size_t)n * sizeof(float2), hipMemcpyHostToDevice,
+                             h->stream));
+      d_level0 = h->d_scan;
+    }
+  } else if (!d_level0) {
     if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
     if (n > 0)
       HIP_TRY(hipMemcpyAsync(h->d_scan, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
@@ -902,7 +983,20 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
     }
   }
   if (int rc = launch_update_batch(h, batch)) return rc;
+  if (slot >= 0) {
+    HIP_TRY(hipEventRecord(h->upd_evt[slot], h->stream));
+    h->upd_busy[slot] = true;
+  }
+  if (!h->async_update) HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_synchronize(hsm_ctx* h) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->upd_busy[0] = h->upd_busy[1] = false;
   return HSM_OK;
 }
 

@@ -117,9 +117,16 @@ int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float
  *           HSL/slam_main/MapRepMultiMap.h:134-147 -> OccGridMapBase::updateByScan,
  *           HSL/map/OccGridMapBase.h:121-260.  Level 0 uses (pts, n, origo); coarse
  *           levels use the scan retained by the last hsm_match, scaled by 2^-level,
- *           exactly as the reference does. */
+ *           exactly as the reference does.
+ *           Returns when the update is QUEUED on the context's stream (pts_xy has been copied and may be
+ *           reused at once): every later call on this context -- matches, downloads, further updates --
+ *           is ordered behind it, so results are the same as if it had completed; a device fault
+ *           surfaces at the next call that waits.  hsm_synchronize() waits explicitly; the environment
+ *           variable HSM_ASYNC_UPDATE=0 makes the call itself wait. */
 int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n,
                        const float origo[2]);
+/* wait until all work queued on the context has completed (and report any device error) */
+int hsm_synchronize(hsm_ctx* h);
 /* one level, explicit level-scaled container (OccGridMapBase::updateByScan itself) */
 int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
                              const float* pts_level_xy, int n, const float origo_level[2]);
