@@ -766,3 +766,43 @@ def test_ragged_batch_with_empty_and_tiny_scans(capi, pyr, pyramid_scene):
             if n >= 500:
                 po, _ = o.match(init[i], scans[i])
                 assert_pose_close(pose[i], po, f"ragged {i}")
+
+
+def test_queued_update_equals_blocking_update(capi, pyramid_scene, monkeypatch):
+    """updateByScan returns once queued: the caller may scribble over its scan buffer at once, later calls see
+    the completed update, and the map is bit-identical to a context that blocks in every update
+    (HSM_ASYNC_UPDATE=0) and to one that waits on the end-of-kernel signal (HSM_SPIN_WAIT=0)"""
+    sc = pyramid_scene
+    monkeypatch.setenv("HSM_ASYNC_UPDATE", "0")
+    monkeypatch.setenv("HSM_SPIN_WAIT", "0")
+    blocking = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    monkeypatch.delenv("HSM_ASYNC_UPDATE")
+    monkeypatch.delenv("HSM_SPIN_WAIT")
+    queued = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    for m in (blocking, queued):
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+    rng = np.random.default_rng(77)
+    for t in range(40):
+        scan = np.ascontiguousarray(sc.build_scans[t]).copy()
+        if t % 7 == 3:
+            scan = scan[: 1 + (t * 13) % 60]       # tiny scans exercise the staging slots as well
+        hint = sc.build_poses[t] + (rng.uniform(-0.03, 0.03, 3) * [1, 1, 0.2]).astype(np.float32)
+        pb, cb = blocking.matchData(hint, scan)
+        buf = scan.copy()
+        pq, cq = queued.matchData(hint, buf)
+        assert np.array_equal(bits(pb), bits(pq)) and np.array_equal(bits(cb), bits(cq)), t
+        blocking.updateByScan(scan, pb)
+        queued.updateByScan(buf, pq)
+        buf[:] = np.float32(1e6)                    # the call has copied what it needs
+        if t % 5 == 0:
+            assert np.array_equal(queued.take_dirty_bbox(0), blocking.take_dirty_bbox(0))
+        if t % 11 == 0:
+            la, lb = queued.download_level(0), blocking.download_level(0)
+            assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1]), t
+    queued.synchronize()
+    for lvl in range(sc.levels):
+        la, lb = queued.download_level(lvl), blocking.download_level(lvl)
+        assert (la[0] != 0).sum() > 1000
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1]), lvl
+    assert np.array_equal(queued.occupancy_grid(0), blocking.occupancy_grid(0))
