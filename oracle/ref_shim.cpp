@@ -11,6 +11,7 @@
 // and as the "reference" CPU baseline in bench.py.
 #include "slam_main/HectorSlamProcessor.h"
 
+#include <mutex>
 #include <sstream>
 #include <vector>
 
@@ -43,11 +44,26 @@ struct Ref {
 
 // the reference prints a banner (MapRepMultiMap.h:60) and a clamp message
 // (ScanMatcher.h:211,214) on std::cout; keep test output clean
+// Process-wide and reference counted: the bench's all-cores leg calls in from many threads, and
+// per-call save/restore of std::cout's buffer would leave it pointing at another thread's dead sink.
 struct CoutMute {
-  std::streambuf* old;
-  std::ostringstream sink;
-  CoutMute() : old(std::cout.rdbuf(sink.rdbuf())) {}
-  ~CoutMute() { std::cout.rdbuf(old); }
+  struct NullBuf : std::streambuf {
+    int overflow(int c) override { return c; }
+  };
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static int& depth() { static int d = 0; return d; }
+  static std::streambuf*& saved() { static std::streambuf* s = nullptr; return s; }
+  CoutMute() {
+    std::lock_guard<std::mutex> lk(mu());
+    if (depth()++ == 0) {
+      static NullBuf* nb = new NullBuf;  // never destroyed: safe at any point of process exit
+      saved() = std::cout.rdbuf(nb);
+    }
+  }
+  ~CoutMute() {
+    std::lock_guard<std::mutex> lk(mu());
+    if (--depth() == 0) std::cout.rdbuf(saved());
+  }
 };
 
 static hectorslam::DataContainer make_container(const float* pts, int n, const float origo[2]) {
@@ -220,8 +236,7 @@ void hr_covariance_for_poses(void* h, int level, int batch, const float* poses, 
                              float* out_world, float* out_lh7) {
   Ref* r = (Ref*)h;
   hectorslam::DataContainer dc = make_container(pts, n, 0);
-  std::ostringstream sink;
-  std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
+  CoutMute mute;
   for (int b = 0; b < batch; ++b) {
     auto* util = r->level(level).gridMapUtil;
     const Eigen::Vector3f p = v3(poses + 3 * b);
@@ -236,7 +251,6 @@ void hr_covariance_for_poses(void* h, int level, int batch, const float* poses, 
       for (int i = 0; i < 7; ++i) out_lh7[7 * b + i] = util->getLikelihoodForState(v3(sp[i]), dc);
     }
   }
-  std::cout.rdbuf(old);
 }
 // f4 lives in hector_map_tools (needs nav_msgs); restatement only, same symbol set in both libraries
 void hr_ray_distances(const signed char* grid, int sx, int sy, float ox, float oy, float res, int n, const float* bw,

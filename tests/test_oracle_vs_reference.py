@@ -1,6 +1,7 @@
 """Pin the plain-C++ restatement (oracle/hector_oracle.cpp, "ho") against the reference's own
 code (oracle/_ref/libhector_ref.so, "hr" = unmodified hector_slam_lib headers compiled through
 the private Eigen/tf stand-in).  Every comparison is BIT-EXACT (integer/index work and fp32)."""
+import os
 import numpy as np
 import pytest
 
@@ -199,3 +200,29 @@ def test_randomised_geometries_restatement_equals_reference(oracle_mod):
             a, b = o["ho"].download_level(lvl), o["hr"].download_level(lvl)
             assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), (trial, lvl)
             assert np.array_equal(o["ho"].occupancy_grid(lvl), o["hr"].occupancy_grid(lvl))
+
+
+def test_reference_shim_is_thread_safe_about_stdout(oracle_mod, small_scene):
+    """the bench's all-cores CPU leg drives the reference from many threads; the shim silences the reference's
+    std::cout chatter process-wide (a per-call save/restore once left std::cout on a dead buffer: exit crash)"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref not built")
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, threading, numpy as np
+        sys.path.insert(0, %r)
+        from oracle import pyoracle
+        pts = np.random.default_rng(0).uniform(-40, 40, (64, 2)).astype(np.float32)
+        def work():
+            o = pyoracle.Oracle("hr", 0.1, 128, 128, 2)
+            for k in range(400):
+                o.match(np.zeros(3, np.float32), pts)
+                o.update_by_scan(np.zeros(3, np.float32), pts)
+                o.on_map_updated()
+        th = [threading.Thread(target=work) for _ in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        print("done", flush=True)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-500:])
