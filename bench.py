@@ -404,7 +404,7 @@ def extra_workload(name: str, args, local_rank: int):
                            "gn_iterations_per_scan": its, "kernel": m.last_launch_config()},
                 "roofline": {"bound": "hbm", "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                              "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
-                             "kernel": "gn_match_kernel", "kernel_ms": kern_ms,
+                             "kernel": kernel_name, "kernel_ms": kern_ms,
                              "algorithmic_bytes_per_launch": bytes_per_launch}})
     if not args.no_cpu:
         o, kind = cpu_oracle()
@@ -532,8 +532,10 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC profile of THIS workload (rocprofv3 cannot run
     # inside the timed process); null when the run is not the profiled configuration
     traffic = floor_ms = None
+    kernel_name = "gn_match_kernel"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))["gn_match_kernel"]
+        kernel_name = "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))[kernel_name]
         if B == BATCH_PER_GPU and args.levels == 1:
             traffic = tj["hbm_bytes_per_launch"]
             floor_ms = tj.get("valu_issue_floor_ms")
@@ -554,10 +556,10 @@ def main():
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
                                      "correction calibrated on known-byte kernels), profiles/r01/traffic.json; the "
-                                     "algorithmic bytes are 13.5x larger because endpoints stay in VGPRs across the 6 "
+                                     "algorithmic bytes are 13.5x larger because endpoints stay on chip across the 6 "
                                      "iterations and the texel plane is served from L2 -- frac > 1 is NOT an HBM "
                                      "utilisation, the kernel is VALU-issue + texture-path bound (DESIGN.md 3.1)",
-                     "kernel": "gn_match_kernel", "kernel_ms": kern_ms,
+                     "kernel": kernel_name, "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12,
                      # the limit that actually binds: instruction issue of the bit-exact beam body (measured with

@@ -391,7 +391,8 @@ class MapRepMultiMap:
         cfg = np.empty(5, np.int32)
         _check(self._lib.hsm_last_launch_config(self._h, cfg), "hsm_last_launch_config")
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
-                "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": int(cfg[4])}
+                "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": max(int(cfg[4]), 0),
+                "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4]))}
 
     # ---- parity / debug ---------------------------------------------------------------------
     def hessian_derivs(self, level, pose_map, pts_level):

@@ -252,6 +252,10 @@ __device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
     const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(((lead & ~3u) + (threadIdx.x & 3u)) << 4));
 #elif defined(HSM_EXP_NOLOAD)  // experiment: the beam body without any texel traffic
     const float4 q = make_float4(__uint_as_float(index | 0x3f000000u), 0.25f, 0.75f, __uint_as_float((index >> 3) | 0x3f000000u));
+#elif defined(HSM_EXP_MASKLOAD)  // experiment: only a quarter of the lanes gather (1 = one lane of every quad, 2 = four whole quads)
+    float4 q = make_float4(0.3f, 0.25f, 0.75f, 0.6f);
+    if (HSM_EXP_MASKLOAD == 1 ? (threadIdx.x & 3u) == 0u : (threadIdx.x & 63u) < 16u)
+      q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(index << 4));
 #elif defined(HSM_EXP_SAMELINE)  // experiment: every lane reads the same texel
     const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)((index & 0u) + 4096u));
 #else
@@ -634,6 +638,150 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
     }
     if (scan == 0) publish_done(P);
+  }
+}
+
+// ---- throughput form with a per-beam texel cache --------------------------------------------------
+// From the third GN step on the estimate moves by a fraction of a cell, so most beams fall into the SAME
+// map cell as in the step before (bench workload: 77 / 46 / 14 / 2 / 0.2 % of the lanes change cell in steps
+// 2..6) and would gather the texel they already hold.  The gather, not the arithmetic, is what the texture
+// path charges for -- one lane-request per cycle, whatever the pattern (profiles/r01/README.md) -- so this
+// form keeps every beam's last texel and its byte offset in VGPRs (5 registers per beam) and gathers only in
+// the lanes whose offset changed (exec-masked load; skipped by the whole wave when no lane changed).  To stay
+// at 4 waves per SIMD (<= 128 VGPRs) the endpoints move from VGPRs to LDS: slot [wave][k][lane], written and
+// read by the same lane only, so no barrier is ever needed (SPB * BPL * 512 B per workgroup).  Same
+// arithmetic on the same texel values in the same order as gn_match_kernel: identical bits.
+// One wave per scan, quad layout, no trace.
+#ifndef HSM_CACHE_CHUNK
+#define HSM_CACHE_CHUNK 3
+#endif
+constexpr int kCacheChunk = HSM_CACHE_CHUNK;
+
+template <int SPB, int BPL>
+__global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const MatchParams P) {
+  __shared__ f2 lds_pts[SPB][BPL][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int scan = blockIdx.x * SPB + wave;
+  if (scan >= P.batch) return;
+  int beg = 0, n = P.shared_n;
+  if (P.offsets) {
+    beg = P.offsets[scan];
+    n = P.offsets[scan + 1] - beg;
+  }
+  float pw0 = P.begin_world[3 * scan + 0], pw1 = P.begin_world[3 * scan + 1], pw2 = P.begin_world[3 * scan + 2];
+  if (n == 0) {
+    if (lane == 0) {
+      P.out_pose[3 * scan + 0] = pw0;
+      P.out_pose[3 * scan + 1] = pw1;
+      P.out_pose[3 * scan + 2] = pw2;
+    }
+    return;
+  }
+  const float2* __restrict__ pts = P.pts + beg;
+  f2(*mine)[64] = lds_pts[wave];
+#pragma unroll
+  for (int k = 0; k < BPL; ++k) {
+    const int i = lane + k * 64;
+    const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: see gn_match_kernel
+    mine[k][lane] = f2{q.x, q.y};
+  }
+  float4 tq[BPL];
+  unsigned toff[BPL];
+  Acc9 acc;
+  acc.zero();
+  float reg_scale = 1.0f;
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<kLayoutQuad>(L);
+    const float ratio = ps / reg_scale;  // powers of two: exact (see gn_match_kernel)
+    reg_scale = ps;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+      if (ratio != 1.0f) mine[k][lane] *= f2{ratio, ratio};
+      toff[k] = 0xffffffffu;  // never a texel offset (not a multiple of 16): every beam gathers in the first step
+    }
+    for (int it = 0; it < gn_steps; ++it) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      acc.zero();
+      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      // chunks of kCacheChunk beams: locate them all (offsets, the masked gathers of the lanes that moved to
+      // another cell), then consume them in beam order -- the few gathers that remain overlap each other
+#pragma unroll
+      for (int k0 = 0; k0 < BPL; k0 += kCacheChunk) {
+        BeamSample b[kCacheChunk];
+        BeamRot r[kCacheChunk];
+        f2 pc[kCacheChunk];
+#pragma unroll
+        for (int u = 0; u < kCacheChunk; ++u)  // the chunk's LDS reads back to back: one wait instead of one per beam
+          if (k0 + u < BPL) pc[u] = mine[k0 + u][lane];
+#pragma unroll
+        for (int u = 0; u < kCacheChunk; ++u) {
+          const int k = k0 + u;
+          if (k < BPL) {
+            const f2 p = pc[u];
+            r[u].r.x = cs.x * p.x - sc.x * p.y;
+            r[u].r.y = cs.y * p.x + sc.y * p.y;
+            const f2 c = f2{e2.x + r[u].r.x, e2.y + r[u].r.y};
+            const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, R.limx);
+            const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, R.limy);
+            const bool oob = (sx_ != c.x) | (sy_ != c.y);
+            const unsigned ix = (unsigned)(int)sx_;
+            const unsigned iy = (unsigned)(int)sy_;
+            b[u].X.y = __builtin_amdgcn_fractf(sx_);
+            b[u].Y.y = __builtin_amdgcn_fractf(sy_);
+            unsigned idx = quad_index(ix, iy, R.tiles_x, R.sx);
+            asm volatile("" : "+v"(idx));  // computed unconditionally: a select below, not a branch
+#if defined(HSM_EXP_CACHE_FLOOR)  // experiment: every lane always hits its cached texel after the first gather
+            const unsigned off = ((oob ? (unsigned)R.zero_index : idx) & 0u) + 4096u;
+#else
+            const unsigned off = (oob ? (unsigned)R.zero_index : idx) << 4;
+#endif
+            if (off != toff[k]) {
+              tq[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R.quad) + (size_t)off);
+              toff[k] = off;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kCacheChunk; ++u) {
+          const int k = k0 + u;
+          if (k < BPL) {
+            b[u].X.x = 1.0f - b[u].X.y;
+            b[u].Y.x = 1.0f - b[u].Y.y;
+            b[u].lo = f2{tq[k].x, tq[k].y};
+            b[u].hi = f2{tq[k].z, tq[k].w};
+            beam_finish(b[u], r[u], acc);
+          }
+        }
+        asm volatile(""
+                     : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
+                     :
+                     : "memory");
+      }
+      wave_allreduce9(acc);
+      gn_solve_and_step(acc, ex, ey, eth);
+    }
+    eth = normalize_angle(eth);
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+    pw2 = eth;
+  }
+  if (lane == 0) {
+    P.out_pose[3 * scan + 0] = pw0;
+    P.out_pose[3 * scan + 1] = pw1;
+    P.out_pose[3 * scan + 2] = pw2;
+    if (P.out_cov) {
+      float* c = P.out_cov + 9 * scan;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
+    }
   }
 }
 

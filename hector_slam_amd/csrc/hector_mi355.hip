@@ -94,6 +94,7 @@ struct hsm_ctx {
   // updateByScan returns when its kernels are QUEUED (env HSM_ASYNC_UPDATE=0: wait for them): everything
   // that reads the map afterwards is ordered behind them on `stream`.  Host endpoints are staged in one of
   // two pinned blocks, each guarded by the event of the update that last read it.
+  bool texel_cache = true;          // env HSM_TEXEL_CACHE=0: plain gn_match_kernel for throughput launches too
   bool async_update = true;
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
   float2* h_upd_pinned[2] = {nullptr, nullptr};
@@ -143,7 +144,7 @@ struct hsm_ctx {
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
-  int last_cfg[5] = {0, 0, 0, 0, 0};
+  int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -265,6 +266,21 @@ template <int WPS, int SPB, int BPL>
 int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
+  if constexpr (WPS == 1 && (BPL == 9 || BPL == 17)) {
+    // throughput launches of long scans: the texel-cache form (gn_match.h)
+    if (h->texel_cache && h->layout == kLayoutQuad && P.begin_world && !P.trace) {
+      hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL>), dim3(grid), dim3(block), 0, stream, P);
+      HIP_TRY(hipGetLastError());
+      h->last_cfg[0] = h->layout;
+      h->last_cfg[1] = WPS;
+      h->last_cfg[2] = block;
+      h->last_cfg[3] = grid;
+      h->last_cfg[4] = BPL;
+      h->last_cfg[5] = 1;
+      return HSM_OK;
+    }
+  }
+  h->last_cfg[5] = 0;
   if (h->layout == kLayoutPlane)
     hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, BPL>), dim3(grid), dim3(block), 0, stream, P);
   else
@@ -503,6 +519,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_COOP_MIN")) h->coop_min_beams = atoi(env);
   if (const char* env = getenv("HSM_SPIN_WAIT")) h->spin_wait = atoi(env) != 0;
   if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
+  if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
 
 #define CREATE_TRY(expr)                                   \
@@ -635,6 +652,7 @@ int hsm_gn_iterations_per_match(const hsm_ctx* h) {
 int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]) {
   if (!h || !cfg) return fail(HSM_ERR_INVALID, "null argument");
   for (int i = 0; i < 5; ++i) cfg[i] = h->last_cfg[i];
+  if (h->last_cfg[5]) cfg[4] = -cfg[4];  // texel-cache form: endpoints in LDS, not VGPRs
   return HSM_OK;
 }
 

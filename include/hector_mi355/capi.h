@@ -268,7 +268,9 @@ int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
 /* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
 int hsm_gn_iterations_per_match(const hsm_ctx* h);
 /* effective kernel configuration of the last match launch:
- * {layout, waves_per_scan, block, grid, beams_per_lane (0 = endpoints streamed from memory)} */
+ * {layout, waves_per_scan, block, grid, beams_per_lane (0 = endpoints streamed from memory; negative =
+ * the texel-cache form: that many beams per lane with endpoints in LDS and the last texel of every beam
+ * kept in VGPRs)} */
 int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]);
 
 const char* hsm_last_error(void);

@@ -806,3 +806,37 @@ def test_queued_update_equals_blocking_update(capi, pyramid_scene, monkeypatch):
         assert (la[0] != 0).sum() > 1000
         assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1]), lvl
     assert np.array_equal(queued.occupancy_grid(0), blocking.occupancy_grid(0))
+
+
+def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch):
+    """gn_match_cached_kernel (endpoints in LDS, last texel of every beam kept in VGPRs, gathers only in the
+    lanes whose cell changed) == gn_match_kernel bit for bit: poses and covariances, full pyramid, ragged scans"""
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    monkeypatch.setenv("HSM_TEXEL_CACHE", "1")
+    cached = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)
+    monkeypatch.setenv("HSM_TEXEL_CACHE", "0")
+    plain = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)
+    for lvl in range(sc.levels):
+        lv = o.download_level(lvl)
+        cached.upload_level(lvl, *lv)
+        plain.upload_level(lvl, *lv)
+    rng = np.random.default_rng(31)
+    nq = len(sc.query_scans)
+    for sizes in ([1081] * 96, list(rng.integers(330, 1081, 64)) + [0, 577, 576, 1081, 0], [450] * 40):
+        scans, init = [], []
+        for j, n in enumerate(sizes):
+            full = sc.query_scans[j % nq]
+            n = min(int(n), full.shape[0])
+            scans.append(full[np.sort(rng.choice(full.shape[0], n, replace=False))] if n else np.zeros((0, 2), np.float32))
+            init.append(sc.query_init[j % nq] + (rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]).astype(np.float32))
+        init = np.asarray(init, np.float32)
+        pts, offs = synth.pack_scans(scans)
+        pc, cc = cached.match_batch(init, pts, offs)
+        cfg = cached.last_launch_config()
+        pp, cp = plain.match_batch(init, pts, offs)
+        assert cfg["texel_cache"] and not plain.last_launch_config()["texel_cache"], cfg
+        assert np.array_equal(bits(pc), bits(pp)) and np.array_equal(bits(cc), bits(cp)), sizes[:3]
+    po = np.stack([o.match(init[j], scans[j])[0] for j in range(8)])
+    assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
