@@ -404,7 +404,8 @@ def extra_workload(name: str, args, local_rank: int):
                            "gn_iterations_per_scan": its, "kernel": m.last_launch_config()},
                 "roofline": {"bound": "hbm", "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                              "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
-                             "kernel": kernel_name, "kernel_ms": kern_ms,
+                             "kernel": ("gn_match_cached_kernel" if m.last_launch_config().get("texel_cache")
+                                        else "gn_match_kernel"), "kernel_ms": kern_ms,
                              "algorithmic_bytes_per_launch": bytes_per_launch}})
     if not args.no_cpu:
         o, kind = cpu_oracle()
