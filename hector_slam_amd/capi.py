@@ -92,6 +92,7 @@ SIGNATURES = {
     "hsm_eval_beams": (_i, [_vp, _i, _f32p, _vp, _i, _vp]),
     "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
     "hsm_debug_set_update_serial": (_i, [_vp, _i, C.c_uint]),
+    "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
@@ -414,6 +415,9 @@ class MapRepMultiMap:
         s, c = np.empty_like(x), np.empty_like(x)
         _check(self._lib.hsm_debug_sincos(self._h, x.size, x, s, c), "hsm_debug_sincos")
         return s, c
+
+    def debug_set_coop_barrier(self, value):
+        _check(self._lib.hsm_debug_set_coop_barrier(self._h, int(value) & 0xffffffff), "hsm_debug_set_coop_barrier")
 
     def match_level(self, level, begin_world, pts_level, max_iter, cov=None):
         a, p, n = _pts(pts_level)

@@ -794,10 +794,30 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 // otherwise), and every workgroup sums the K partials in the same fixed order -- wave 0, lane l takes
 // workgroup l, then the DPP/permlane tree -- so all of them take the identical GN step.  Partials are double
 // buffered by step parity: one grid sync per step.
+// Grid barrier of the cooperative matcher: one monotonically increasing device-memory counter (the host passes
+// its value at launch, so it is never reset), one agent-scope release increment per workgroup and an acquire
+// spin by thread 0 -- 2-3 us per GN step cheaper than cooperative_groups' grid.sync() (HSM_COOP_BARRIER=0
+// selects that one).  All K workgroups are co-resident: the launch is still a cooperative launch.
+#ifndef HSM_COOP_BARRIER
+#define HSM_COOP_BARRIER 1
+#endif
+__device__ __forceinline__ void coop_barrier(unsigned* counter, unsigned target) {
+  __syncthreads();  // the workgroup's partials are written
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P, float* __restrict__ partials) {
+__global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P, float* __restrict__ partials,
+                                                            unsigned* __restrict__ bar_counter, unsigned bar_base) {
+#if !HSM_COOP_BARRIER
   namespace cg = cooperative_groups;
   cg::grid_group grid = cg::this_grid();
+#endif
   __shared__ float red[4][9];
   __shared__ float tot[9];
   const int lane = threadIdx.x & 63;
@@ -840,7 +860,11 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
       __syncthreads();
       float* mine = partials + ((size_t)(step & 1) * K + blockIdx.x) * 9;
       if (threadIdx.x < 9) mine[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+#if HSM_COOP_BARRIER
+      coop_barrier(bar_counter, bar_base + (unsigned)K * (unsigned)(step + 1));
+#else
       grid.sync();
+#endif
       // every workgroup: the same K partials in the same order
       if (wave == 0) {
         const float* src = partials + ((size_t)(step & 1) * K + lane) * 9;

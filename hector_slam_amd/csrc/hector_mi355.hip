@@ -139,6 +139,7 @@ struct hsm_ctx {
   int trig_n = -1;
   signed char* d_occ = nullptr;     // occupancy export staging
   size_t d_occ_cap = 0;
+  unsigned coop_bar_base = 0;   // value the grid-barrier counter has when the next cooperative launch starts
   float* d_partials = nullptr;  // [2][64][9] per-workgroup partial sums of gn_match_coop_kernel
   int coop_min_beams = 4096;    // single scans at least this long take the multi-workgroup matcher (env HSM_COOP_MIN)
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
@@ -535,7 +536,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   CREATE_TRY(hipSetDevice(h->device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
-  CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 9 * sizeof(float)));
+  CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 9 * sizeof(float) + 64));  // + the grid-barrier counter
+  CREATE_TRY(hipMemset(h->d_partials, 0, 2 * 64 * 9 * sizeof(float) + 64));
   CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float),
                            hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_small, 0, kSmallFloats * sizeof(float));
@@ -795,10 +797,15 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     if (K > 64) K = 64;
     if (K < 2) K = 2;
     float* partials = h->d_partials;
-    void* args[] = {(void*)&P, (void*)&partials};
+    unsigned* bar_counter = reinterpret_cast<unsigned*>(h->d_partials + 2 * 64 * 9);
+    unsigned bar_base = h->coop_bar_base;
+    void* args[] = {(void*)&P, (void*)&partials, (void*)&bar_counter, (void*)&bar_base};
     const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane>
                                                 : (const void*)gn_match_coop_kernel<kLayoutQuad>;
     if (hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream) == hipSuccess) {
+      unsigned steps = 0;
+      for (int l = P.first_level; l >= P.last_level; --l) steps += (unsigned)P.lv[l].gn_steps;
+      h->coop_bar_base += (unsigned)K * steps;  // one arrival per workgroup per GN step
       h->last_cfg[0] = h->layout;
       h->last_cfg[1] = -K;  // negative: K cooperating workgroups instead of waves per scan
       h->last_cfg[2] = 256;
@@ -1633,6 +1640,16 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out4, d_out, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return HSM_OK;
+}
+
+int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->d_partials + 2 * 64 * 9, &value, sizeof value, hipMemcpyHostToDevice));
+  h->coop_bar_base = value;
   return HSM_OK;
 }
 

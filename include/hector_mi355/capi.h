@@ -262,6 +262,9 @@ int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const flo
 /* test hook: set the 16-bit per-scan generation counter of `level`'s key planes (it wraps every 65535
  * updates -- 27 minutes at 40 Hz -- and the wrap path has to be exercised without running that long) */
 int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial);
+/* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by
+ * workgroups x GN steps per dense match and wraps at 2^32) */
+int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value);
 /* device sin/cos (fp64-evaluated, rounded once to fp32) of n angles -- numerics test hook */
 int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
 

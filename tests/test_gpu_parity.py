@@ -615,6 +615,14 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene):
     assert steps.value == 14 and np.array_equal(bits(trace[13 * 12 + 3:14 * 12]), bits(cov))
     po, _ = o.match(sc.query_init[0], pts)
     assert_pose_close(pose, po, "trace path")
+    # the grid barrier's arrival counter is monotonic across launches and wraps at 2^32: matches that straddle the
+    # wrap (8 workgroups x 14 steps = 112 arrivals per launch) give the same bits as before it
+    ref = [g.matchData(sc.query_init[q], pts) for q in range(3)]
+    g.debug_set_coop_barrier(0xffffffff - 150)
+    for rep in range(4):
+        for q in range(3):
+            pq, cq = g.matchData(sc.query_init[q], pts)
+            assert np.array_equal(bits(pq), bits(ref[q][0])) and np.array_equal(bits(cq), bits(ref[q][1])), (rep, q)
 
 
 def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene):
