@@ -207,21 +207,38 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
 }
 
 // dense over the box [x0..x1] x [y0..y1]: bresenhamCellFree / bresenhamCellOcc (OccGridMapBase.h:216-241)
+//
+// "A beam of THIS scan ends here" is the cell's bit in the end-cell bitmap (set by update_mark_occ_kernel,
+// cleared here), so the occ-key plane is only read where the bit is set -- end cells are walls, and most of that
+// plane's cache lines are never touched by this pass.  The bitmap word is cleared by the lane of its first cell;
+// that is only safe when every reader of a word sits in the SAME wavefront (reads program-ordered before the
+// store), which holds when rows are a multiple of 64 cells: the pass then runs over the box widened to 64-cell
+// column boundaries (the extra cells carry no key of this scan).  Other map widths keep the plain form.
 __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
   if (P.x1 < P.x0) return;  // this level has nothing to apply
-  const int w = P.x1 - P.x0 + 1, h = P.y1 - P.y0 + 1;
+  const bool aligned = (P.lv.sx & 63) == 0;
+  const int bx0 = aligned ? (P.x0 & ~63) : P.x0;
+  const int w = aligned ? ((P.x1 | 63) - bx0 + 1) : (P.x1 - P.x0 + 1), h = P.y1 - P.y0 + 1;
   const size_t n = (size_t)w * h;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-    const int x = P.x0 + (int)(t % (size_t)w), y = P.y0 + (int)(t / (size_t)w);
+    const int x = bx0 + (int)(t % (size_t)w), y = P.y0 + (int)(t / (size_t)w);
     const size_t c = (size_t)y * P.lv.sx + x;
-    // clear the end-cell bitmap for the next scan: every set bit lies inside the box, so zeroing each word
-    // that overlaps the box (first thread of the word in this row) is exact
-    if ((c & 31u) == 0 || x == P.x0) P.lv.occ_bits[c >> 5] = 0u;
     const unsigned int kf = P.lv.key_free[c];
-    const unsigned int ko = P.lv.key_occ[c];
+    unsigned int ko;
+    bool occ;
+    if (aligned) {
+      const unsigned int word = P.lv.occ_bits[c >> 5];
+      occ = (word >> (c & 31u)) & 1u;
+      ko = occ ? P.lv.key_occ[c] : 0u;
+      if (word != 0u && (c & 31u) == 0) P.lv.occ_bits[c >> 5] = 0u;
+    } else {
+      // every set bit lies inside the box, so zeroing each word that overlaps it is exact
+      if ((c & 31u) == 0 || x == P.x0) P.lv.occ_bits[c >> 5] = 0u;
+      ko = P.lv.key_occ[c];
+      occ = (ko >> 16) == P.serial;
+    }
     const bool fre = (kf >> 16) == P.serial;
-    const bool occ = (ko >> 16) == P.serial;
     if (!fre && !occ) continue;
     float l = P.lv.logodds[c];
     int stamp;
