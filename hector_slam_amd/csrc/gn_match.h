@@ -100,6 +100,23 @@ __device__ __forceinline__ void publish_done(const MatchParams& P) {
   if (P.done_flag) __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md; used for speed only -- any placement is
+// correct), and every XCD has its own 4 MiB L2.  A batch is usually spatially ordered (consecutive scans of a
+// trajectory, hypotheses around one pose), so handing each XCD a CONTIGUOUS eighth of the batch keeps the map
+// region its L2 has to hold eight times smaller than the round-robin default would.  Bijective for any grid.
+#ifndef HSM_XCD_SWIZZLE
+#define HSM_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xcd_block(int b, int nblocks) {
+#if HSM_XCD_SWIZZLE
+  const int xcd = b & 7, idx = b >> 3, q = nblocks >> 3, r = nblocks & 7;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+#else
+  (void)nblocks;
+  return b;
+#endif
+}
+
 // Texel address of cell (x, y) in the quad plane.
 // HSM_QUAD_TILE == 0 (default): row major, index = y*sizeX + x like the reference's grid -- one
 //   v_mad_u32_u24 per beam.
@@ -479,7 +496,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   const int wave = threadIdx.x >> 6;
   const int team = wave / WPS;
   const int wit = wave - team * WPS;
-  const int scan = blockIdx.x * SPB + team;
+  const int scan = xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + team;
   if (scan >= P.batch) return;  // whole team exits together
 
   int beg = 0, n = P.shared_n;
@@ -662,7 +679,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   __shared__ f2 lds_pts[SPB][BPL][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int scan = blockIdx.x * SPB + wave;
+  const int scan = xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + wave;
   if (scan >= P.batch) return;
   int beg = 0, n = P.shared_n;
   if (P.offsets) {
@@ -805,8 +822,10 @@ __device__ __forceinline__ void coop_barrier(unsigned* counter, unsigned target)
   __syncthreads();  // the workgroup's partials are written
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+    // relaxed polls (each acquire load would invalidate the caches), ONE acquire fence once everybody arrived
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
       __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
