@@ -202,6 +202,19 @@ def test_ingest_point_cloud_bit_exact(capi, oracle_mod, pyramid_scene):
             ref, ro = o.point_cloud_to_container(cloud, T, *gates, s)
             assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (n, cutoff)
             assert np.array_equal(bits(go), bits(ro)) and ref.shape[0] > n // 4
+    # argument validation: NULL transform / negative count / too many points are refused, nothing is ingested
+    import ctypes as C
+    lib = capi.load_library()
+    cnt = C.c_int(-7)
+    c3 = synthetic_cloud(rng, 10)
+    assert lib.hsm_ingest_point_cloud(g._h, c3.ctypes.data, 10, None, 0.16, 900.0, -1.0, 1.0, 20.0, None,
+                                      C.byref(cnt), None) == -1 and b"bad argument" in lib.hsm_last_error()
+    assert lib.hsm_ingest_point_cloud(g._h, c3.ctypes.data, -1, rigid_rows(rng).ctypes.data, 0.16, 900.0, -1.0, 1.0,
+                                      20.0, None, C.byref(cnt), None) == -1
+    assert lib.hsm_ingest_laser_scan_tf(g._h, None, 5, 0.0, 0.1, 0.1, 30.0, 30.0, rigid_rows(rng).ctypes.data, 0.16,
+                                        900.0, -1.0, 1.0, 20.0, None, C.byref(cnt), None) == -1
+    assert lib.hsm_ingest_point_cloud(g._h, c3.ctypes.data, 70000, rigid_rows(rng).ctypes.data, 0.16, 900.0, -1.0,
+                                      1.0, 20.0, None, C.byref(cnt), None) == -1 and cnt.value == -7
     # alternating entries share the geometry-table cache: the float2 and double2 tables must not be confused
     r = synthetic_ranges(rng, 1081)
     T = rigid_rows(rng)
