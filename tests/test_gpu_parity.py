@@ -823,9 +823,11 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
     g, o = pyr
     sc = pyramid_scene
     monkeypatch.setenv("HSM_TEXEL_CACHE", "1")
-    cached = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)
+    cached = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1,
+                                 layout=capi.LAYOUT_QUAD)
     monkeypatch.setenv("HSM_TEXEL_CACHE", "0")
-    plain = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)
+    plain = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1,
+                                layout=capi.LAYOUT_QUAD)
     for lvl in range(sc.levels):
         lv = o.download_level(lvl)
         cached.upload_level(lvl, *lv)
