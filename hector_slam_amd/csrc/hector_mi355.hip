@@ -198,6 +198,7 @@ LevelRW level_rw(const Level& L) {
   v.sx = L.sx;
   v.sy = L.sy;
   v.tiles_x = L.tiles_x();
+  v.kf_tiles_x = (L.sx + 7) / 8;
   v.quad_texels = L.quad_texels();
   return v;
 }
@@ -382,7 +383,7 @@ int update_level(hsm_ctx* h, UpdateBatch& batch, int level, const float pose_wor
   if (n > 0) {
     if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than 65535 beams");
     if (++L.serial > 0xFFFFu) {  // key generation wrapped: clear the key planes once
-      HIP_TRY(hipMemsetAsync(L.d_key_free, 0, L.cells() * sizeof(unsigned int), h->stream));
+      HIP_TRY(hipMemsetAsync(L.d_key_free, 0, key_free_cells(L.sx, L.sy) * sizeof(unsigned int), h->stream));
       HIP_TRY(hipMemsetAsync(L.d_key_occ, 0, L.cells() * sizeof(unsigned int), h->stream));
       L.serial = 1;
     }
@@ -572,9 +573,9 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
       CREATE_TRY(hipMalloc((void**)&L.d_quad, ((size_t)L.quad_texels() + 1) * sizeof(float4)));
       CREATE_TRY(hipMemsetAsync(L.d_quad + L.quad_texels(), 0, sizeof(float4), h->stream));
     }
-    CREATE_TRY(hipMalloc((void**)&L.d_key_free, n * sizeof(unsigned int)));
+    CREATE_TRY(hipMalloc((void**)&L.d_key_free, key_free_cells(L.sx, L.sy) * sizeof(unsigned int)));
     CREATE_TRY(hipMalloc((void**)&L.d_key_occ, n * sizeof(unsigned int)));
-    CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, n * sizeof(unsigned int), h->stream));
+    CREATE_TRY(hipMemsetAsync(L.d_key_free, 0, key_free_cells(L.sx, L.sy) * sizeof(unsigned int), h->stream));
     CREATE_TRY(hipMemsetAsync(L.d_key_occ, 0, n * sizeof(unsigned int), h->stream));
     CREATE_TRY(hipMalloc((void**)&L.d_occ_bits, ((n + 31) / 32 + 1) * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((n + 31) / 32 + 1) * sizeof(unsigned int), h->stream));

@@ -49,7 +49,30 @@ struct LevelRW {
   unsigned int* occ_bits; // 1 bit per cell: "some beam of the current scan ends here" (set in pass 1a, cleared in pass 2)
   int sx, sy;
   int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
+  int kf_tiles_x;            // free-key tiles per row = ceil(sx / 8)   (key_free_index)
 };
+
+// The free-key plane is stored in 8x4-cell tiles (= one 128-byte line).  The line walk of update_mark_free_kernel
+// writes one 4-byte tag per visited cell: row major, a y-major beam touches a new cache line every step and an
+// x-major one every 32 steps; tiled, both touch a new line every 4..8 steps, and the lanes of a wave (64
+// consecutive steps of one beam) share lines either way.  HSM_KEYFREE_TILE=0: row major.
+#ifndef HSM_KEYFREE_TILE
+#define HSM_KEYFREE_TILE 1
+#endif
+__host__ __device__ __forceinline__ size_t key_free_cells(int sx, int sy) {
+#if HSM_KEYFREE_TILE
+  return (size_t)((sx + 7) / 8) * (size_t)((sy + 3) / 4) * 32u;
+#else
+  return (size_t)sx * sy;
+#endif
+}
+__device__ __forceinline__ unsigned int key_free_index(const LevelRW& L, unsigned int x, unsigned int y) {
+#if HSM_KEYFREE_TILE
+  return ((((y >> 2) * (unsigned int)L.kf_tiles_x) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);
+#else
+  return y * (unsigned int)L.sx + x;
+#endif
+}
 
 struct UpdateParams {
   LevelRW lv;
@@ -85,6 +108,7 @@ struct BeamLine {
   int offset_a, offset_b;
   unsigned int e0;
   unsigned int start;
+  bool x_major;  // the major (per-step) axis is x
 };
 
 // geometry of beam i exactly as updateByScan / updateLineBresenhami derive it
@@ -109,6 +133,7 @@ __device__ __forceinline__ BeamLine beam_line(const UpdateParams& P, int i) {
   const int offset_dx = dx > 0 ? 1 : -1;                 // util::sign, sign(0) = -1
   const int offset_dy = (dy > 0 ? 1 : -1) * P.lv.sx;
   b.start = (unsigned int)(y0 * P.lv.sx + x0);
+  b.x_major = abs_dx >= abs_dy;
   if (abs_dx >= abs_dy) {  // :200-207
     b.abs_da = abs_dx;
     b.abs_db = abs_dy;
@@ -170,6 +195,7 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
   const unsigned int q64 = inc / b.abs_da, r64 = inc - q64 * b.abs_da;
   const unsigned int step_a = (unsigned int)(64 * b.offset_a);
   unsigned int base = b.start + (unsigned int)(lane * b.offset_a);
+  const bool x_major = b.x_major;
   // Duplicate suppression.  Neighbouring beams of a dense scan run through the SAME cells for their first
   // hundreds of steps (all lines start in the same cell and separate by less than a cell until 1/dtheta
   // cells out).  If beam-1 is valid, lies in the same octant and visits the same cell at step i, it writes
@@ -184,10 +210,14 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
   for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(dedup && i < pb.abs_da && pq == q)) {
       const unsigned int c = base + (unsigned int)((int)q * b.offset_b);  // == line_cell(b, i)
+      // the same cell as (x, y): i steps along the major axis, q along the minor one
+      const int sa = b.offset_a > 0 ? (int)i : -(int)i, sb = b.offset_b > 0 ? (int)q : -(int)q;
+      const unsigned int cx = (unsigned int)(P.bx + (x_major ? sa : sb)), cy = (unsigned int)(P.by + (x_major ? sb : sa));
+      const unsigned int kc = key_free_index(P.lv, cx, cy);
       if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {  // 32x denser than the key plane: stays in L2
-        atomicMax(&P.lv.key_free[c], key);
+        atomicMax(&P.lv.key_free[kc], key);
       } else {
-        P.lv.key_free[c] = tag;
+        P.lv.key_free[kc] = tag;
       }
     }
     base += step_a;
@@ -224,7 +254,7 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
     const int x = bx0 + (int)(t % (size_t)w), y = P.y0 + (int)(t / (size_t)w);
     const size_t c = (size_t)y * P.lv.sx + x;
-    const unsigned int kf = P.lv.key_free[c];
+    const unsigned int kf = P.lv.key_free[key_free_index(P.lv, (unsigned int)x, (unsigned int)y)];
     unsigned int ko;
     bool occ;
     if (aligned) {
