@@ -157,16 +157,40 @@ __device__ __forceinline__ unsigned int line_cell(const BeamLine& b, unsigned in
 }
 
 // pass 1a: end cells.  One thread per beam: atomicMax leaves the FIRST beam that ends in a cell.
+// Neighbouring beams end in the same cell (near walls) or in the same 32-cell bitmap word (walls along x), and
+// same-address atomics serialise in L2, so each wavefront first combines what it can: of a run of adjacent lanes
+// with the same end cell only the first (lowest beam index = largest key, exactly what atomicMax would keep)
+// issues the atomicMax, and the bits of a run of adjacent lanes with the same bitmap word are OR-ed by a
+// segmented scan so that only the first lane of the run issues the atomicOr.
 __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
   const int beam = blockIdx.x * blockDim.x + threadIdx.x;
-  if (beam >= P.n) return;
-  const BeamLine b = beam_line(P, beam);
-  if (!b.valid) return;
-  const unsigned int key = (P.serial << 16) | (0xFFFFu - (unsigned int)beam);
-  const unsigned int c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
-  atomicMax(&P.lv.key_occ[c], key);
-  atomicOr(&P.lv.occ_bits[c >> 5], 1u << (c & 31u));
+  const int lane = threadIdx.x & 63;
+  if (((int)(blockIdx.x * blockDim.x) + (int)(threadIdx.x & ~63u)) >= P.n) return;  // whole wave beyond the scan
+  bool valid = beam < P.n;
+  unsigned int c = 0xffffffffu;
+  if (valid) {
+    const BeamLine b = beam_line(P, beam);
+    valid = b.valid;
+    if (valid) c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
+  }
+  const unsigned int c_prev = (unsigned int)__shfl_up((int)c, 1);
+  const bool first_of_cell = valid && (lane == 0 || c_prev != c);
+  if (first_of_cell) atomicMax(&P.lv.key_occ[c], (P.serial << 16) | (0xFFFFu - (unsigned int)beam));
+  // bitmap: runs of adjacent valid lanes with the same word
+  const unsigned int w = valid ? (c >> 5) : (0xfffffff0u - (unsigned int)lane);  // invalid lanes never join a run
+  const unsigned int w_prev = (unsigned int)__shfl_up((int)w, 1);
+  const bool head = lane == 0 || w_prev != w;
+  const unsigned long long heads = __ballot(head);
+  unsigned int m = valid ? (1u << (c & 31u)) : 0u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int up = (unsigned int)__shfl_down((int)m, d);
+    // lanes lane+1 .. lane+d belong to this lane's run iff none of them starts a new one
+    const bool same = (lane + d < 64) && (((heads >> (lane + 1)) & ((1ull << d) - 1ull)) == 0ull);
+    if (same) m |= up;
+  }
+  if (head && valid) atomicOr(&P.lv.occ_bits[w], m);
 }
 
 // pass 1b: line cells (after 1a has completed).  WHICH beam crossed a cell first only matters
