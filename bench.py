@@ -429,8 +429,10 @@ def extra_workload(name: str, args, local_rank: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 200 for the headline workload: ~12 ms, so that the barrier + "
+                         "synchronise bracket of the timed region stays below 1 %% of it; 30 for the extras)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10 / 5)")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="scans per GPU")
     ap.add_argument("--levels", type=int, default=1, help="pyramid levels of the headline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -438,6 +440,10 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
                     help="config3 = the headline (BASELINE configs[2]); others are single-GPU extras")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "config3" else 30
+    if args.warmup is None:
+        args.warmup = 10 if args.workload == "config3" else 5
 
     import torch
     import torch.distributed as dist
