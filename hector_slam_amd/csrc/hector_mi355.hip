@@ -95,6 +95,10 @@ struct hsm_ctx {
   // that reads the map afterwards is ordered behind them on `stream`.  Host endpoints are staged in one of
   // two pinned blocks, each guarded by the event of the update that last read it.
   bool texel_cache = true;          // env HSM_TEXEL_CACHE=0: plain gn_match_kernel for throughput launches too
+  // ordering between the context's stream (updates) and caller-owned streams (hsm_match_batch_device)
+  unsigned long long upd_epoch = 0, upd_epoch_ordered = 0;
+  hipEvent_t evt_updates = nullptr, evt_foreign = nullptr;
+  bool foreign_match_pending = false;
   bool async_update = true;
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
   float2* h_upd_pinned[2] = {nullptr, nullptr};
@@ -469,6 +473,17 @@ int select_device(const hsm_ctx* h) {
   return HSM_OK;
 }
 
+// every writer of the map queues behind a batch match that a caller-owned stream may still be running, and
+// bumps the epoch the next such match orders itself behind
+int order_after_foreign_match(hsm_ctx* h) {
+  if (h->foreign_match_pending) {
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->evt_foreign, 0));
+    h->foreign_match_pending = false;
+  }
+  ++h->upd_epoch;
+  return HSM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -609,6 +624,8 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_ingest);
   (void)hipFree(h->d_occ);
   if (h->h_scan_pinned) (void)hipHostFree(h->h_scan_pinned);
+  if (h->evt_updates) (void)hipEventDestroy(h->evt_updates);
+  if (h->evt_foreign) (void)hipEventDestroy(h->evt_foreign);
   if (h->h_small) (void)hipHostFree(h->h_small);
   for (int k = 0; k < 2; ++k) {
     if (h->h_upd_pinned[k]) (void)hipHostFree(h->h_upd_pinned[k]);
@@ -622,6 +639,7 @@ int hsm_reset(hsm_ctx* h) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
+  if (int rc = order_after_foreign_match(h)) return rc;
   for (Level& L : h->levels) {
     if (int rc = fill_level(h, L)) return rc;
     L.dirty[0] = L.dirty[1] = 0;  // every cell changed: the whole level is dirty for host mirrors
@@ -679,7 +697,24 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   // per-scan length is only known on the device for CSR input; shared_n doubles as the
   // sizing hint there (callers pass the typical beams per scan, 0 = unknown)
   const int hint = shared_n > 0 ? shared_n : 1081;
-  return launch_match(h, P, hint, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (s == h->stream) return launch_match(h, P, hint, s);
+  // A caller-owned stream is not ordered against the context's own one, on which map updates are queued
+  // (hsm_update_by_scan returns before they ran): order the match behind the updates queued so far, and
+  // leave a marker the next update waits for, so that it does not rewrite the map under a running match.
+#if !defined(HSM_EXP_NO_XSTREAM_ORDER)  // (negative control of test_queued_updates_are_ordered_against_caller_streams)
+  if (h->upd_epoch != h->upd_epoch_ordered) {
+    if (!h->evt_updates) HIP_TRY(hipEventCreateWithFlags(&h->evt_updates, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->evt_updates, h->stream));
+    HIP_TRY(hipStreamWaitEvent(s, h->evt_updates, 0));
+    h->upd_epoch_ordered = h->upd_epoch;
+  }
+#endif
+  if (int rc = launch_match(h, P, hint, s)) return rc;
+  if (!h->evt_foreign) HIP_TRY(hipEventCreateWithFlags(&h->evt_foreign, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->evt_foreign, s));
+  h->foreign_match_pending = true;
+  return HSM_OK;
 }
 
 int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
@@ -935,6 +970,7 @@ int hsm_update_by_scan(hsm_ctx* h, const float pose_world[3], const float* pts_x
 static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_xy, int n, const float origo[2],
                        const float2* d_prestaged) {
   if (int rc = select_device(h)) return rc;
+  if (int rc = order_after_foreign_match(h)) return rc;
   const float zero[2] = {0.0f, 0.0f};
   const float* o = origo ? origo : zero;
   // level 0: the caller's container
@@ -1033,6 +1069,7 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
     return fail(HSM_ERR_INVALID, "hsm_update_by_scan_level: bad argument");
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
+  if (int rc = order_after_foreign_match(h)) return rc;
   const float zero[2] = {0.0f, 0.0f};
   if (int rc = ensure_scan_capacity(h->d_scan, h->d_scan_cap, (size_t)n)) return rc;
   if (n > 0)
@@ -1525,6 +1562,7 @@ int hsm_upload_level(hsm_ctx* h, int level, const float* logodds, const int* upd
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
   Level& L = h->levels[level];
+  if (int rc = order_after_foreign_match(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (logodds) HIP_TRY(hipMemcpy(L.d_logodds, logodds, L.cells() * sizeof(float), hipMemcpyHostToDevice));
   if (update_index)

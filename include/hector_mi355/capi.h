@@ -104,7 +104,8 @@ int hsm_match_trace(hsm_ctx* h, const float begin_world[3], const float* pts_xy,
  *   d_scan_offsets [B+1] CSR offsets into d_pts_xy in points, or NULL = every
  *                  hypothesis uses the same scan d_pts_xy[0 .. shared_n)
  *   d_out_pose     [B*3]       d_out_cov [B*9] or NULL
- * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous.
+ * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous.  The library orders it behind
+ * every map update queued on the context so far, and the next map update behind it (events; no host wait).
  * Does not touch the retained-scan state. */
 int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world,
                            const float* d_pts_xy, const int* d_scan_offsets, int shared_n,

@@ -850,3 +850,50 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
         assert np.array_equal(bits(pc), bits(pp)) and np.array_equal(bits(cc), bits(cp)), sizes[:3]
     po = np.stack([o.match(init[j], scans[j])[0] for j in range(8)])
     assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
+
+
+def test_queued_updates_are_ordered_against_caller_streams(capi, pyramid_scene, monkeypatch):
+    """hsm_match_batch_device runs on a CALLER-owned stream while map updates are queued on the context's own:
+    a batch match must see every update queued before it, and an update must not rewrite the map under a batch
+    match that is still running.  Interleaved tightly and compared with a context that blocks in every update."""
+    import torch
+    sc = pyramid_scene
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("HSM_ASYNC_UPDATE", "0")
+    ref = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    monkeypatch.delenv("HSM_ASYNC_UPDATE")
+    dut = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    for m in (ref, dut):
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+    B = 256
+    full = sc.query_scans[0]
+    init = np.repeat(sc.query_init[0:1], B, 0) + np.random.default_rng(3).uniform(-0.03, 0.03, (B, 3)).astype(np.float32) * np.float32([1, 1, 0.2])
+    d_init = torch.from_numpy(init).to(dev)
+    d_pts = torch.from_numpy(np.ascontiguousarray(full)).to(dev)
+    side = torch.cuda.Stream(device=dev)
+    from hector_slam_amd import synth
+    rng = np.random.default_rng(8)
+    sfac = float(np.float32(1.0) / np.float32(sc.resolution))
+    dense = [synth.make_scan(sc.world, sc.build_poses[t], 16384, sfac, rng) for t in range(30)]  # long-running updates
+    outs = {"ref": [], "dut": []}
+    for name, m in (("ref", ref), ("dut", dut)):
+        d_pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+        for t in range(30):
+            m.matchData(sc.build_poses[t], dense[t])                   # retains the coarse containers
+            m.updateByScan(dense[t], sc.build_poses[t])                # queued (dut) / blocking (ref); ~0.1 ms of GPU work
+            m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), 0, full.shape[0], d_pose.data_ptr(), 0,
+                                 side.cuda_stream)
+            if name == "ref":
+                side.synchronize()
+            if t % 3 == 2:                                             # leave some matches in flight under the next update
+                side.synchronize()
+                outs[name].append(d_pose.cpu().numpy().copy())
+        side.synchronize()
+        m.synchronize()
+        outs[name].append(d_pose.cpu().numpy().copy())
+    for a, b in zip(outs["ref"], outs["dut"]):
+        assert np.array_equal(bits(a), bits(b))
+    for lvl in range(sc.levels):
+        la, lb = ref.download_level(lvl), dut.download_level(lvl)
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1])
