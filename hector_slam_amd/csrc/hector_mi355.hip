@@ -99,6 +99,7 @@ struct hsm_ctx {
   unsigned long long upd_epoch = 0, upd_epoch_ordered = 0;
   hipEvent_t evt_updates = nullptr, evt_foreign = nullptr;
   bool foreign_match_pending = false;
+  hipStream_t foreign_stream = nullptr;
   bool async_update = true;
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
   float2* h_upd_pinned[2] = {nullptr, nullptr};
@@ -477,7 +478,14 @@ int select_device(const hsm_ctx* h) {
 // bumps the epoch the next such match orders itself behind
 int order_after_foreign_match(hsm_ctx* h) {
   if (h->foreign_match_pending) {
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->evt_foreign, 0));
+    // everything the caller has queued on that stream up to now (a superset of our matches)
+    if (!h->evt_foreign) HIP_TRY(hipEventCreateWithFlags(&h->evt_foreign, hipEventDisableTiming));
+    if (hipEventRecord(h->evt_foreign, h->foreign_stream) == hipSuccess) {
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->evt_foreign, 0));
+    } else {  // the caller destroyed the stream meanwhile: its work has been flushed or is covered by a device sync
+      (void)hipGetLastError();
+      HIP_TRY(hipDeviceSynchronize());
+    }
     h->foreign_match_pending = false;
   }
   ++h->upd_epoch;
@@ -711,8 +719,9 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   }
 #endif
   if (int rc = launch_match(h, P, hint, s)) return rc;
-  if (!h->evt_foreign) HIP_TRY(hipEventCreateWithFlags(&h->evt_foreign, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(h->evt_foreign, s));
+  // no marker here (an event record between back-to-back launches costs 2-3 us of kernel time each): the
+  // next writer of the map records one on this stream when it arrives (order_after_foreign_match)
+  h->foreign_stream = s;
   h->foreign_match_pending = true;
   return HSM_OK;
 }
