@@ -16,6 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SRC = os.path.join(_PKG, "csrc", "hector_mi355.hip")
 DEPS = [SRC, os.path.join(_PKG, "csrc", "gn_match.h"), os.path.join(_PKG, "csrc", "map_update.h"),
+        os.path.join(_PKG, "csrc", "libm_exact.h"),
         os.path.join(_ROOT, "include", "hector_mi355", "capi.h")]
 LIB = os.path.join(_PKG, "lib", "libhector_mi355.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",

@@ -27,6 +27,7 @@ from . import build as _build
 
 HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
+PARITY_FAST, PARITY_EXACT = 0, 1
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -51,6 +52,8 @@ SIGNATURES = {
     "hsm_set_update_factor_free": (_i, [_vp, _f]),
     "hsm_set_update_factor_occupied": (_i, [_vp, _f]),
     "hsm_on_map_updated": (_i, [_vp]),
+    "hsm_set_parity": (_i, [_vp, _i]),
+    "hsm_parity": (_i, [_vp]),
     "hsm_match": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
     "hsm_match_trace": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p, _f32p, _i, C.POINTER(_i)]),
     "hsm_match_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     "hsm_debug_set_update_serial": (_i, [_vp, _i, C.c_uint]),
     "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
+    "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
     "hsm_last_error": (C.c_char_p, []),
@@ -150,12 +154,21 @@ class MapRepMultiMap:
 
     def __init__(self, mapResolution: float, mapSizeX: int, mapSizeY: int, numDepth: int,
                  startCoords=(0.5, 0.5), device: int = -1, layout: int = LAYOUT_AUTO,
-                 waves_per_scan: int = 0):
+                 waves_per_scan: int = 0, parity: int | None = None):
         self._lib = load_library()
         self._h = _vp()
         opts = HsmOpts(device, layout, waves_per_scan)
         _check(self._lib.hsm_create(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords[0],
                                     startCoords[1], C.byref(opts), C.byref(self._h)), "hsm_create")
+        if parity is not None:
+            self.set_parity(parity)
+
+    def set_parity(self, mode: int):
+        """PARITY_FAST (tree summation) / PARITY_EXACT (the reference's beam-order fp32 chains: bit-identical poses)"""
+        _check(self._lib.hsm_set_parity(self._h, mode), "hsm_set_parity")
+
+    def parity(self) -> int:
+        return self._lib.hsm_parity(self._h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -393,7 +406,8 @@ class MapRepMultiMap:
         _check(self._lib.hsm_last_launch_config(self._h, cfg), "hsm_last_launch_config")
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
                 "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": max(int(cfg[4]), 0),
-                "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4]))}
+                "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4])),
+                "parity": "exact" if self.parity() == PARITY_EXACT else "fast"}
 
     # ---- parity / debug ---------------------------------------------------------------------
     def hessian_derivs(self, level, pose_map, pts_level):
@@ -415,6 +429,13 @@ class MapRepMultiMap:
         s, c = np.empty_like(x), np.empty_like(x)
         _check(self._lib.hsm_debug_sincos(self._h, x.size, x, s, c), "hsm_debug_sincos")
         return s, c
+
+    def debug_expf(self, x):
+        """device expf(x) and getGridProbability(x)"""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        e, p = np.empty_like(x), np.empty_like(x)
+        _check(self._lib.hsm_debug_expf(self._h, x.size, x, e, p), "hsm_debug_expf")
+        return e, p
 
     def debug_set_coop_barrier(self, value):
         _check(self._lib.hsm_debug_set_coop_barrier(self._h, int(value) & 0xffffffff), "hsm_debug_set_coop_barrier")

@@ -34,12 +34,15 @@
 // Numerics: built with -ffp-contract=off.  Every per-beam value (M, dM/dx, dM/dy,
 // rotDeriv and the nine products) is the same IEEE fp32 expression, in the same
 // order, as the reference; only the ORDER of the beam summation differs (strided
-// partial sums + tree instead of one sequential chain).  sin/cos/exp are evaluated
-// in fp64 and rounded once to fp32 (within 1 ulp of glibc's sinf/cosf/expf, which
-// the reference calls through the float overloads).
+// partial sums + tree instead of one sequential chain) -- and with HSM_PARITY_EXACT not
+// even that: the nine per-beam products are staged through LDS and summed by nine lanes
+// in beam order, i = 0 .. n-1, exactly the reference's fp32 chains.  sinf/cosf/expf are
+// glibc's algorithms operation for operation (libm_exact.h): identical bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
+
+#include "libm_exact.h"
 
 namespace hsm {
 
@@ -117,6 +120,14 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
 #endif
 }
 
+// The lane index, recomputed where it is used (two v_mbcnt) instead of being carried in a VGPR from the top of a
+// kernel that has none to spare: the volatile asm is neither hoisted nor merged with the threadIdx-derived value.
+__device__ __forceinline__ int lane_id_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // Texel address of cell (x, y) in the quad plane.
 // HSM_QUAD_TILE == 0 (default): row major, index = y*sizeX + x like the reference's grid -- one
 //   v_mad_u32_u24 per beam.
@@ -148,44 +159,10 @@ __device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y,
   oy = a.t1 + (a.l10 * x + a.l11 * y);
 }
 
-// sinf/cosf of the reference (float overloads): fp64 then one rounding.
-// Lean fp64 kernel instead of the generic libm sincos(double): Cody-Waite reduction by pi/2 in
-// two parts (the 33-bit head makes k*head exact for |k| < 2^20) and the classic degree-13/14
-// minimax polynomials on [-pi/4, pi/4] (fdlibm k_sin/k_cos coefficients, < 1 ulp in fp64).
-// ~25 fp64 instructions, a handful of live registers, no table, no slow path in the hot loop;
-// validated to round to the correctly rounded fp32 value (tests sweep it on the device).
-__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) {
-  double x = (double)th;
-  if (!(fabs(x) < 1048576.0)) {
-    // unrealistically large angles (the matcher normalises theta after every level):
-    // bring them into range first; inf/NaN fall through and yield NaN like libm
-    x = fmod(x, 6.283185307179586476925);
-  }
-  const double k = rint(x * 0.63661977236758134308);
-  double r = x - k * 1.57079632673412561417e+00;  // exact product
-  r = r - k * 6.07710050650619224932e-11;
-  const double z = r * r;
-  double ps = 1.58969099521155010221e-10;
-  ps = ps * z + -2.50507602534068634195e-08;
-  ps = ps * z + 2.75573137070700676789e-06;
-  ps = ps * z + -1.98412698298579493134e-04;
-  ps = ps * z + 8.33333333332248946124e-03;
-  ps = ps * z + -1.66666666666666324348e-01;
-  // x == +-0 keeps its sign (k = +-0 turns x - k*c into +0): sinf(-0.0f) = -0.0f
-  const double sr = (x == 0.0) ? x : r + r * z * ps;
-  double pc = -1.13596475577881948265e-11;
-  pc = pc * z + 2.08757232129817482790e-09;
-  pc = pc * z + -2.75573143513906633035e-07;
-  pc = pc * z + 2.48015872894767294178e-05;
-  pc = pc * z + -1.38888888888741095749e-03;
-  pc = pc * z + 4.16666666666666019037e-02;
-  const double cr = 1.0 - 0.5 * z + z * z * pc;
-  const int q = (int)k & 3;
-  const double sd = (q & 1) ? cr : sr;
-  const double cd = (q & 1) ? sr : cr;
-  s = (float)((q & 2) ? -sd : sd);
-  c = (float)(((q + 1) & 2) ? -cd : cd);
-}
+// sinf/cosf of the reference (float overloads; OccGridMapUtil.h:70-71 compile to one
+// sincosf call): glibc's algorithm operation for operation (libm_exact.h) -- identical bits for every
+// argument, ~20 fp64 operations, no table on the |theta| < 120 path the matcher lives on.
+__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) { libm::sincosf_glibc(th, s, c); }
 
 // util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
 __device__ __forceinline__ float normalize_angle(float angle) {
@@ -379,6 +356,59 @@ __device__ __forceinline__ float beam_accumulate(const LevelRegs& L, float ex, f
   return beam_finish(b, r, a, terms_out);
 }
 
+// ---- HSM_PARITY_EXACT: the reference's summation ORDER -------------------------------------------
+// getCompleteHessianDerivs (OccGridMapUtil.h:76-98) runs nine independent fp32 chains over the beams,
+// acc_t = acc_t + product_t(i) for i = 0 .. n-1.  The products are the same bits in every form of the
+// matcher; what the throughput forms change is the order of the additions (lane-strided partial sums +
+// tree), which is where the last-bit differences of H and dTr -- and, on scans where Gauss-Newton has
+// not settled, the visible pose differences -- come from.  The exact form keeps the reference's order:
+// a round of T consecutive beams (one per lane of the team) writes its 9 x T products to LDS, row t =
+// term t, and lane t of the team's first wave (t = 0..8) adds row t to its running sum left to right.
+// The nine chains run side by side in nine lanes; a round costs 64 dependent v_add_f32 per 64 beams on
+// top of the beam arithmetic (about 2.5x the instruction count of the fast form).  Padding lanes and
+// out-of-map beams contribute +-0, which leaves a running sum that started at +0 unchanged bit for bit.
+constexpr int kExactPad = 4;  // row stride T + 4 floats: rows stay 16-byte aligned, the nine chain lanes hit distinct banks
+
+// the nine products with the reference's signs (g = -G): dTr[0..2], H(0,0), H(1,1), H(2,2), H(0,1), H(0,2), H(1,2)
+__device__ __forceinline__ void beam_products(const BeamSample& b, const BeamRot& r, float pr[9]) {
+  const BeamTerms t = sample_finish(b);
+  const float Gx = t.G.x, Gy = t.G.y;
+  const float funVal = 1.0f - t.M;
+  const float rotDeriv = r.r.y * Gx - r.r.x * Gy;  // :87
+  pr[0] = -(Gx * funVal);
+  pr[1] = -(Gy * funVal);
+  pr[2] = rotDeriv * funVal;
+  pr[3] = Gx * Gx;
+  pr[4] = Gy * Gy;
+  pr[5] = rotDeriv * rotDeriv;
+  pr[6] = Gx * Gy;
+  pr[7] = -(Gx * rotDeriv);
+  pr[8] = -(Gy * rotDeriv);
+}
+
+// one round: beams base .. base+T-1 (thread tid holds beam base+tid).  `run` is meaningful in threads
+// 0..8 of the team only.  T == 64: one wavefront, whose LDS operations execute in program order -- no
+// barrier; T > 64: the team owns its workgroup and synchronises around the chain.
+template <int T>
+__device__ __forceinline__ float exact_round(const float pr[9], float* __restrict__ stage, int tid, float run) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) stage[t * (T + kExactPad) + tid] = pr[t];
+  if (T > 64) __syncthreads();
+  if (tid < 9) {
+    const float* row = stage + tid * (T + kExactPad);
+#pragma unroll 4
+    for (int j = 0; j < T; j += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + j);
+      run += v.x;
+      run += v.y;
+      run += v.z;
+      run += v.w;
+    }
+  }
+  if (T > 64) __syncthreads();
+  return run;
+}
+
 // Wavefront all-reduce without LDS traffic: four DPP steps inside each row of 16 lanes (the
 // cross-lane operand rides on the v_add itself), then the two gfx950 row/half swaps
 // (v_permlane16_swap, v_permlane32_swap).  Every lane ends with the same bits.
@@ -487,16 +517,18 @@ __device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, floa
 // independent and issue back to back (latency hiding by ILP, not only by occupancy).  The
 // per-lane summation order (ascending beam index) is the same as the memory loop's, so both
 // forms produce identical bits.  Longer scans (or BPL == 0) take the memory loop.
-template <int WPS, int SPB, int LAYOUT, int BPL>
+template <int WPS, int SPB, int LAYOUT, int BPL, bool EXACT = false>
 __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const MatchParams P) {
   static_assert(WPS == 1 || SPB == 1, "barrier-synchronised teams own their workgroup");
+  static_assert(!EXACT || BPL == 0, "the exact-order form streams the endpoints");
   constexpr int T = 64 * WPS;  // lanes per team
   __shared__ float red[2][WPS][9];
+  __shared__ float stage[EXACT ? SPB * 9 * (T + kExactPad) : 1];  // exact_round(): [team][term][beam of the round]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int team = wave / WPS;
   const int wit = wave - team * WPS;
-  const int scan = xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + team;
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + team);  // wave-uniform
   if (scan >= P.batch) return;  // whole team exits together
 
   int beg = 0, n = P.shared_n;
@@ -618,6 +650,32 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
                        : "memory");
         }
 #endif
+      } else if (EXACT) {
+        float run = 0.0f;
+        float* st = stage + team * 9 * (T + kExactPad);
+        for (int base = 0; base < n; base += T) {  // team-uniform trip count
+          const int i = base + tid_in_team;
+          const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products (see above)
+          BeamRot r;
+          const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+          float pr[9];
+          beam_products(b, r, pr);
+          run = exact_round<T>(pr, st, tid_in_team, run);
+        }
+        float t[9];
+        if (WPS == 1) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) t[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(run), k));
+        } else {
+          // threads 0..8 publish; the next write of red[] lies behind the >= 2 barriers of the next step's rounds
+          if (tid_in_team < 9) red[0][0][tid_in_team] = run;
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < 9; ++k) t[k] = red[0][0][k];
+        }
+        acc.d01 = f2{t[0], t[1]}; acc.d2 = t[2];
+        acc.hd = f2{t[3], t[4]}; acc.h22 = t[5];
+        acc.h01 = t[6]; acc.hr = f2{t[7], t[8]};
       } else {
         for (int i = tid_in_team; i < n; i += T) {
           const float2 p = pts[i];
@@ -626,8 +684,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
           beam_finish(b, r, acc);
         }
       }
-      team_allreduce9<WPS>(acc, red, buf, wit, lane);
-      buf ^= 1;
+      if (!EXACT) {
+        team_allreduce9<WPS>(acc, red, buf, wit, lane);
+        buf ^= 1;
+      }
       gn_solve_and_step(acc, ex, ey, eth);
       if (P.trace) {  // kernel-uniform; only the single-scan hook path sets it
         if (scan == 0 && lane == 0 && wit == 0) {
@@ -679,7 +739,8 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   __shared__ f2 lds_pts[SPB][BPL][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int scan = xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + wave;
+  // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + wave);
   if (scan >= P.batch) return;
   int beg = 0, n = P.shared_n;
   if (P.offsets) {
@@ -782,6 +843,16 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
                      :
                      : "memory");
       }
+      // a scan longer than the 64 * BPL cached beams (BPL comes from a host-side length HINT): the rest streams
+      // from memory like gn_match_kernel's loop, in the same per-lane order (wave-uniform trip count)
+#if !defined(HSM_EXP_NO_TAIL)
+      for (int i = 64 * BPL + (n > 64 * BPL ? lane_id_now() : 0); i < n; i += 64) {
+        const float2 p = pts[i];
+        BeamRot r;
+        const BeamSample b = beam_fetch<kLayoutQuad>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+        beam_finish(b, r, acc);
+      }
+#endif
       wave_allreduce9(acc);
       gn_solve_and_step(acc, ex, ey, eth);
     }
@@ -789,7 +860,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw2 = eth;
   }
-  if (lane == 0) {
+  if (lane_id_now() == 0) {
     P.out_pose[3 * scan + 0] = pw0;
     P.out_pose[3 * scan + 1] = pw1;
     P.out_pose[3 * scan + 2] = pw2;
@@ -935,11 +1006,12 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
 
 // ---- parity / debug kernels: one evaluation at a given map-frame pose ------------
 // H, dTr of one getCompleteHessianDerivs call (same device functions as the matcher)
-template <int LAYOUT>
+template <int LAYOUT, bool EXACT = false>
 __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const float2* __restrict__ pts,
                                                       int n, float ex, float ey, float eth,
                                                       float* out12 /* H[9] col-major, dTr[3] */) {
   __shared__ float red[2][16][9];
+  __shared__ float stage[EXACT ? 9 * (1024 + kExactPad) : 1];
   const int lane = threadIdx.x & 63;
   const int wit = threadIdx.x >> 6;
   float sinRot, cosRot;
@@ -947,11 +1019,30 @@ __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const 
   Acc9 acc;
   acc.zero();
   const LevelRegs R = level_regs<LAYOUT>(L);
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const float2 p = pts[i];
-    beam_accumulate<LAYOUT>(R, ex, ey, sinRot, cosRot, p.x, p.y, acc);
+  if (EXACT) {
+    const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+    float run = 0.0f;
+    for (int base = 0; base < n; base += 1024) {
+      const int i = base + (int)threadIdx.x;
+      const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);
+      BeamRot r;
+      const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x, p.y}, r);
+      float pr[9];
+      beam_products(b, r, pr);
+      run = exact_round<1024>(pr, stage, (int)threadIdx.x, run);
+    }
+    if (threadIdx.x < 9) red[0][0][threadIdx.x] = run;
+    __syncthreads();
+    acc.d01 = f2{red[0][0][0], red[0][0][1]}; acc.d2 = red[0][0][2];
+    acc.hd = f2{red[0][0][3], red[0][0][4]}; acc.h22 = red[0][0][5];
+    acc.h01 = red[0][0][6]; acc.hr = f2{red[0][0][7], red[0][0][8]};
+  } else {
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const float2 p = pts[i];
+      beam_accumulate<LAYOUT>(R, ex, ey, sinRot, cosRot, p.x, p.y, acc);
+    }
+    team_allreduce9<16>(acc, red, 0, wit, lane);
   }
-  team_allreduce9<16>(acc, red, 0, wit, lane);
   if (threadIdx.x == 0) {
     out12[0] = acc.hd.x; out12[1] = acc.h01; out12[2] = acc.hr.x;
     out12[3] = acc.h01; out12[4] = acc.hd.y; out12[5] = acc.hr.y;

@@ -95,11 +95,16 @@ struct hsm_ctx {
   // that reads the map afterwards is ordered behind them on `stream`.  Host endpoints are staged in one of
   // two pinned blocks, each guarded by the event of the update that last read it.
   bool texel_cache = true;          // env HSM_TEXEL_CACHE=0: plain gn_match_kernel for throughput launches too
-  // ordering between the context's stream (updates) and caller-owned streams (hsm_match_batch_device)
-  unsigned long long upd_epoch = 0, upd_epoch_ordered = 0;
+  // ordering between the context's stream (updates) and caller-owned streams (hsm_match_batch_device):
+  // per caller stream the update epoch it has been ordered behind, and whether it may still run a match
+  struct ForeignStream {
+    hipStream_t s;
+    unsigned long long ordered_epoch;
+    bool pending;
+  };
+  std::vector<ForeignStream> foreign;
+  unsigned long long upd_epoch = 1;
   hipEvent_t evt_updates = nullptr, evt_foreign = nullptr;
-  bool foreign_match_pending = false;
-  hipStream_t foreign_stream = nullptr;
   bool async_update = true;
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
   float2* h_upd_pinned[2] = {nullptr, nullptr};
@@ -110,7 +115,7 @@ struct hsm_ctx {
   bool spin_wait = true;       // single-scan matches: poll the kernel's completion word (env HSM_SPIN_WAIT=0: off)
   unsigned done_seq = 0;
   std::vector<Level> levels;
-  std::mutex mu;
+  mutable std::mutex mu;
   hipStream_t stream = nullptr;
   // single-scan staging (device) + pinned result
   float2* d_scan = nullptr;
@@ -150,6 +155,7 @@ struct hsm_ctx {
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
+  bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -318,8 +324,28 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
+// HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
+template <int WPS, int SPB>
+int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+  const int block = 64 * WPS * SPB;
+  const int grid = (P.batch + SPB - 1) / SPB;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, 0, true>), dim3(grid), dim3(block), 0, stream, P);
+  else
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, 0, true>), dim3(grid), dim3(block), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = WPS;
+  h->last_cfg[2] = block;
+  h->last_cfg[3] = grid;
+  h->last_cfg[4] = 0;
+  h->last_cfg[5] = 0;
+  return HSM_OK;
+}
+
 template <int WPS, int SPB>
 int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  if (h->exact) return launch_match_exact<WPS, SPB>(h, P, stream);
   const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
   if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
   if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
@@ -477,17 +503,20 @@ int select_device(const hsm_ctx* h) {
 // every writer of the map queues behind a batch match that a caller-owned stream may still be running, and
 // bumps the epoch the next such match orders itself behind
 int order_after_foreign_match(hsm_ctx* h) {
-  if (h->foreign_match_pending) {
-    // everything the caller has queued on that stream up to now (a superset of our matches)
+  for (hsm_ctx::ForeignStream& f : h->foreign) {
+    if (!f.pending) continue;
+    // everything the caller has queued on that stream up to now (a superset of our matches); the wait captures
+    // the event's state at this call, so one event serves all streams in turn
     if (!h->evt_foreign) HIP_TRY(hipEventCreateWithFlags(&h->evt_foreign, hipEventDisableTiming));
-    if (hipEventRecord(h->evt_foreign, h->foreign_stream) == hipSuccess) {
+    if (hipEventRecord(h->evt_foreign, f.s) == hipSuccess) {
       HIP_TRY(hipStreamWaitEvent(h->stream, h->evt_foreign, 0));
     } else {  // the caller destroyed the stream meanwhile: its work has been flushed or is covered by a device sync
       (void)hipGetLastError();
       HIP_TRY(hipDeviceSynchronize());
     }
-    h->foreign_match_pending = false;
+    f.pending = false;
   }
+  if (h->foreign.size() > 16) h->foreign.clear();  // nothing pending any more: forget streams callers may have destroyed
   ++h->upd_epoch;
   return HSM_OK;
 }
@@ -546,6 +575,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
   if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
+  if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -675,6 +705,15 @@ int hsm_set_update_factor_occupied(hsm_ctx* h, float f) {
 }
 int hsm_on_map_updated(hsm_ctx* h) { return h ? HSM_OK : fail(HSM_ERR_INVALID, "null context"); }
 
+int hsm_set_parity(hsm_ctx* h, int mode) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (mode != HSM_PARITY_FAST && mode != HSM_PARITY_EXACT) return fail(HSM_ERR_INVALID, "hsm_set_parity: unknown mode");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->exact = mode == HSM_PARITY_EXACT;
+  return HSM_OK;
+}
+int hsm_parity(const hsm_ctx* h) { return (h && h->exact) ? HSM_PARITY_EXACT : HSM_PARITY_FAST; }
+
 int hsm_gn_iterations_per_match(const hsm_ctx* h) {
   return h ? 6 + 4 * ((int)h->levels.size() - 1) : 0;
 }
@@ -702,27 +741,34 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   P.shared_n = shared_n;
   P.out_pose = d_out_pose;
   P.out_cov = d_out_cov;
-  // per-scan length is only known on the device for CSR input; shared_n doubles as the
-  // sizing hint there (callers pass the typical beams per scan, 0 = unknown)
+  // per-scan length is only known on the device for CSR input; shared_n doubles as the sizing HINT there
+  // (callers pass the typical beams per scan, 0 = unknown).  It only picks the kernel form: every form handles
+  // scans longer than the hint (the beams beyond the register/LDS-resident ones stream from memory).
   const int hint = shared_n > 0 ? shared_n : 1081;
   hipStream_t s = (hipStream_t)stream;
   if (s == h->stream) return launch_match(h, P, hint, s);
   // A caller-owned stream is not ordered against the context's own one, on which map updates are queued
   // (hsm_update_by_scan returns before they ran): order the match behind the updates queued so far, and
   // leave a marker the next update waits for, so that it does not rewrite the map under a running match.
+  hsm_ctx::ForeignStream* fs = nullptr;
+  for (hsm_ctx::ForeignStream& f : h->foreign)
+    if (f.s == s) fs = &f;
+  if (!fs) {
+    h->foreign.push_back({s, 0ull, false});
+    fs = &h->foreign.back();
+  }
 #if !defined(HSM_EXP_NO_XSTREAM_ORDER)  // (negative control of test_queued_updates_are_ordered_against_caller_streams)
-  if (h->upd_epoch != h->upd_epoch_ordered) {
+  if (fs->ordered_epoch != h->upd_epoch) {  // THIS stream has not been ordered behind the latest map writes yet
     if (!h->evt_updates) HIP_TRY(hipEventCreateWithFlags(&h->evt_updates, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(h->evt_updates, h->stream));
     HIP_TRY(hipStreamWaitEvent(s, h->evt_updates, 0));
-    h->upd_epoch_ordered = h->upd_epoch;
+    fs->ordered_epoch = h->upd_epoch;
   }
 #endif
   if (int rc = launch_match(h, P, hint, s)) return rc;
   // no marker here (an event record between back-to-back launches costs 2-3 us of kernel time each): the
-  // next writer of the map records one on this stream when it arrives (order_after_foreign_match)
-  h->foreign_stream = s;
-  h->foreign_match_pending = true;
+  // next writer of the map records one on every stream with a pending match (order_after_foreign_match)
+  fs->pending = true;
   return HSM_OK;
 }
 
@@ -835,8 +881,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   const unsigned seq = ++h->done_seq;
   P.done_flag = h->spin_wait ? reinterpret_cast<unsigned*>(hs_dev + kDoneFlagOff) : nullptr;
   P.done_seq = seq;
-  if (n >= h->coop_min_beams && h->wps_override == 0) {
-    // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h)
+  if (n >= h->coop_min_beams && h->wps_override == 0 && !h->exact) {
+    // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
+    // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
     int K = (n + 1023) / 1024;  // ~4 beams per lane
     if (const char* env = getenv("HSM_COOP_K")) K = atoi(env);
     if (K > 64) K = 64;
@@ -879,7 +926,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
 // once (register resident), device memory otherwise
 static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, size_t& d_cap, const float2** out) {
   // (a dense scan for the multi-workgroup matcher is re-read every GN step: it must live in device memory)
-  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && (n < h->coop_min_beams || h->wps_override != 0)) {
+  // (and so does the exact-order form)
+  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !h->exact &&
+      (n < h->coop_min_beams || h->wps_override != 0)) {
     if ((size_t)n > h->h_scan_pinned_cap) {
       if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
       h->h_scan_pinned = nullptr;
@@ -1552,6 +1601,7 @@ int hsm_world_coords_pose(const hsm_ctx* h, int level, const float m[3], float w
 }
 int hsm_update_index(const hsm_ctx* h, int level) {
   if (valid_level(h, level)) return -1;
+  std::lock_guard<std::mutex> lk(h->mu);  // read by the facade's publisher thread while the scan thread updates
   return h->levels[level].last_update_index;
 }
 
@@ -1654,7 +1704,14 @@ int hsm_hessian_derivs(hsm_ctx* h, int level, const float pose_map[3], const flo
   if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
   const LevelView v = level_view(h->levels[level], 1.0f, 1);
   float* d_out = h->d_small + 16;
-  if (h->layout == kLayoutPlane)
+  if (h->exact) {
+    if (h->layout == kLayoutPlane)
+      hipLaunchKernelGGL((gn_eval_kernel<kLayoutPlane, true>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
+                         pose_map[0], pose_map[1], pose_map[2], d_out);
+    else
+      hipLaunchKernelGGL((gn_eval_kernel<kLayoutQuad, true>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
+                         pose_map[0], pose_map[1], pose_map[2], d_out);
+  } else if (h->layout == kLayoutPlane)
     hipLaunchKernelGGL((gn_eval_kernel<kLayoutPlane>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
                        pose_map[0], pose_map[1], pose_map[2], d_out);
   else
@@ -1705,6 +1762,26 @@ int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial) {
   if (int rc = valid_level(h, level)) return rc;
   std::lock_guard<std::mutex> lk(h->mu);
   h->levels[level].serial = serial;
+  return HSM_OK;
+}
+
+int hsm_debug_expf(hsm_ctx* h, int n, const float* x, float* out_exp, float* out_prob) {
+  if (!h || n < 0 || (n > 0 && (!x || !out_exp || !out_prob))) return fail(HSM_ERR_INVALID, "hsm_debug_expf: bad argument");
+  if (n == 0) return HSM_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  float* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 3 * (size_t)n * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(expf_debug_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, n, d + n, d + 2 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_exp, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_prob, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(HSM_ERR_HIP, "hsm_debug_expf", e);
   return HSM_OK;
 }
 

@@ -87,10 +87,10 @@ struct UpdateParams {
   int x0, y0, x1, y1;       // inclusive cell bounding box of everything this scan can touch
 };
 
-// GridMapLogOddsFunctions::getGridProbability (GridMapLogOdds.h:163-166);
-// expf evaluated in fp64 and rounded once.
+// GridMapLogOddsFunctions::getGridProbability (GridMapLogOdds.h:163-166): exp(float) is glibc's expf
+// there; libm_exact.h reproduces it bit for bit
 __device__ __forceinline__ float grid_probability(float log_odds) {
-  const float odds = (float)exp((double)log_odds);
+  const float odds = libm::expf_glibc(log_odds);
   return odds / (odds + 1.0f);
 }
 
@@ -123,6 +123,10 @@ __device__ __forceinline__ BeamLine beam_line(const UpdateParams& P, int i) {
   b.y1 = (int)ey;
   const int x0 = P.bx, y0 = P.by;
   b.valid = !(x0 == b.x1 && y0 == b.y1);  // :158
+  // A NaN endpoint: x86's cvttss2si makes it INT_MIN, which fails the bounds test below and drops the beam; this
+  // device's conversion makes it 0, a VALID cell.  The same finite-range test the host's bounding box uses
+  // (update_level) keeps both consistent with the reference; every finite coordinate it rejects fails :176-188 anyway.
+  if (!(ex > -2.0f && ex < (float)P.lv.sx + 2.0f && ey > -2.0f && ey < (float)P.lv.sy + 2.0f)) b.valid = false;
   // both endpoints inside the map, :176-188
   if ((x0 < 0) || (x0 >= P.lv.sx) || (y0 < 0) || (y0 >= P.lv.sy)) b.valid = false;
   if ((b.x1 < 0) || (b.x1 >= P.lv.sx) || (b.y1 < 0) || (b.y1 >= P.lv.sy)) b.valid = false;
@@ -285,6 +289,7 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
       const unsigned int word = P.lv.occ_bits[c >> 5];
       occ = (word >> (c & 31u)) & 1u;
       ko = occ ? P.lv.key_occ[c] : 0u;
+      occ = occ && (ko >> 16) == P.serial;  // (a bit without this scan's key cannot occur; cheap to insist)
       if (word != 0u && (c & 31u) == 0) P.lv.occ_bits[c >> 5] = 0u;
     } else {
       // every set bit lies inside the box, so zeroing each word that overlaps it is exact
@@ -547,6 +552,14 @@ __global__ void __launch_bounds__(1024) ingest_point_cloud_kernel(CloudIngestPar
     __syncthreads();
   }
   if (threadIdx.x == 0) *P.out_n = base;
+}
+
+// device expf / getGridProbability sweep for the parity tests
+__global__ void expf_debug_kernel(const float* __restrict__ x, int n, float* __restrict__ e, float* __restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  e[i] = libm::expf_glibc(x[i]);
+  p[i] = grid_probability(x[i]);
 }
 
 __global__ void rebuild_prob_kernel(LevelRW L) {

@@ -55,6 +55,15 @@ typedef struct hsm_opts {
   int waves_per_scan;  /* 0 = auto (env HSM_WPS overrides), else 1,2,4,8,16 */
 } hsm_opts;
 
+/* summation order of the Hessian / gradient reduction (OccGridMapUtil.h:76-98):
+ *   FAST   lane-strided partial sums + tree: the reference's per-beam products, summed in another order;
+ *          poses within 1e-4 m / 1e-4 rad of the reference wherever its Gauss-Newton iteration has settled
+ *   EXACT  the reference's order, beam 0 .. n-1 in nine sequential fp32 chains: H, dTr, every GN step and
+ *          the final pose are BIT-IDENTICAL to the reference CPU matcher on every scan (about 2.5x the
+ *          instructions per GN iteration).  sinf/cosf/expf are glibc's algorithms in both modes.
+ * Default FAST; env HSM_PARITY=exact selects EXACT at hsm_create, hsm_set_parity switches at run time. */
+enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1 };
+
 /* ---- construction ---------------------------------------------------------
  * replaces: MapRepMultiMap::MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, numDepth,
  *           startCoords, draw, debug)                    HSL/slam_main/MapRepMultiMap.h:48-72
@@ -78,6 +87,9 @@ int hsm_set_update_factor_occupied(hsm_ctx* h, float occupied_factor);
  * The device probability texels are refreshed eagerly by update_by_scan, so this
  * only has to exist; it returns HSM_OK. */
 int hsm_on_map_updated(hsm_ctx* h);
+/* no reference counterpart: selects HSM_PARITY_FAST / HSM_PARITY_EXACT for all later matches of the context */
+int hsm_set_parity(hsm_ctx* h, int mode);
+int hsm_parity(const hsm_ctx* h);
 
 /* ---- the hot path -----------------------------------------------------------
  * replaces: MapRepMultiMap::matchData(beginEstimateWorld, dataContainer, covMatrix)
@@ -103,9 +115,12 @@ int hsm_match_trace(hsm_ctx* h, const float begin_world[3], const float* pts_xy,
  *   d_begin_world  [B*3]       d_pts_xy [total*2]
  *   d_scan_offsets [B+1] CSR offsets into d_pts_xy in points, or NULL = every
  *                  hypothesis uses the same scan d_pts_xy[0 .. shared_n)
+ *   shared_n       with CSR offsets: a sizing HINT (typical beams per scan, 0 = unknown -> 1081); it selects
+ *                  the kernel form only -- scans longer than the hint are matched correctly, just slower
  *   d_out_pose     [B*3]       d_out_cov [B*9] or NULL
  * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous.  The library orders it behind
- * every map update queued on the context so far, and the next map update behind it (events; no host wait).
+ * every map update queued on the context so far, and the next map update behind it (events; no host wait),
+ * per caller stream: matches may be in flight on several caller-owned streams at once.
  * Does not touch the retained-scan state. */
 int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world,
                            const float* d_pts_xy, const int* d_scan_offsets, int shared_n,
@@ -266,8 +281,10 @@ int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial);
 /* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by
  * workgroups x GN steps per dense match and wraps at 2^32) */
 int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value);
-/* device sin/cos (fp64-evaluated, rounded once to fp32) of n angles -- numerics test hook */
+/* device sincosf of n angles (glibc's algorithm, csrc/libm_exact.h) -- numerics test hook */
 int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
+/* device expf(x) and getGridProbability(x) = e/(e+1) of n values -- numerics test hook */
+int hsm_debug_expf(hsm_ctx* h, int n, const float* x, float* out_exp, float* out_prob);
 
 /* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
 int hsm_gn_iterations_per_match(const hsm_ctx* h);

@@ -170,18 +170,11 @@ public:
     const float origo[2] = {o[0], o[1]};
     const float* pts = n > 0 ? &dataContainer.getVecEntry(0)[0] : 0;
 
-    // the device planes are written outside the lockers (nobody else reads them); the lockers
-    // guard the host mirrors, which is what the map publisher thread reads
+    // The reference takes each level's locker around its update (MapProcContainer.h:103-116) because the update
+    // writes the cells the publisher thread reads.  Here the update writes DEVICE planes that nobody else reads;
+    // the cells the publisher reads are the host mirrors, and those are only written by refreshMirror() -- under
+    // the level's locker.  So a reader still sees either the state before or after an update, never one in between.
     hsm_update_by_scan(ctx, pose, pts, n, origo);
-
-    // the lockers are honoured exactly where the reference takes them (MapProcContainer.h:103-116): readers
-    // of the host mirror see either the state before or after this update, never a refresh in between
-    for (size_t i = 0; i < mirrors.size(); ++i) {
-      if (mutexes[i]) {
-        mutexes[i]->lockMap();
-        mutexes[i]->unlockMap();
-      }
-    }
   }
 
   virtual void setUpdateFactorFree(float free_factor)
@@ -257,7 +250,11 @@ protected:
   {
     std::lock_guard<std::mutex> lk(mirrorMutex);
     GridMap& m = *mirrors[level];
-    if (m.getUpdateIndex() == hsm_update_index(ctx, level) && !forceRefresh[level]) {
+    // the update counter is read ONCE, before the dirty box is taken: an update the scan thread queues after this
+    // point may or may not be inside the box fetched below, so the mirror only claims to be as new as `target`
+    // and the next getGridMap() looks again
+    const int target = hsm_update_index(ctx, level);
+    if (m.getUpdateIndex() == target && !forceRefresh[level]) {
       return;  // nothing happened on the device since the last refresh
     }
     forceRefresh[level] = false;
@@ -272,7 +269,7 @@ protected:
       LogOddsCell* first = &m.getCell(bb[0], bb[1]);
       hsm_download_cells(ctx, level, bb[0], bb[1], bb[2], bb[3], first, m.getSizeX());
     }
-    while (m.getUpdateIndex() < hsm_update_index(ctx, level)) {
+    while (m.getUpdateIndex() < target) {
       m.setUpdated();
     }
     if (mutexes[level]) {

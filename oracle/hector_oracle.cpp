@@ -858,4 +858,18 @@ int ho_pose_difference_larger_than(const float p1[3], const float p2[3], float d
   return pose_difference_larger_than(p1, p2, d, a) ? 1 : 0;
 }
 
+void ho_libm_sincosf(int n, const float* x, float* out_sin, float* out_cos) {
+  for (int i = 0; i < n; ++i) {
+    sincosf(x[i], &out_sin[i], &out_cos[i]);  // what GCC makes of the reference's sin(pose[2]), cos(pose[2]) pair
+  }
+}
+void ho_libm_expf(int n, const float* x, float* out_exp, float* out_prob) {
+  for (int i = 0; i < n; ++i) {
+    const float odds = expf(x[i]);
+    out_exp[i] = odds;
+    out_prob[i] = odds / (odds + 1.0f);
+  }
+}
+
+
 }  // extern "C"

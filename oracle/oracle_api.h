@@ -84,6 +84,12 @@ void ORF(proc_last_pose)(void* h, float pose[3], float cov[9]);
 float ORF(normalize_angle)(float a);
 int ORF(pose_difference_larger_than)(const float p1[3], const float p2[3], float dist, float ang);
 
+/* the host libm calls of the path, as this process links them (glibc sincosf / expf through their ifunc
+ * variants), for n arguments each -- the device's csrc/libm_exact.h is checked against these bit for bit.
+ * out_prob = getGridProbability (GridMapLogOdds.h:163-166): odds = expf(x); odds / (odds + 1.0f). */
+void ORF(libm_sincosf)(int n, const float* x, float* out_sin, float* out_cos);
+void ORF(libm_expf)(int n, const float* x, float* out_exp, float* out_prob);
+
 /* ---- rows next to the path, restated from the ROS node hector_mapping/src/HectorMappingRos.cpp */
 /* f2: publishMap's cell loop (:449-468): -1 unknown, 0 if isFree (logOdds < 0), 100 if isOccupied (> 0);
  * GridMapLogOdds.h:76-84 */

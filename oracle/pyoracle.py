@@ -76,6 +76,8 @@ def _load(kind: str):
                                          f, f, f, f, f, _f32p, _f32p]),
         "project_laser": (i, [_f32p, i, f, f, f, f, C.c_double, _f32p]),
         "normalize_angle": (f, [f]),
+        "libm_sincosf": (None, [i, _f32p, _f32p, _f32p]),
+        "libm_expf": (None, [i, _f32p, _f32p, _f32p]),
         "pose_difference_larger_than": (i, [_f32p, _f32p, f, f]),
     }
     ns = {}
@@ -113,6 +115,22 @@ def ray_distances(kind, grid, origin_xy, resolution, begin_world, end_world):
                        b.reshape(-1) if b.size else np.zeros(2, np.float32), e.reshape(-1) if e.size else
                        np.zeros(2, np.float32), dist, hit.reshape(-1) if b.size else np.zeros(2, np.float32))
     return dist, hit
+
+
+def libm_sincosf(x, kind="ho"):
+    """host sinf/cosf (glibc, as the reference links them) of an array"""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    s, c = np.empty_like(x), np.empty_like(x)
+    _load(kind)["libm_sincosf"](x.size, x, s, c)
+    return s, c
+
+
+def libm_expf(x, kind="ho"):
+    """host expf and getGridProbability of an array"""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    e, p = np.empty_like(x), np.empty_like(x)
+    _load(kind)["libm_expf"](x.size, x, e, p)
+    return e, p
 
 
 class Oracle:

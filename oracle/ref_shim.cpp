@@ -359,4 +359,18 @@ int hr_project_laser(const float* ranges, int n, float angle_min, float angle_in
   return count;
 }
 
+void hr_libm_sincosf(int n, const float* x, float* out_sin, float* out_cos) {
+  for (int i = 0; i < n; ++i) {
+    sincosf(x[i], &out_sin[i], &out_cos[i]);  // what GCC makes of the reference's sin(pose[2]), cos(pose[2]) pair
+  }
+}
+void hr_libm_expf(int n, const float* x, float* out_exp, float* out_prob) {
+  for (int i = 0; i < n; ++i) {
+    const float odds = expf(x[i]);
+    out_exp[i] = odds;
+    out_prob[i] = odds / (odds + 1.0f);
+  }
+}
+
+
 }  // extern "C"

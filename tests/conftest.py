@@ -13,6 +13,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _have_gpu() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a machine without a HIP device SKIPS the gpu-marked tests (reported as skipped, not
+    passed); with `-m gpu` they run and fail loudly there -- the product has no CPU path to fall back to."""
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in config.getoption("-m"):
+        return
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device (gpu-marked test; run with -m gpu on the GPU box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def oracle_kinds():
+    """CPU checkers to parametrise over: the restatement always, the reference-compiled one where its prebuilt
+    library is present (the build container and, via the snapshot, the GPU box)."""
+    from oracle import pyoracle
+    return ["ho"] + (["hr"] if pyoracle.available("hr") else [])
+
+
 def bits(a):
     """uint32 view for bit-exact float comparisons."""
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

@@ -1,0 +1,289 @@
+"""HSM_PARITY_EXACT: the GPU matcher is BIT-IDENTICAL to the reference CPU matcher -- H, dTr, every Gauss-Newton
+step, the pose and the covariance -- on every scan, settled or not.
+
+What makes that possible: the per-beam products were bit-exact all along; sinf / cosf / expf
+are glibc's algorithms operation for operation (csrc/libm_exact.h); and in this mode the nine sums of
+getCompleteHessianDerivs (OccGridMapUtil.h:76-98) run in the reference's order, beam 0 .. n-1, as nine sequential
+fp32 chains (gn_match.h exact_round).  So no tolerance appears in this file: every comparison is on uint32 views.
+
+Runs against both CPU checkers where oracle/_ref/libhector_ref.so is present: "ho" (restatement) and "hr" (the
+unmodified reference headers).
+"""
+import numpy as np
+import pytest
+
+from conftest import bits, make_oracle, oracle_kinds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a HIP device"
+    from hector_slam_amd import capi as m
+    m.load_library()
+    return m
+
+
+@pytest.fixture(scope="module", params=oracle_kinds())
+def kind(request):
+    return request.param
+
+
+def same(a, b):
+    return np.array_equal(bits(a), bits(b))
+
+
+def exact_gpu(capi, sc, o=None, **kw):
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, parity=capi.PARITY_EXACT, **kw)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    assert g.parity() == capi.PARITY_EXACT
+    if o is None:
+        g.build_map(sc.build_poses, sc.build_scans)
+    else:
+        for lvl in range(sc.levels):
+            g.upload_level(lvl, *o.download_level(lvl))
+    return g
+
+
+@pytest.fixture(scope="module")
+def pyr(capi, oracle_mod, pyramid_scene, kind):
+    o = make_oracle(oracle_mod, kind, pyramid_scene)
+    return exact_gpu(capi, pyramid_scene), o  # the GPU builds its own map with its own update kernels
+
+
+def test_hessian_and_gradient_bit_identical(pyr, pyramid_scene):
+    """one getCompleteHessianDerivs evaluation: all 9 + 3 numbers equal the reference's, every level"""
+    g, o = pyr
+    sc = pyramid_scene
+    for q in range(len(sc.query_scans)):
+        for lvl in range(sc.levels):
+            pts = sc.query_scans[q] * np.float32(1.0 / 2 ** lvl)
+            pm = o.map_coords_pose(lvl, sc.query_init[q])
+            Hg, dg = g.hessian_derivs(lvl, pm, pts)
+            Ho, do = o.hessian_derivs(lvl, pm, pts)
+            assert same(Hg, Ho) and same(dg, do), (q, lvl)
+
+
+@pytest.mark.parametrize("layout", ["quad", "plane"])
+@pytest.mark.parametrize("wps", [0, 1, 2, 4, 8, 16])
+def test_single_scan_match_bit_identical_for_every_team_width(capi, oracle_mod, pyramid_scene, kind, wps, layout):
+    """hsm_match through 1..16 wavefronts per scan: pose AND covariance bit-identical (the team width changes how the
+    beams are dealt to lanes, not the order of the nine sums)"""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o, waves_per_scan=wps, layout=capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE)
+    for q in range(len(sc.query_scans)):
+        pg, cg = g.matchData(sc.query_init[q], sc.query_scans[q])
+        po, co = o.match(sc.query_init[q], sc.query_scans[q])
+        assert same(pg, po) and same(cg, co), (q, pg, po)
+    full = sc.query_scans[2]
+    for n in (40, 63, 64, 65, 127, 129, 1000, 1023, 1025):
+        pts = full[np.linspace(0, full.shape[0] - 1, n).astype(int)]
+        pg, cg = g.matchData(sc.query_init[2], pts)
+        po, co = o.match(sc.query_init[2], pts)
+        assert same(pg, po) and same(cg, co), n
+    cov_in = np.arange(9, dtype=np.float32)
+    p, c = g.matchData(sc.query_init[0], np.zeros((0, 2), np.float32), cov_in)  # empty scan: pass-through
+    assert same(p, sc.query_init[0]) and same(c, cov_in)
+
+
+def test_config1_single_level_five_iterations(capi, oracle_mod, small_scene, kind):
+    """BASELINE configs[0]: 181 beams, 256^2 single-resolution map, 5 GN iterations"""
+    sc = small_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc)
+    for q in range(len(sc.query_scans)):
+        for it in (0, 1, 5):
+            pg, cg = g.match_level(0, sc.query_init[q], sc.query_scans[q], it)
+            po, co = o.match_level(0, sc.query_init[q], sc.query_scans[q], it)
+            assert same(pg, po) and same(cg, co), (q, it)
+
+
+def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
+    """starts far outside the basin (angle clamp active, Gauss-Newton not settling) and a start at the map border
+    (80 % of the beams outside the map, cond(H) ~ 1e10): chaotic for any other summation order, identical here"""
+    g, o = pyr
+    sc = pyramid_scene
+    rng = np.random.default_rng(7)
+    for q in range(8):
+        init = sc.query_truth[q] + np.array([rng.uniform(-.5, .5), rng.uniform(-.5, .5), rng.uniform(-.5, .5)], np.float32)
+        pg, cg = g.matchData(init, sc.query_scans[q])
+        po, co = o.match(init, sc.query_scans[q])
+        assert same(pg, po) and same(cg, co), q
+    far = np.array([11.5, 9.0, 0.3], np.float32)
+    pts = sc.query_scans[0]
+    for it in (0, 3):
+        pg, cg = g.match_level(0, far, pts, it)
+        po, co = o.match_level(0, far, pts, it)
+        assert same(pg, po) and same(cg, co), it
+
+
+def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind):
+    """the batched entry (one wavefront per scan): ragged CSR batch with empty, tiny, regular and over-long scans"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o)
+    rng = np.random.default_rng(5)
+    scans, init = [], []
+    for q in range(len(sc.query_scans)):
+        full = sc.query_scans[q]
+        # (fragments of a few beams make H singular: the reference then casts NaN coordinates to int and crashes)
+        n = [full.shape[0], 0, 40, 64, 65, 700, 1081][q % 7]
+        scans.append(full[np.linspace(0, full.shape[0] - 1, min(n, full.shape[0])).astype(int)] if n else full[:0])
+        init.append(sc.query_init[q])
+    long_scan = np.concatenate([sc.query_scans[3], sc.query_scans[3][::2] + np.float32(0.01)])  # 1622 beams > 64 * 17
+    scans.append(long_scan)
+    init.append(sc.query_init[3])
+    init = np.stack(init)
+    pts, offs = synth.pack_scans(scans)
+    pb, cb = g.match_batch(init, pts, offs)
+    for q, sq in enumerate(scans):
+        po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
+        assert same(pb[q], po), (q, sq.shape[0])
+        if sq.shape[0]:
+            assert same(cb[q], co), q
+    # shared-scan mode: pose hypotheses of ONE scan
+    hyp = np.repeat(sc.query_init[3:4], 9, 0) + np.linspace(-0.05, 0.05, 9, dtype=np.float32)[:, None]
+    ph, ch = g.match_batch(hyp, sc.query_scans[3], None)
+    for k in range(9):
+        po, co = o.match(hyp[k], sc.query_scans[3])
+        assert same(ph[k], po) and same(ch[k], co), k
+
+
+def test_dense_scan_bit_identical(capi, oracle_mod, pyramid_scene, kind):
+    """16k-beam scans (configs[4] shape): the exact form keeps the scan on one 16-wave workgroup"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o)
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    rng = np.random.default_rng(77)
+    for n_beams in (4096, 16384):
+        for q in range(2):
+            pts = synth.make_scan(sc.world, sc.query_truth[q], n_beams, s, rng)
+            pg, cg = g.matchData(sc.query_init[q], pts)
+            assert g.last_launch_config()["waves_per_scan"] == 16
+            po, co = o.match(sc.query_init[q], pts)
+            assert same(pg, po) and same(cg, co), (n_beams, q)
+
+
+def test_slam_loop_from_empty_map_bit_identical(capi, oracle_mod, pyramid_scene, kind):
+    """HectorSlamProcessor::update from an EMPTY map, 30 scans: identical poses at every step, hence identical update
+    decisions and bit-identical maps on all levels at the end -- the whole SLAM state, not just one match"""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc, build=False)
+    o.proc_set_thresholds(0.05, 0.02)
+    p = capi.HectorSlamProcessor(sc.resolution, sc.map_size, sc.map_size, (0.5, 0.5), sc.levels, parity=capi.PARITY_EXACT)
+    p.setUpdateFactorFree(0.4)
+    p.setUpdateFactorOccupied(0.9)
+    p.setMapUpdateMinDistDiff(0.05)
+    p.setMapUpdateMinAngleDiff(0.02)
+    hint = sc.build_poses[0].copy()
+    for t in range(30):
+        o.proc_update(sc.build_scans[t], hint)
+        p.update(sc.build_scans[t], hint)
+        po, co = o.proc_last_pose()
+        assert same(p.getLastScanMatchPose(), po) and same(p.getLastScanMatchCovariance(), co), t
+        hint = po + (sc.build_poses[t + 1] - sc.build_poses[t])
+    for lvl in range(sc.levels):
+        a, b = p.mapRep.download_level(lvl), o.download_level(lvl)
+        assert same(a[0], b[0]) and np.array_equal(a[1], b[1]), lvl
+
+
+def test_randomised_geometries_bit_identical(capi, oracle_mod, kind):
+    """odd map sizes, 1-4 levels, off-centre start coordinates, rooms larger than the map, maps made of one or two
+    scans, laser origins off the robot centre: no 'settled' or 'well conditioned' predicate -- every step is equal"""
+    from hector_slam_amd import synth
+    rng = np.random.default_rng(2024)
+    for trial in range(6):
+        size = int(rng.choice([96, 125, 250, 333, 512]))
+        levels = int(rng.integers(1, 5))
+        while (size >> (levels - 1)) < 8:
+            levels -= 1
+        res = float(rng.choice([0.05, 0.1, 0.2]))
+        start = (float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.3, 0.7)))
+        free, occ = float(rng.uniform(0.3, 0.49)), float(rng.uniform(0.55, 0.95))
+        ext = size * res
+        grow = 1.15 if trial % 2 else 0.6
+        world = synth.World.make(ext * grow, ext * grow * 0.75, n_boxes=4, seed=int(rng.integers(1 << 30)), keep_clear=0.5)
+        s = float(np.float32(1.0) / np.float32(res))
+        n_beams = int(rng.choice([181, 400, 1081]))
+        poses = synth.loop_trajectory(world, 14, frac=0.25).astype(np.float32)
+        poses[:, 0] += (0.5 - start[0]) * ext * 0.3
+        noise = np.random.default_rng(trial)
+        scans = [synth.make_scan(world, p, n_beams, s, noise, range_max=min(30.0, ext)) for p in poses]
+        origos = rng.uniform(-2, 2, (14, 2)).astype(np.float32)
+        o = oracle_mod.Oracle(kind, res, size, size, levels, start)
+        g = capi.MapRepMultiMap(res, size, size, levels, start, parity=capi.PARITY_EXACT)
+        o.set_update_factor_free(free)
+        g.setUpdateFactorFree(free)
+        o.set_update_factor_occupied(occ)
+        g.setUpdateFactorOccupied(occ)
+        pose = poses[0].copy()
+        for t in range(14):
+            hint = pose + (poses[t] - poses[max(t - 1, 0)])
+            po, co = o.match(hint, scans[t], origos[t])
+            pg, cg = g.matchData(hint, scans[t], None, origos[t])
+            if np.isfinite(po).all():
+                assert same(pg, po) and same(cg, co), (trial, size, res, levels, t, pg, po)
+            else:  # a singular H: the reference divides by a zero determinant; NaN payloads are not pinned
+                assert np.array_equal(np.isnan(pg), np.isnan(po))
+                po = hint
+            o.update_by_scan(po, scans[t], origos[t])
+            o.on_map_updated()
+            g.updateByScan(scans[t], po, origos[t])
+            pose = po
+        for lvl in range(levels):
+            a, b = g.download_level(lvl), o.download_level(lvl)
+            assert same(a[0], b[0]) and np.array_equal(a[1], b[1]), (trial, lvl)
+
+
+def test_fast_mode_deviation_is_measured_against_exact_mode(capi, oracle_mod, pyramid_scene, kind):
+    """the default (fast) summation on the same context: same products, another order.  Its deviation from the exact
+    mode IS its deviation from the reference; bound stated here, statistics printed."""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o)
+    from hector_slam_amd import synth
+    pts, offs = synth.pack_scans(sc.query_scans)
+    pe, ce = g.match_batch(sc.query_init, pts, offs)
+    g.set_parity(capi.PARITY_FAST)
+    pf, cf = g.match_batch(sc.query_init, pts, offs)
+    assert g.last_launch_config()["parity"] == "fast"
+    g.set_parity(capi.PARITY_EXACT)
+    pe2, _ = g.match_batch(sc.query_init, pts, offs)
+    assert same(pe, pe2)
+    assert same(pe, o.match_many(sc.query_init, pts, offs))
+    d = np.abs(pf.astype(np.float64) - pe)
+    print(f"fast vs exact: max |dxy| {d[:, :2].max():.2e} m, max |dtheta| {d[:, 2].max():.2e} rad, "
+          f"bit-identical {(bits(pf) == bits(pe)).all(1).mean():.3f}")
+    assert d[:, :2].max() <= 1e-4 and d[:, 2].max() <= 1e-4
+    assert np.abs(cf - ce).max() <= 1e-4 * np.abs(ce).max()
+
+
+def test_committed_golden_vectors_bit_identical(capi):
+    """tests/golden/*.npz hold outputs of the reference's own headers (make_golden.py): poses, covariances and the
+    per-step H / dTr of the golden matches are reproduced bit for bit -- no oracle library involved at all"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g1 = np.load(os.path.join(gold, "config1_181beam_256map.npz"))
+    g = capi.MapRepMultiMap(float(g1["resolution"]), int(g1["map_size"]), int(g1["map_size"]), 1, parity=capi.PARITY_EXACT)
+    g.upload_level(0, g1["logodds"], g1["update_index"])
+    for q in range(4):
+        pts = g1[f"q{q}_pts"]
+        pose, cov = g.match_level(0, g1[f"q{q}_init"], pts, 5)
+        assert same(pose, g1[f"q{q}_pose"]) and same(cov, g1[f"q{q}_cov"]), q
+        for k in range(7):
+            H, d = g.hessian_derivs(0, g1[f"q{q}_step_pose_map"][k], pts)
+            assert same(H, g1[f"q{q}_step_H"][k]) and same(d, g1[f"q{q}_step_dTr"][k]), (q, k)
+    g2 = np.load(os.path.join(gold, "pyramid_1081beam_512map.npz"))
+    g = capi.MapRepMultiMap(float(g2["resolution"]), int(g2["map_size"]), int(g2["map_size"]), 3, parity=capi.PARITY_EXACT)
+    for lvl in range(3):
+        g.upload_level(lvl, g2[f"logodds{lvl}"], g2[f"update_index{lvl}"])
+    for q in range(8):
+        pose, cov = g.matchData(g2["init"][q], g2[f"q{q}_pts"])
+        assert same(pose, g2["pose"][q]) and same(cov, g2["cov"][q]), q

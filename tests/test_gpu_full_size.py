@@ -1,13 +1,18 @@
 """GPU tests at BASELINE.json's full configuration sizes (configs[2..4], the single-GPU share of the
-multi-GPU ones).  The oracle is run on a bounded subset of each batch; the rest of the batch is covered by
-size-independent properties of the path: determinism, permutation equivariance of the batch, batch ==
-single-scan calls bit for bit, idempotence at convergence (a converged pose is a fixed point), and -- for
-the interleaved match/update loop -- bit-identical maps given identical poses.
+multi-GPU ones).
+
+Parity bar, unconditional: in HSM_PARITY_EXACT the pose of EVERY scan of every batch is bit-identical to the
+reference CPU matcher's ("hr": the unmodified reference headers, where oracle/_ref is present; else the restatement)
+-- the whole batch is compared, settled scans and unsettled ones alike.  The default (fast) summation is then measured
+against the exact mode on the same context (same map, same scans, same products, another summation order): its
+deviation from the exact mode IS its deviation from the reference, with the bound stated per workload.  On top:
+size-independent properties of the path -- determinism, permutation equivariance of the batch, batch == single-scan
+calls, idempotence at convergence, and bit-identical maps given identical poses.
 """
 import numpy as np
 import pytest
 
-from conftest import ang_diff, bits, make_oracle
+from conftest import ang_diff, bits, make_oracle, oracle_kinds
 
 pytestmark = pytest.mark.gpu
 TOL_M, TOL_RAD = 1e-4, 1e-4
@@ -28,22 +33,77 @@ def capi():
     return m
 
 
+KIND = oracle_kinds()[-1]  # "hr" (reference-compiled) where available
+
+
+def record(**kw):
+    """parity statistics of the full-size runs, appended as JSON lines to $HSM_PARITY_STATS (tools/gpu_*.sh set it;
+    the committed copies live under profiles/)"""
+    import json
+    import os
+    print(json.dumps(kw))
+    path = os.environ.get("HSM_PARITY_STATS")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+
+
 def build_pair(capi, oracle_mod, sc, oracle_build=True):
     g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
     g.setUpdateFactorFree(0.4)
     g.setUpdateFactorOccupied(0.9)
     g.build_map(sc.build_poses, sc.build_scans)
-    o = make_oracle(oracle_mod, "ho", sc, build=oracle_build)
+    o = make_oracle(oracle_mod, KIND, sc, build=oracle_build)
     return g, o
 
 
-def batch_properties(capi, g, o, init, scans, n_oracle, rng):
-    """shared checks for a big batched matchData; returns the batch result"""
+def oracle_match_all(oracle_mod, sc, init, pts, offs, threads=16):
+    """matchData of the CPU reference for EVERY scan of the batch (threads over the host cores, one private oracle
+    -- map + matcher + probability cache -- per thread)"""
+    import threading
+    B = init.shape[0]
+    T = max(1, min(threads, B // 64))
+    cpu = np.empty((B, 3), np.float32)
+
+    def work(t):
+        o = make_oracle(oracle_mod, KIND, sc)
+        b, e = B * t // T, B * (t + 1) // T
+        cpu[b:e] = o.match_many(init[b:e], pts[offs[b]:offs[e]], offs[b:e + 1] - offs[b])
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    return cpu
+
+
+def batch_properties(capi, oracle_mod, sc, g, init, scans, rng, fast_within_tol, fast_max_m):
+    """shared checks for a big batched matchData; returns the exact-mode batch result"""
     from hector_slam_amd import synth
     B = len(scans)
     pts, offs = synth.pack_scans(scans)
+    # ---- exact mode: the WHOLE batch against the reference, bit for bit, no predicate
+    g.set_parity(capi.PARITY_EXACT)
+    pose_x, cov_x = g.match_batch(init, pts, offs)
+    cpu = oracle_match_all(oracle_mod, sc, init, pts, offs)
+    same = (bits(pose_x) == bits(cpu)).all(1)
+    assert same.all(), f"exact mode: {(~same).sum()} of {B} poses differ from the reference ({KIND})"
+    # ---- fast mode (default), measured against the exact mode
+    g.set_parity(capi.PARITY_FAST)
     pose, cov = g.match_batch(init, pts, offs)
     assert np.isfinite(pose).all() and np.isfinite(cov).all()
+    d = np.abs(pose.astype(np.float64) - pose_x)
+    dxy, dth = d[:, :2].max(1), ang_diff(pose[:, 2], pose_x[:, 2])
+    ok = (dxy <= TOL_M) & (dth <= TOL_RAD)
+    ident = (bits(pose) == bits(pose_x)).all(1)
+    cfg = g.last_launch_config()
+    print(f"B={B} kernel={cfg}: exact == {KIND} on {B}/{B}; fast vs exact: bit-identical {ident.mean():.4f}, within 1e-4 "
+          f"{ok.mean():.5f}, median {np.median(dxy):.1e} m, p99.9 {np.percentile(dxy, 99.9):.1e} m, max {dxy.max():.1e} m")
+    record(test="batch_properties", scene=f"{sc.map_size}^2 x{sc.levels} levels", batch=B, checker=KIND,
+           exact_bit_identical_to_reference=int(same.sum()), fast_bit_identical_to_exact=float(ident.mean()),
+           fast_within_1e4=float(ok.mean()), fast_median_dxy_m=float(np.median(dxy)),
+           fast_p999_dxy_m=float(np.percentile(dxy, 99.9)), fast_max_dxy_m=float(dxy.max()), kernel=cfg)
+    assert ok.mean() >= fast_within_tol, ok.mean()
+    assert dxy.max() <= fast_max_m, dxy.max()  # the fast mode never leaves the reference's basin
     # determinism
     pose2, cov2 = g.match_batch(init, pts, offs)
     assert np.array_equal(bits(pose), bits(pose2)) and np.array_equal(bits(cov), bits(cov2))
@@ -52,39 +112,24 @@ def batch_properties(capi, g, o, init, scans, n_oracle, rng):
     pts_p, offs_p = synth.pack_scans([scans[i] for i in perm])
     pose_p, _ = g.match_batch(init[perm], pts_p, offs_p)
     assert np.array_equal(bits(pose_p), bits(pose[perm]))
-    # oracle parity + batch == single-scan call on a subset
-    # The tolerance is a statement about scans on which the REFERENCE's Gauss-Newton has settled: where
-    # the reference, restarted from its own result, still jumps (a few % of the poses in the big-room
-    # scenes: >10 cm), its output is a chaotic function of the last bits of every sum and no
-    # implementation -- including the reference built by another compiler -- reproduces it to 1e-4 m.
-    # Those scans are identified with the oracle itself and only required to stay in the same basin.
-    sel = rng.choice(B, size=n_oracle, replace=False)
-    worst, settled = (0.0, 0.0), 0
+    # batch == single-scan calls: bit for bit in exact mode (any team width), tolerance in fast mode (other tree)
+    sel = rng.choice(B, size=6, replace=False)
     for q in sel:
-        po, co = o.match(init[q], scans[q])
-        po2, _ = o.match(po, scans[q])
-        e = pose_err(pose[q], po)
-        if pose_err(po2, po)[0] <= 1e-3:
-            settled += 1
-            worst = (max(worst[0], e[0]), max(worst[1], e[1]))
-            assert e[0] <= TOL_M and e[1] <= TOL_RAD, (q, e)
-            assert np.abs(cov[q] - co).max() <= 1e-3 * np.abs(co).max()
-        else:
-            assert e[0] <= 0.5 and e[1] <= 0.05, (q, e)
-    assert settled >= 0.55 * n_oracle, settled
-    cfg = g.last_launch_config()
-    g1 = None
-    for q in sel[:4]:
-        # a single-scan call picks more waves per scan (different summation tree): tolerance, not bits
-        ps, _ = g.matchData(init[q], scans[q])
-        e = pose_err(ps, pose[q])
-        assert e[0] <= TOL_M and e[1] <= TOL_RAD
-    # idempotence at convergence: one more matchData from the converged pose stays put
+        if ok[q]:
+            ps, _ = g.matchData(init[q], scans[q])
+            e = pose_err(ps, pose[q])
+            assert e[0] <= 2 * TOL_M and e[1] <= 2 * TOL_RAD
+    g.set_parity(capi.PARITY_EXACT)
+    for q in sel:
+        ps, cs = g.matchData(init[q], scans[q])
+        assert np.array_equal(bits(ps), bits(pose_x[q])) and np.array_equal(bits(cs), bits(cov_x[q]))
+    g.set_parity(capi.PARITY_FAST)
+    # idempotence at convergence: one more matchData from the converged pose stays put (median; the reference itself
+    # keeps moving on the unsettled tail of the big-room scenes)
     pose3, _ = g.match_batch(pose, pts, offs)
-    d = np.abs(pose3.astype(np.float64) - pose)
-    assert np.median(d[:, :2]) <= 2e-5 and (d[:, :2].max(1) > 1e-3).mean() <= 0.4  # (the unsettled tail, see above)
-    print(f"B={B} kernel={cfg} worst dev vs oracle on {settled}/{n_oracle} settled scans: {worst[0]:.2e} m {worst[1]:.2e} rad")
-    return pose
+    d3 = np.abs(pose3.astype(np.float64) - pose)
+    assert np.median(d3[:, :2]) <= 2e-5
+    return pose_x
 
 
 def test_config3_batch4096_2048map(capi, oracle_mod):
@@ -96,7 +141,8 @@ def test_config3_batch4096_2048map(capi, oracle_mod):
     for lvl in range(sc.levels):  # the map the GPU built == the map the oracle built, bit for bit
         a, b = g.download_level(lvl), o.download_level(lvl)
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
-    pose = batch_properties(capi, g, o, sc.query_init, sc.query_scans, 48, np.random.default_rng(5))
+    pose = batch_properties(capi, oracle_mod, sc, g, sc.query_init, sc.query_scans, np.random.default_rng(5),
+                            fast_within_tol=0.998, fast_max_m=5e-3)
     err = np.abs(pose.astype(np.float64) - sc.query_truth)
     assert np.median(err[:, :2]) < 0.02  # it converges to the ground truth, too
 
@@ -114,7 +160,11 @@ def test_config4_share_4096map_pyramid(capi, oracle_mod):
     assert g.level_info(0)[:2] == (4096, 4096) and g.level_info(2)[:2] == (1024, 1024)
     a, b = g.download_level(0), o.download_level(0)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
-    batch_properties(capi, g, o, sc.query_init, sc.query_scans, 32, np.random.default_rng(6))
+    # 30 % of these scans have not settled in the REFERENCE (restarted from its own result it still moves > 1 mm: the far
+    # walls of the 160 m room are mapped as dotted lines); the exact mode reproduces them all the same, the fast mode
+    # agrees to 1e-4 m on >= 96 % and stays in the same basin on the rest
+    batch_properties(capi, oracle_mod, sc, g, sc.query_init, sc.query_scans, np.random.default_rng(6),
+                     fast_within_tol=0.96, fast_max_m=0.5)
 
 
 def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
@@ -125,7 +175,7 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
     sc = synth.make_scene(n_beams=16384, map_size=8192, levels=3, resolution=0.05, n_build=steps + 1, n_query=2,
                           room=(320.0, 240.0), seed=31, range_max=240.0)
     assert min(s.shape[0] for s in sc.build_scans) > 14000
-    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o = make_oracle(oracle_mod, KIND, sc, build=False)
     o.proc_set_thresholds(0.0, 0.0)
     p = capi.HectorSlamProcessor(sc.resolution, sc.map_size, sc.map_size, (0.5, 0.5), sc.levels)
     p.setUpdateFactorFree(0.4)
@@ -154,7 +204,7 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
     g2 = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
     g2.setUpdateFactorFree(0.4)
     g2.setUpdateFactorOccupied(0.9)
-    o2 = make_oracle(oracle_mod, "ho", sc, build=False)
+    o2 = make_oracle(oracle_mod, KIND, sc, build=False)
     for t in range(4):
         o2.match(sc.build_poses[t], sc.build_scans[t])
         g2.matchData(sc.build_poses[t], sc.build_scans[t])
@@ -165,12 +215,38 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
 
 
+def test_config5_dense_scan_exact_mode_whole_slam_state(capi, oracle_mod):
+    """configs[4] in HSM_PARITY_EXACT: 16384-beam scans, 8192^2 pyramid, match + update interleaved from an empty map --
+    every pose bit-identical to the reference, so every update decision and all three maps are, too"""
+    from hector_slam_amd import synth
+    steps = 6
+    sc = synth.make_scene(n_beams=16384, map_size=8192, levels=3, resolution=0.05, n_build=steps + 1, n_query=2,
+                          room=(320.0, 240.0), seed=31, range_max=240.0)
+    o = make_oracle(oracle_mod, KIND, sc, build=False)
+    o.proc_set_thresholds(0.0, 0.0)
+    p = capi.HectorSlamProcessor(sc.resolution, sc.map_size, sc.map_size, (0.5, 0.5), sc.levels, parity=capi.PARITY_EXACT)
+    p.setUpdateFactorFree(0.4)
+    p.setUpdateFactorOccupied(0.9)
+    p.setMapUpdateMinDistDiff(0.0)
+    p.setMapUpdateMinAngleDiff(0.0)
+    hint = sc.build_poses[0].copy()
+    for t in range(steps):
+        o.proc_update(sc.build_scans[t], hint)
+        p.update(sc.build_scans[t], hint)
+        po, co = o.proc_last_pose()
+        assert np.array_equal(bits(p.getLastScanMatchPose()), bits(po)), t
+        assert np.array_equal(bits(p.getLastScanMatchCovariance()), bits(co)), t
+        hint = po + (sc.build_poses[t + 1] - sc.build_poses[t])
+    assert p.mapRep.last_launch_config()["waves_per_scan"] == 16
+    for lvl in range(sc.levels):
+        a, b = p.mapRep.download_level(lvl), o.download_level(lvl)
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
+
+
 def test_parity_sweep_32768_scans(capi, oracle_mod):
     """configs[3]'s full batch -- 32768 scans -- through the 3-level 2048/1024/512 matchData in 8 launches of 4096
-    (what the 8 GPUs do in parallel), EVERY pose compared with the oracle (threads over the host cores, one private
-    oracle each).  Reports the bit-identical fraction; the tolerance must hold on >= 99.8 % of all scans and on
-    every scan whose reference result is settled."""
-    import threading
+    (what the 8 GPUs do in parallel), EVERY pose compared with the reference (threads over the host cores).
+    Exact mode: 32768 of 32768 bit-identical.  Fast mode: fraction reported, >= 99.8 % within 1e-4 m / 1e-4 rad."""
     from hector_slam_amd import synth
     B, G = 4096, 8
     sc = synth.make_scene(n_beams=1081, map_size=2048, levels=3, resolution=0.05, n_build=120, n_query=B * G,
@@ -180,33 +256,26 @@ def test_parity_sweep_32768_scans(capi, oracle_mod):
     g.setUpdateFactorOccupied(0.9)
     g.build_map(sc.build_poses, sc.build_scans)
     pts, offs = synth.pack_scans(sc.query_scans)
-    gpu = np.concatenate([g.match_batch(sc.query_init[k * B:(k + 1) * B],
-                                        pts[offs[k * B]:offs[(k + 1) * B]],
-                                        offs[k * B:(k + 1) * B + 1] - offs[k * B], want_cov=False)[0]
-                          for k in range(G)])
-    T = 16
-    cpu = np.empty_like(gpu)
-    cpu2 = np.empty_like(gpu)
 
-    def work(t):
-        o = make_oracle(oracle_mod, "ho", sc)
-        b, e = (B * G) * t // T, (B * G) * (t + 1) // T
-        o_pts, o_offs = pts[offs[b]:offs[e]], offs[b:e + 1] - offs[b]
-        cpu[b:e] = o.match_many(sc.query_init[b:e], o_pts, o_offs)
-        cpu2[b:e] = o.match_many(cpu[b:e], o_pts, o_offs)
+    def gpu_all():
+        return np.concatenate([g.match_batch(sc.query_init[k * B:(k + 1) * B], pts[offs[k * B]:offs[(k + 1) * B]],
+                                             offs[k * B:(k + 1) * B + 1] - offs[k * B], want_cov=False)[0]
+                               for k in range(G)])
 
-    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-    [x.start() for x in th]
-    [x.join() for x in th]
-    d = np.abs(gpu.astype(np.float64) - cpu)
-    dth = ang_diff(gpu[:, 2], cpu[:, 2])
-    ok = (d[:, 0] <= TOL_M) & (d[:, 1] <= TOL_M) & (dth <= TOL_RAD)
-    same = (gpu.view(np.uint32) == cpu.view(np.uint32)).all(1)
-    settled = np.abs(cpu2.astype(np.float64) - cpu)[:, :2].max(1) <= 1e-3
-    print(f"32768 scans: bit-identical {same.mean():.4f}, within tolerance {ok.mean():.5f}, settled {settled.mean():.4f}, "
-          f"max dev on settled {d[settled, :2].max():.2e} m, worst overall {d[:, :2].max():.2e} m")
-    assert ok.mean() >= 0.998
-    assert same.mean() >= 0.95
-    # a settled reference result may still sit next to a second fixed point of the piecewise-bilinear cost
-    # (DESIGN.md section 4): allow a handful of those, nothing beyond a millimetre
-    assert (~ok & settled).sum() <= 8 and d[settled, :2].max() <= 1e-3
+    g.set_parity(capi.PARITY_EXACT)
+    exact = gpu_all()
+    g.set_parity(capi.PARITY_FAST)
+    fast = gpu_all()
+    cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
+    same = (bits(exact) == bits(cpu)).all(1)
+    d = np.abs(fast.astype(np.float64) - cpu)
+    ok = (d[:, 0] <= TOL_M) & (d[:, 1] <= TOL_M) & (ang_diff(fast[:, 2], cpu[:, 2]) <= TOL_RAD)
+    ident = (bits(fast) == bits(cpu)).all(1)
+    print(f"32768 scans vs {KIND}: exact mode bit-identical {same.sum()}/{same.size}; fast mode bit-identical "
+          f"{ident.mean():.4f}, within tolerance {ok.mean():.5f}, worst {d[:, :2].max():.2e} m")
+    record(test="parity_sweep_32768", checker=KIND, exact_bit_identical_to_reference=int(same.sum()), scans=int(same.size),
+           fast_bit_identical_to_reference=float(ident.mean()), fast_within_1e4=float(ok.mean()),
+           fast_worst_dxy_m=float(d[:, :2].max()))
+    assert same.all(), (~same).sum()
+    assert ok.mean() >= 0.998 and ident.mean() >= 0.95
+    assert d[:, :2].max() <= 1e-3

@@ -4,17 +4,21 @@ inputs and against the committed golden vectors.
 Bars (BASELINE.json north_star / SURVEY.md 8(d)):
   * integer / index work (map update: log-odds + stamps): BIT-EXACT
   * world<->map transforms (host fp32): BIT-EXACT
-  * per-beam terms M, dM/dx, dM/dy, rotDeriv: BIT-EXACT given the rotation's sin/cos (the device
-    evaluates them in fp64 and rounds once; within 1 ulp of any host sinf/cosf)
-  * probability texels: <= 1 ulp from the oracle's expf-based value
-  * pose estimate: |dx|, |dy| <= 1e-4 m, |dtheta| <= 1e-4 rad  (POSE_TOL below)
+  * sinf / cosf / expf on the device: BIT-EXACT against the host libm the reference links (glibc's
+    algorithms restated in csrc/libm_exact.h)
+  * per-beam terms M, dM/dx, dM/dy, rotDeriv and the probability texels: BIT-EXACT
+  * pose estimate, default (fast) summation: |dx|, |dy| <= 1e-4 m, |dtheta| <= 1e-4 rad  (POSE_TOL below);
+    HSM_PARITY_EXACT: bit-identical (tests/test_gpu_exact_parity.py)
+
+Every test that takes an oracle runs twice where oracle/_ref/libhector_ref.so is present: against the plain-C++
+restatement ("ho") and against the UNMODIFIED reference headers compiled through the Eigen stand-in ("hr").
 """
 import os
 
 import numpy as np
 import pytest
 
-from conftest import ang_diff, bits, make_oracle, ulp_diff
+from conftest import ang_diff, bits, make_oracle, oracle_kinds, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -58,14 +62,20 @@ def make_gpu(capi, scene, free=0.4, occ=0.9, build=True, **kw):
     return g
 
 
-@pytest.fixture(scope="module")
-def pyr(capi, oracle_mod, pyramid_scene):
-    return make_gpu(capi, pyramid_scene), make_oracle(oracle_mod, "ho", pyramid_scene)
+@pytest.fixture(scope="module", params=oracle_kinds())
+def kind(request):
+    """which CPU checker: "ho" = restatement, "hr" = the reference's own headers"""
+    return request.param
 
 
 @pytest.fixture(scope="module")
-def sml(capi, oracle_mod, small_scene):
-    return make_gpu(capi, small_scene), make_oracle(oracle_mod, "ho", small_scene)
+def pyr(capi, oracle_mod, pyramid_scene, kind):
+    return make_gpu(capi, pyramid_scene), make_oracle(oracle_mod, kind, pyramid_scene)
+
+
+@pytest.fixture(scope="module")
+def sml(capi, oracle_mod, small_scene, kind):
+    return make_gpu(capi, small_scene), make_oracle(oracle_mod, kind, small_scene)
 
 
 # ---------------------------------------------------------------- geometry / storage
@@ -95,22 +105,35 @@ def test_map_update_bit_exact(pyr, pyramid_scene):
         assert g.getUpdateIndex(lvl) == len(pyramid_scene.build_scans) - 1
 
 
-def test_probability_plane_within_one_ulp(pyr, pyramid_scene):
+def test_probability_plane_bit_exact(pyr, pyramid_scene, oracle_mod):
+    """p = e^l / (e^l + 1) with glibc's expf: every cell of every level equals the host's value bit for bit, and
+    equals what the reference's own sampler returns at integer coordinates"""
     g, o = pyr
     for lvl in range(pyramid_scene.levels):
         lo, _ = o.download_level(lvl)
         got = g.download_prob(lvl)
-        # (1) the device's definition: exp in fp64 rounded once to fp32, then fp32 odds/(odds+1)
-        odds = np.exp(lo.astype(np.float64)).astype(np.float32)
-        assert np.array_equal(bits(got), bits(odds / (odds + np.float32(1.0))))
-        # (2) against the oracle's own expf-based probabilities: at integer coordinates
-        # interpMapValueWithDerivatives returns M = P(ix, iy) exactly (fractions are 0)
+        _, prob = oracle_mod.libm_expf(lo.reshape(-1), o.kind)
+        assert np.array_equal(bits(got).reshape(-1), bits(prob))
+        # at integer coordinates interpMapValueWithDerivatives returns M = P(ix, iy) exactly (fractions are 0)
         ys, xs = np.nonzero(lo[:-2, :-2] != 0)
         sel = np.random.default_rng(3).choice(len(xs), size=min(20000, len(xs)), replace=False)
         ref = o.interp(lvl, np.stack([xs[sel], ys[sel]], 1).astype(np.float32))[:, 0]
-        d = ulp_diff(got[ys[sel], xs[sel]], ref)
-        assert d.max() <= 1, d.max()
-        assert (d == 0).mean() > 0.98, (d == 0).mean()
+        assert np.array_equal(bits(got[ys[sel], xs[sel]]), bits(ref))
+
+
+def test_device_expf_equals_host_libm(sml, oracle_mod):
+    """device expf over the whole log-odds range and far beyond (overflow / underflow / denormal results / NaN)"""
+    g, o = sml
+    rng = np.random.default_rng(22)
+    x = np.concatenate([rng.uniform(-60, 60, 2_000_000), rng.uniform(-110, 95, 1_000_000), rng.normal(0, 1e-3, 100_000),
+                        [0.0, -0.0, 50.0, 88.0, 88.72, 88.73, 89.0, -87.3, -87.4, -100.0, -103.2, -103.3, -103.97, -103.98,
+                         -104.0, 1e-30, -1e-30, 1e38, -1e38, np.inf, -np.inf]]).astype(np.float32)
+    e, p = g.debug_expf(x)
+    eh, ph = oracle_mod.libm_expf(x, o.kind)
+    assert np.array_equal(bits(e), bits(eh))
+    fin = np.isfinite(eh)
+    assert np.array_equal(bits(p[fin]), bits(ph[fin]))
+    assert np.isnan(g.debug_expf(np.array([np.nan], np.float32))[0]).all()
 
 
 def test_upload_then_download_roundtrip_and_rebuild(capi, pyr, pyramid_scene):
@@ -130,30 +153,27 @@ def test_upload_then_download_roundtrip_and_rebuild(capi, pyr, pyramid_scene):
 
 
 # ---------------------------------------------------------------- per-beam / per-step
-def test_device_sincos_is_correctly_rounded(sml):
-    """the lean fp64 sin/cos kernel rounds to the correctly rounded fp32 value (== float32 of the
-    fp64 libm result) over 3M angles incl. the huge-angle fallback; <= 1 ulp from any host sinf"""
-    g, _ = sml
+def test_device_sincos_equals_host_libm(sml, oracle_mod):
+    """device sincosf == the host's sincosf (glibc, what the reference's sin(pose[2]) / cos(pose[2]) compile to) for
+    3M angles in all three argument ranges of the algorithm (|x| < pi/4, < 120, beyond) and the special values"""
+    g, o = sml
     rng = np.random.default_rng(21)
     x = np.concatenate([rng.uniform(-3.2, 3.2, 1_000_000), rng.uniform(-100, 100, 1_000_000),
-                        rng.uniform(-1e5, 1e5, 900_000), rng.uniform(-1e9, 1e9, 100_000),
-                        [0.0, -0.0, np.pi, -np.pi, np.pi / 2, 1e-30, 1048575.9, 1048576.0, 3e7]]).astype(np.float32)
+                        rng.uniform(-1e5, 1e5, 800_000), rng.uniform(-1e9, 1e9, 100_000), rng.normal(0, 1e-3, 100_000),
+                        [0.0, -0.0, np.pi, -np.pi, np.pi / 2, np.pi / 4, 0.78539, 0.7854, 1e-30, 2.44e-4, 2.45e-4, 119.99,
+                         120.0, 120.01, 1048575.9, 1048576.0, 3e7, 1e30, 3.4e38, -3.4e38]]).astype(np.float32)
     s, c = g.debug_sincos(x)
-    xd = x.astype(np.float64)
-    small = np.abs(xd) < 1048576.0
-    assert np.array_equal(bits(s[small]), bits(np.sin(xd[small]).astype(np.float32)))
-    assert np.array_equal(bits(c[small]), bits(np.cos(xd[small]).astype(np.float32)))
-    # beyond 2^20 rad the argument is first reduced with fmod(x, fp64 2*pi): still within 1e-6
-    assert np.abs(s[~small] - np.sin(xd[~small])).max() < 1e-6
-    assert np.abs(c[~small] - np.cos(xd[~small])).max() < 1e-6
+    sh, ch = oracle_mod.libm_sincosf(x, o.kind)
+    assert np.array_equal(bits(s), bits(sh))
+    assert np.array_equal(bits(c), bits(ch))
     s2, c2 = g.debug_sincos(np.array([np.inf, -np.inf, np.nan], np.float32))
     assert np.isnan(s2).all() and np.isnan(c2).all()
 
 
 @pytest.mark.parametrize("layout", ["quad", "plane"])
-def test_per_beam_terms_bit_exact(capi, oracle_mod, pyramid_scene, layout):
+def test_per_beam_terms_bit_exact(capi, oracle_mod, pyramid_scene, layout, kind):
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc)
+    o = make_oracle(oracle_mod, kind, sc)
     g = make_gpu(capi, sc, build=False, layout=capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE)
     for lvl in range(sc.levels):
         g.upload_level(lvl, *o.download_level(lvl))
@@ -164,9 +184,8 @@ def test_per_beam_terms_bit_exact(capi, oracle_mod, pyramid_scene, layout):
             pm = o.map_coords_pose(lvl, sc.query_init[q])
             got = g.eval_beams(lvl, pm, pts)
             # oracle per-beam terms: M, gx, gy from interp at the transformed point; the transform
-            # uses the same fp32 expression t + (c*x + (-s)*y).  sin/cos as the device defines
-            # them: evaluated in fp64, rounded once to fp32 (independent of any host libm)
-            s, c = np.float32(np.sin(np.float64(pm[2]))), np.float32(np.cos(np.float64(pm[2])))
+            # uses the same fp32 expression t + (c*x + (-s)*y), sin/cos from the host libm
+            s, c = (v[0] for v in oracle_mod.libm_sincosf(pm[2:3], kind))
             tx = pm[0] + (c * pts[:, 0] + (-s) * pts[:, 1])
             ty = pm[1] + (s * pts[:, 0] + c * pts[:, 1])
             ref = o.interp(lvl, np.stack([tx, ty], 1).astype(np.float32))
@@ -228,7 +247,7 @@ def test_empty_scan_and_degenerate_map(capi, pyr, pyramid_scene):
     # fresh map: p = 0.5 everywhere -> H(0,0) == 0 -> the pose must not move
     fresh = make_gpu(capi, sc, build=False)
     p, c = fresh.matchData(sc.query_init[1], sc.query_scans[1])
-    fo = o.__class__("ho", sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    fo = o.__class__(o.kind, sc.resolution, sc.map_size, sc.map_size, sc.levels)
     po, co = fo.match(sc.query_init[1], sc.query_scans[1])
     assert np.array_equal(bits(p), bits(po)) and np.array_equal(c, co) and not c.any()
 
@@ -257,7 +276,8 @@ def test_far_starts_clamp_and_out_of_map_beams(pyr, pyramid_scene):
     far = np.array([11.5, 9.0, 0.3], np.float32)
     pm = o.map_coords_pose(0, far)
     pts = sc.query_scans[0]
-    s_, c_ = np.float32(np.sin(np.float64(pm[2]))), np.float32(np.cos(np.float64(pm[2])))
+    from oracle import pyoracle
+    s_, c_ = (v[0] for v in pyoracle.libm_sincosf(pm[2:3], o.kind))
     tx = pm[0] + (c_ * pts[:, 0] + (-s_) * pts[:, 1])
     ty = pm[1] + (s_ * pts[:, 0] + c_ * pts[:, 1])
     ref = o.interp(0, np.stack([tx, ty], 1).astype(np.float32))
@@ -275,10 +295,10 @@ def test_far_starts_clamp_and_out_of_map_beams(pyr, pyramid_scene):
 
 
 # ---------------------------------------------------------------- batched path
-def test_batch_equals_singles_and_is_deterministic(capi, oracle_mod, pyramid_scene):
+def test_batch_equals_singles_and_is_deterministic(capi, oracle_mod, pyramid_scene, kind):
     from hector_slam_amd import synth
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc)
+    o = make_oracle(oracle_mod, kind, sc)
     g1 = make_gpu(capi, sc, build=False, waves_per_scan=1)
     for lvl in range(sc.levels):
         g1.upload_level(lvl, *o.download_level(lvl))
@@ -305,9 +325,9 @@ def test_batch_equals_singles_and_is_deterministic(capi, oracle_mod, pyramid_sce
 
 
 @pytest.mark.parametrize("wps", [1, 2, 4, 8, 16])
-def test_every_team_width_meets_pose_tolerance(capi, oracle_mod, pyramid_scene, wps):
+def test_every_team_width_meets_pose_tolerance(capi, oracle_mod, pyramid_scene, wps, kind):
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc)
+    o = make_oracle(oracle_mod, kind, sc)
     g = make_gpu(capi, sc, build=False, waves_per_scan=wps)
     for lvl in range(sc.levels):
         g.upload_level(lvl, *o.download_level(lvl))
@@ -329,12 +349,12 @@ def test_every_team_width_meets_pose_tolerance(capi, oracle_mod, pyramid_scene, 
 
 
 # ---------------------------------------------------------------- processor loop
-def test_slam_loop_match_update_interleaved(capi, oracle_mod, pyramid_scene):
+def test_slam_loop_match_update_interleaved(capi, oracle_mod, pyramid_scene, kind):
     """HectorSlamProcessor::update from an EMPTY map: match -> threshold -> updateByScan, 25 scans.
     Poses stay within tolerance of the oracle's at every step; the maps agree except for the few
     cells whose Bresenham endpoints flip because the poses differ in the last bits."""
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
     o.proc_set_thresholds(0.05, 0.02)
     p = capi.HectorSlamProcessor(sc.resolution, sc.map_size, sc.map_size, (0.5, 0.5), sc.levels)
     p.setUpdateFactorFree(0.4)
@@ -360,7 +380,7 @@ def test_slam_loop_match_update_interleaved(capi, oracle_mod, pyramid_scene):
         assert (bits(lo_g) != bits(lo_o)).sum() <= 0.002 * touched
     # with identical poses fed to both, the maps are bit-identical (pure index work)
     g2 = make_gpu(capi, sc, build=False)
-    o2 = make_oracle(oracle_mod, "ho", sc, build=False)
+    o2 = make_oracle(oracle_mod, kind, sc, build=False)
     for t in range(10):
         o2.match(sc.build_poses[t], sc.build_scans[t], origo)       # retains the coarse containers
         g2.matchData(sc.build_poses[t], sc.build_scans[t], None, origo)
@@ -371,12 +391,12 @@ def test_slam_loop_match_update_interleaved(capi, oracle_mod, pyramid_scene):
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
 
 
-def test_update_edge_cases_bit_exact(capi, oracle_mod, small_scene):
+def test_update_edge_cases_bit_exact(capi, oracle_mod, small_scene, kind):
     """empty scan, begin == end beams, beams leaving the map, robot outside the map, the occupied
     clamp at 50 and the free->occupied revert -- all bit-exact against the oracle"""
     sc = small_scene
     g = make_gpu(capi, sc, build=False)
-    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
     s = np.float32(sc.scale_to_map)
     cases = [
         (np.array([0, 0, 0], np.float32), np.zeros((0, 2), np.float32)),                       # empty
@@ -470,12 +490,12 @@ def test_capi_error_paths_fail_loudly(capi, small_scene):
     assert np.isfinite(p).all()
 
 
-def test_concurrent_callers_are_serialised(capi, oracle_mod, pyramid_scene):
+def test_concurrent_callers_are_serialised(capi, oracle_mod, pyramid_scene, kind):
     """the reference contract is one writer + one reader thread; the context's mutex must keep concurrent
     matchData / occupancy reads on ONE context, and independent contexts in parallel, all correct"""
     import threading
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc)
+    o = make_oracle(oracle_mod, kind, sc)
     g = make_gpu(capi, sc)
     g2 = make_gpu(capi, sc)
     expect = [o.match(sc.query_init[q], sc.query_scans[q])[0] for q in range(8)]
@@ -502,7 +522,7 @@ def test_concurrent_callers_are_serialised(capi, oracle_mod, pyramid_scene):
     assert not errs, errs[:3]
 
 
-def test_randomised_geometries(capi, oracle_mod):
+def test_randomised_geometries(capi, oracle_mod, kind):
     """odd map sizes (partial edge rows, cells % 4 != 0), 1..4 levels, off-centre start coordinates, random update
     factors, rooms larger than the map.  Every step matches the same scan against IDENTICAL maps on both sides
     (both maps are then updated with the oracle's pose, and stay bit-identical on every level to the end).  The
@@ -532,7 +552,7 @@ def test_randomised_geometries(capi, oracle_mod):
         scans = [synth.make_scan(world, p, n_beams, s, noise, range_max=min(30.0, ext)) for p in poses]
         origos = rng.uniform(-2, 2, (14, 2)).astype(np.float32)
 
-        o = oracle_mod.Oracle("ho", res, size, size, levels, start)
+        o = oracle_mod.Oracle(kind, res, size, size, levels, start)
         g = capi.MapRepMultiMap(res, size, size, levels, start)
         o.set_update_factor_free(free)
         g.setUpdateFactorFree(free)
@@ -575,12 +595,12 @@ def test_randomised_geometries(capi, oracle_mod):
     print(f"settled + well-determined: {settled_total}/{steps_total}")
 
 
-def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene):
+def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
     """single scans >= 4096 beams take the multi-workgroup cooperative matcher (gn_match_coop_kernel): same poses
     as the one-workgroup kernel and as the oracle, for both layouts, incl. the hook trace"""
     from hector_slam_amd import synth
     sc = pyramid_scene
-    o = make_oracle(oracle_mod, "ho", sc)
+    o = make_oracle(oracle_mod, kind, sc)
     s = float(np.float32(1.0) / np.float32(sc.resolution))
     rng = np.random.default_rng(77)
     for layout in (capi.LAYOUT_QUAD, capi.LAYOUT_PLANE):
@@ -625,13 +645,13 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene):
             assert np.array_equal(bits(pq), bits(ref[q][0])) and np.array_equal(bits(cq), bits(ref[q][1])), (rep, q)
 
 
-def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene):
+def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
     """the key planes carry a 16-bit per-scan generation; after 65535 updates (27 min at 40 Hz) it wraps and the
     planes are cleared once.  Updates straddling the wrap -- with stale keys of generation 65533..65535 left in the
     planes -- must still be bit-exact."""
     sc = pyramid_scene
     g = make_gpu(capi, sc, build=False)
-    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
     lib = capi.load_library()
     for t in range(24):
         if t == 6:
@@ -651,7 +671,7 @@ def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene):
     assert_pose_close(pg, po, "after the wrap")
 
 
-def test_single_process_device_group(capi, oracle_mod, pyramid_scene):
+def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
     """hsm_group_*: R replicas in one process (here all on device 0 -- the sharding, threading and replica
     consistency logic is the same as with R devices).  Batched matching over the group == one context, bit for
     bit and in order; the SLAM cycle keeps every replica's map identical to a single context's and to the oracle's"""
@@ -661,7 +681,7 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene):
     assert grp.size() == 3
     grp.set_update_factors(0.4, 0.9)
     one = make_gpu(capi, sc, build=False)
-    o = make_oracle(oracle_mod, "ho", sc, build=False)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
     o.proc_set_thresholds(0.0, 0.0)
     origo = np.array([0.2, -0.1], np.float32) * np.float32(sc.scale_to_map)
     hint = sc.build_poses[0].copy()
@@ -697,14 +717,14 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene):
 
 
 @pytest.mark.parametrize("levels", [1, 2, 5])
-def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, levels):
+def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, levels, kind):
     """level counts other than the default 3 (MapRepSingleMap-like 1, launch-file default 2, deep 5), a reset in the
     middle of a run, update factors changed on the fly (they only affect later updates), a first scan mapped without
     matching: poses follow the oracle; with identical poses the maps are bit-identical"""
     from hector_slam_amd import synth
     sc = synth.make_scene(n_beams=720, map_size=1024, levels=levels, resolution=0.05, n_build=40, n_query=2,
                           room=(30.0, 22.0), seed=31 + levels)
-    o = oracle_mod.Oracle("ho", sc.resolution, sc.map_size, sc.map_size, levels)
+    o = oracle_mod.Oracle(kind, sc.resolution, sc.map_size, sc.map_size, levels)
     g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, levels)
     assert g.getMapLevels() == levels == o.levels() and g.gn_iterations_per_match() == 6 + 4 * (levels - 1)
 
@@ -892,6 +912,91 @@ def test_queued_updates_are_ordered_against_caller_streams(capi, pyramid_scene, 
         side.synchronize()
         m.synchronize()
         outs[name].append(d_pose.cpu().numpy().copy())
+    for a, b in zip(outs["ref"], outs["dut"]):
+        assert np.array_equal(bits(a), bits(b))
+    for lvl in range(sc.levels):
+        la, lb = ref.download_level(lvl), dut.download_level(lvl)
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1])
+
+
+def test_scans_longer_than_the_length_hint(capi, pyr, pyramid_scene):
+    """hsm_match_batch_device sizes its kernel form from a HINT (`shared_n` with CSR offsets: typical beams per scan,
+    0 = unknown).  Scans longer than the hint -- beyond the 64 * BPL beams the texel-cache / register-resident forms
+    keep on chip -- must be matched completely: same bits as the form that streams every beam from memory."""
+    import torch
+    from hector_slam_amd import synth
+    _, o = pyr
+    sc = pyramid_scene
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1)  # the throughput forms
+    for lvl in range(sc.levels):
+        g.upload_level(lvl, *o.download_level(lvl))
+    long_scan = np.concatenate([sc.query_scans[3], sc.query_scans[3][::2] + np.float32(0.01)])  # 1622 beams
+    scans = [sc.query_scans[0], long_scan, sc.query_scans[1][:300], long_scan[:1100], sc.query_scans[2]]
+    init = np.stack([sc.query_init[0], sc.query_init[3], sc.query_init[1], sc.query_init[3], sc.query_init[2]])
+    pts, offs = synth.pack_scans(scans)
+    ref_pose, ref_cov = g.match_batch(init, pts, offs)  # host entry: sized from the true maximum (memory loop)
+    assert g.last_launch_config()["beams_per_lane"] == 0
+    dev = torch.device("cuda", 0)
+    d_init, d_pts, d_offs = (torch.from_numpy(a).to(dev) for a in (init, pts, offs))
+    stream = torch.cuda.current_stream()
+    forms = set()
+    for hint in (0, 1081, 500, 300, 100):  # texel-cache BPL 17 / 9, register-resident BPL 5 / 2
+        d_pose = torch.zeros((len(scans), 3), dtype=torch.float32, device=dev)
+        d_cov = torch.zeros((len(scans), 9), dtype=torch.float32, device=dev)
+        g.match_batch_device(len(scans), d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), hint,
+                             d_pose.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        cfg = g.last_launch_config()
+        forms.add((cfg["texel_cache"], cfg["beams_per_lane"]))
+        assert np.array_equal(bits(d_pose.cpu().numpy()), bits(ref_pose)), (hint, cfg)
+        assert np.array_equal(bits(d_cov.cpu().numpy()), bits(ref_cov)), (hint, cfg)
+    assert len(forms) >= 4, forms
+    po, _ = o.match(init[1], long_scan)
+    assert_pose_close(ref_pose[1], po, "1622-beam scan")
+
+
+def test_two_caller_streams_are_each_ordered_against_updates(capi, pyramid_scene, monkeypatch):
+    """the same with matches in flight on TWO caller-owned streams inside one update epoch: each stream is ordered
+    behind the queued updates on its own, and the next update waits for both (the ordering state is per stream)"""
+    import torch
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("HSM_ASYNC_UPDATE", "0")
+    ref = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    monkeypatch.delenv("HSM_ASYNC_UPDATE")
+    dut = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    for m in (ref, dut):
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+    B = 256
+    full = sc.query_scans[0]
+    init = np.repeat(sc.query_init[0:1], B, 0) + np.random.default_rng(3).uniform(-0.03, 0.03, (B, 3)).astype(np.float32) * np.float32([1, 1, 0.2])
+    d_init = torch.from_numpy(init).to(dev)
+    d_pts = torch.from_numpy(np.ascontiguousarray(full)).to(dev)
+    sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    rng = np.random.default_rng(8)
+    sfac = float(np.float32(1.0) / np.float32(sc.resolution))
+    dense = [synth.make_scan(sc.world, sc.build_poses[t], 16384, sfac, rng) for t in range(24)]
+    outs = {"ref": [], "dut": []}
+    for name, m in (("ref", ref), ("dut", dut)):
+        d_pose = [torch.zeros((B, 3), dtype=torch.float32, device=dev) for _ in sides]
+        for t in range(24):
+            m.matchData(sc.build_poses[t], dense[t])
+            m.updateByScan(dense[t], sc.build_poses[t])
+            for k, side in enumerate(sides):  # second stream: first call of this epoch on that stream, too
+                m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), 0, full.shape[0], d_pose[k].data_ptr(), 0,
+                                     side.cuda_stream)
+                if name == "ref":
+                    side.synchronize()
+            if t % 3 == 2:
+                for side in sides:
+                    side.synchronize()
+                outs[name].append(np.stack([p.cpu().numpy() for p in d_pose]))
+        for side in sides:
+            side.synchronize()
+        m.synchronize()
+        outs[name].append(np.stack([p.cpu().numpy() for p in d_pose]))
     for a, b in zip(outs["ref"], outs["dut"]):
         assert np.array_equal(bits(a), bits(b))
     for lvl in range(sc.levels):

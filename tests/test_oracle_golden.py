@@ -10,6 +10,12 @@ from conftest import bits
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(scope="module", autouse=True, params=["cpu", pytest.param("gpubox", marks=pytest.mark.gpu)])
+def where(request):
+    """runs in the CPU suite and again (gpu-marked, no device needed) in the GPU box's `-m gpu` run"""
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def g1():
     return np.load(os.path.join(GOLD, "config1_181beam_256map.npz"))

@@ -7,7 +7,13 @@ import pytest
 
 from conftest import bits, make_oracle
 
-pytestmark = pytest.mark.skipif(False, reason="")
+
+
+@pytest.fixture(scope="module", autouse=True, params=["cpu", pytest.param("gpubox", marks=pytest.mark.gpu)])
+def where(request):
+    """every test of this module runs twice: in the CPU suite, and (gpu-marked, no device needed) in the GPU box's
+    `-m gpu` run, so that the pin of the restatement to the reference shows up in the driver's own GPU-box log"""
+    return request.param
 
 
 @pytest.fixture(scope="module")
