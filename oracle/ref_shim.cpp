@@ -10,6 +10,7 @@
 // GPU box with the snapshot).  Used to pin oracle/hector_oracle.cpp bit-for-bit
 // and as the "reference" CPU baseline in bench.py.
 #include "slam_main/HectorSlamProcessor.h"
+#include "hector_map_tools/HectorMapTools.h"  // f4: -I $(REFROOT)/hector_map_tools/include, nav_msgs from oracle/stubs
 
 #include <mutex>
 #include <sstream>
@@ -252,36 +253,31 @@ void hr_covariance_for_poses(void* h, int level, int batch, const float* poses, 
     }
   }
 }
-// f4 lives in hector_map_tools (needs nav_msgs); restatement only, same symbol set in both libraries
+// f4 through the reference's own code: hectormaptools' DistanceMeasurementProvider::getDist, the UNMODIFIED
+// hector_map_tools/include/hector_map_tools/HectorMapTools.h:132-234 compiled against a stand-in for the two
+// generated message headers it includes (oracle/stubs/nav_msgs/).  One provider per call; the grid is copied into
+// the message's data vector exactly as hector_map_server receives it.
 void hr_ray_distances(const signed char* grid, int sx, int sy, float ox, float oy, float res, int n, const float* bw,
                       const float* ew, float* out_dist, float* out_hit) {
-  const float inv = 1.0f / res;
+  std::shared_ptr<nav_msgs::OccupancyGrid> map(new nav_msgs::OccupancyGrid());
+  map->info.resolution = res;
+  map->info.width = (uint32_t)sx;
+  map->info.height = (uint32_t)sy;
+  map->info.origin.position.x = ox;
+  map->info.origin.position.y = oy;
+  map->data.assign(grid, grid + (size_t)sx * sy);
+  HectorMapTools::DistanceMeasurementProvider dmp;
+  dmp.setMap(map);
   for (int r = 0; r < n; ++r) {
-    const int x0 = (int)((bw[2 * r] - ox) * inv), y0 = (int)((bw[2 * r + 1] - oy) * inv);
-    const int x1 = (int)((ew[2 * r] - ox) * inv), y1 = (int)((ew[2 * r + 1] - oy) * inv);
-    float dist = -1.0f;
-    if (x0 >= 0 && x0 < sx && y0 >= 0 && y0 < sy && x1 >= 0 && x1 < sx && y1 >= 0 && y1 < sy) {
-      int dx = x1 - x0, dy = y1 - y0;
-      unsigned adx = abs(dx), ady = abs(dy);
-      int oa = dx > 0 ? 1 : -1, ob = (dy > 0 ? 1 : -1) * sx;
-      unsigned da = adx, db = ady;
-      if (adx < ady) { da = ady; db = adx; int t = oa; oa = ob; ob = t; }
-      unsigned off = y0 * sx + x0, end = da < 5000u ? da : 5000u;
-      int err = da / 2, hit = -1;
-      for (unsigned i = 0; i < end; ++i) {
-        if (grid[off] == 100) { hit = (int)off; break; }
-        off += oa; err += db;
-        if ((unsigned)err >= da) { off += ob; err -= da; }
-      }
-      if (hit != -1) {
-        Eigen::Vector2i b(x0, y0), e(hit % sx, hit / sx);
-        int distMap = ((b - e).cast<float>()).norm();
-        dist = distMap;
-        out_hit[2 * r] = ox + ((float)e[0] * res);
-        out_hit[2 * r + 1] = oy + ((float)e[1] * res);
-      }
+    // getDist writes hitCoords from an UNINITIALISED end_point_map when there is no hit (HectorMapTools.h:146-156):
+    // only the distance says whether the hit is meaningful
+    Eigen::Vector2f hit(0.0f, 0.0f);
+    const float d = dmp.getDist(Eigen::Vector2f(bw[2 * r], bw[2 * r + 1]), Eigen::Vector2f(ew[2 * r], ew[2 * r + 1]), &hit);
+    out_dist[r] = d;
+    if (d >= 0.0f) {
+      out_hit[2 * r] = hit[0];
+      out_hit[2 * r + 1] = hit[1];
     }
-    out_dist[r] = res * dist;
   }
 }
 // f2 through the reference's own GridMap::isFree / isOccupied (GridMapLogOdds.h:76-84)

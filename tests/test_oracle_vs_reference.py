@@ -232,3 +232,46 @@ def test_reference_shim_is_thread_safe_about_stdout(oracle_mod, small_scene):
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_ray_distance_restatement_equals_hector_map_tools(oracle_mod):
+    """f4: the restatement of DistanceMeasurementProvider::getDist ("ho") against the UNMODIFIED
+    hector_map_tools/HectorMapTools.h:132-234 ("hr", compiled against the nav_msgs stand-in) -- 12k random rays on a
+    6000 x 400 grid: rays inside and outside the map, zero-length and axis-aligned rays, and rays longer than the
+    5000-step cap of bresenham2D (a wall beyond step 5000 must NOT be found)."""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref/libhector_ref.so not built (needs /root/reference)")
+    rng = np.random.default_rng(44)
+    sx, sy, res = 6000, 400, 0.05
+    grid = np.full((sy, sx), -1, np.int8)
+    grid[rng.random((sy, sx)) < 0.002] = 100      # sparse obstacles
+    grid[rng.random((sy, sx)) < 0.3] = 0
+    grid[:, 5600:5603] = 100                      # a wall 5600 cells out: beyond the cap for rays starting at x < 600
+    grid[:, 0:560] = np.where(grid[:, 0:560] == 100, 0, grid[:, 0:560])  # keep the start region free
+    grid[180:220, 560:5590] = 0                   # ... and a free corridor to the wall
+    ox, oy = -3.0, -7.5
+    n = 12000
+    begin = np.stack([rng.uniform(ox, ox + sx * res, n), rng.uniform(oy, oy + sy * res, n)], 1).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    length = rng.uniform(0.0, 40.0, n)
+    end = (begin + np.stack([np.cos(ang), np.sin(ang)], 1) * length[:, None]).astype(np.float32)
+    end[:50] = begin[:50]
+    begin[50:100] += 1000.0
+    end[100:150] -= 1000.0
+    end[150:200, 1] = begin[150:200, 1]
+    end[200:250, 0] = begin[200:250, 0]
+    # the capped ones: along the corridor from x < 560 cells to beyond the wall (> 5000 major steps away)
+    begin[250:450] = np.stack([ox + rng.uniform(1, 550, 200) * res, oy + rng.uniform(182, 218, 200) * res], 1)
+    end[250:450] = np.stack([np.full(200, ox + 5900 * res), begin[250:450, 1] + rng.uniform(-0.05, 0.05, 200)], 1)
+    d_o, h_o = oracle_mod.ray_distances("ho", grid, (ox, oy), res, begin, end)
+    d_r, h_r = oracle_mod.ray_distances("hr", grid, (ox, oy), res, begin, end)
+    assert np.array_equal(bits(d_o), bits(d_r))
+    has = d_r >= 0
+    assert np.array_equal(bits(h_o[has]), bits(h_r[has]))
+    assert np.isnan(h_o[~has]).all() and np.isnan(h_r[~has]).all()
+    assert (d_r[250:450] < 0).all()               # the cap: the wall 5000+ steps away is not seen
+    near = begin[250:450].copy()
+    near[:, 0] += 100 * res * 5                   # the same rays started 500 cells closer do see it
+    d2, _ = oracle_mod.ray_distances("hr", grid, (ox, oy), res, near[near[:, 0] > ox + 700 * res], end[250:450][near[:, 0] > ox + 700 * res])
+    assert (d2 > 0).all() and d2.size > 20
+    assert 0.1 < has.mean() < 0.95
