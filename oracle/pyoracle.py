@@ -15,8 +15,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBS = {"ho": os.path.join(_HERE, "build", "libhector_oracle.so"),
-         "hr": os.path.join(_HERE, "_ref", "libhector_ref.so")}
+_SAN = os.environ.get("HSM_ORACLE_SAN") == "1"  # tools/sanitize_cpu.sh: the ASan/UBSan builds (make -C oracle SAN=1)
+_LIBS = {"ho": os.path.join(_HERE, "build", *(["san"] if _SAN else []), "libhector_oracle.so"),
+         "hr": os.path.join(_HERE, "_ref", *(["san"] if _SAN else []), "libhector_ref.so")}
 _loaded: dict = {}
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -25,7 +26,7 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(quiet: bool = True) -> None:
     """make -C oracle: restatement always; _ref only where /root/reference exists."""
-    subprocess.run(["make", "-C", _HERE], check=True,
+    subprocess.run(["make", "-C", _HERE] + (["SAN=1"] if _SAN else []), check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
 
 

@@ -20,7 +20,8 @@ import pytest
 from conftest import ang_diff, make_oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_BIN = os.path.join(ROOT, "oracle", "_ref", "slam_driver_ref")
+_SAN = ["san"] if os.environ.get("HSM_ORACLE_SAN") == "1" else []  # tools/sanitize_cpu.sh: the ASan/UBSan build
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", *_SAN, "slam_driver_ref")
 GPU_BIN = os.path.join(ROOT, "oracle", "_ref", "slam_driver_mi355")
 FACADE = os.path.join(ROOT, "include", "hector_slam_lib", "slam_main", "MapRepMultiMap.h")
 
