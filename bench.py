@@ -8,20 +8,29 @@ resident in HBM.  With --gpus N every rank holds a replica of the map and its ow
 one collective of the path -- an RCCL all-gather of the [B,3] poses -- is double buffered and asynchronous.  Rank 0
 prints ONE JSON line (see the driver contract in the task description).
 
-Extra evidence in the same line:
-  roofline      dominant kernel (gn_match_kernel), one HIP event pair on its stream around the timed region;
-                achieved = algorithmic bytes per launch ((24*N + 60) B per GN iteration) / mean
-                launch time; peak = 8 TB/s HBM3E; traffic = PMC-measured HBM bytes per launch (profiles/r01);
-                plus the limit that actually binds (VALU-issue floor) -- DESIGN.md 3.1
+Extra evidence in the same line (N = 1 only):
+  roofline      dominant kernel, one HIP event pair on its stream around the timed region.  `bound` names what binds
+                it -- VALU instruction issue -- and achieved / peak / frac are wave64 VALU instructions per second
+                against 1024 SIMDs x clock / 2 cycles, from counters collected IN THIS RUN: bench.py re-executes itself
+                (`--leg pmc`) under `rocprofv3 --pmc`, one pass per counter group.  `traffic` / `hbm` = HBM bytes per
+                launch from the same passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction).  `contract`
+                keeps SURVEY.md 8(d)'s figure (algorithmic bytes / time against 8 TB/s), labelled: it exceeds 1 because
+                endpoints and texels are served on chip, i.e. it is not a utilisation of anything.
+  exact_parity  the same launch in HSM_PARITY_EXACT (reference summation order): throughput, and the fraction of poses
+                bit-identical to the reference on the parity sample (1.0)
+  pyramid       the same batch through the full 3-level 2048/1024/512 schedule (14 iterations, SURVEY.md 8(d)'s start
+                errors +-0.15 m / +-0.05 rad), fast and exact mode, parity fractions vs the reference -- measured in a
+                child process (`--leg pyramid`), so that a kernel trace of this process holds the headline launches only
   cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and scans, single
                 thread (the reference is single threaded), bounded sample, plus the GPU-vs-CPU pose deviation on
                 that sample (parity evidence, tolerance 1e-4) and the fraction of bit-identical poses;
                 cpu_baseline_all_cores: the same on up to 64 host threads
-  pyramid       (--pyramid) the same batch through the full 3-level 2048/1024/512 schedule (14 iterations);
-                `--workload config3pyr` is the stand-alone form of it
 
---workload config2|config3pyr|config4|config5 measures the other BASELINE configs on one GPU (latency of a single
-scan, 3-level batch, 4096^2 pyramid, dense 16k-beam match+update loop), same JSON schema.
+--workload config2|config3pyr|config4|config5 measures the other BASELINE configs (latency of a single scan, 3-level
+batch, 4096^2 pyramid, dense 16k-beam match+update loop), same JSON schema.  config3pyr / config4 / config5 also run
+with --gpus N: config4 is configs[3] itself at N = 8 (4096 scans per GPU on the 3-level 4096^2 pyramid, all-gather of
+the poses); config5 is configs[4] (replicated pyramid: rank 0 matches, pose + scan are broadcast, every rank replays the
+update, the maps are compared across ranks at the end).
 """
 from __future__ import annotations
 
@@ -180,11 +189,14 @@ def cpu_baseline_all_cores(build_poses, build_scans, init, pts, offs, levels: in
             "sample": f"{sum(done)} matchData calls in {dt:.1f} s on {T} threads, one private map + matcher per thread"}
 
 
-def extra_workload(name: str, args, local_rank: int):
-    """Single-GPU measurement of one of the non-headline BASELINE configs; prints one JSON line in the same
-    schema (metric = GN iterations/s of that workload; roofline on its matcher launch; reference CPU leg)."""
+def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int = 1):
+    """One of the non-headline BASELINE configs; rank 0 prints one JSON line in the same schema (metric = GN
+    iterations/s of that workload; roofline on its matcher launch; reference CPU leg at N = 1).  With N > 1 ranks the
+    batched workloads weak-scale (own scans per rank, replicated pyramid, one all-gather of the poses per launch) and
+    config5 runs the replicated-map protocol of sharding.ReplicaSync."""
     import torch
-    from hector_slam_amd import capi, synth
+    import torch.distributed as dist
+    from hector_slam_amd import capi, sharding, synth
     beams, size, res, room, rmax, levels, batch = WORKLOADS[name]
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream()
@@ -202,7 +214,7 @@ def extra_workload(name: str, args, local_rank: int):
         o.set_update_factor_occupied(0.9)
         return o, ("reference" if kind == "hr" else "port")
 
-    out = {"metric": "scan-match GN iterations/sec", "unit": "GN it/s", "n_gpus": 1, "steps": args.steps,
+    out = {"metric": "scan-match GN iterations/sec", "unit": "GN it/s", "n_gpus": nranks, "steps": args.steps,
            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic"}
 
@@ -225,17 +237,45 @@ def extra_workload(name: str, args, local_rank: int):
             m.onMapUpdated()
         pose = poses[0]
         gpu_poses = []
+        # N > 1 (configs[4] on a node): one dense scan does not shard -- every rank holds a replica of the pyramid,
+        # rank 0 matches, ONE broadcast carries pose + scan, every rank replays the (deterministic) update
+        sync = sharding.ReplicaSync(beams, dev) if nranks > 1 else None
+        lib = capi.load_library()
         for t in range(1, T + 1):
             if t == args.warmup + 1:
                 m.synchronize()
+                if nranks > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            hint = pose + (poses[t] - poses[t - 1])
-            pose, _ = m.matchData(hint, scans[t])
-            m.updateByScan(scans[t], pose)     # returns when queued; the next matchData waits behind it
+            if rank == 0:
+                hint = pose + (poses[t] - poses[t - 1])
+                pose, _ = m.matchData(hint, scans[t])
+                scan_t = scans[t]
+                if sync:
+                    sync.broadcast(pose, scan_t)
+            else:
+                pose, scan_t = sync.broadcast(None, None)
+                a = np.ascontiguousarray(scan_t, np.float32)  # what rank 0's matchData retained for the coarse levels
+                capi._check(lib.hsm_retain_scan(m._h, a.ctypes.data, a.shape[0], np.zeros(2, np.float32)), "hsm_retain_scan")
+            m.updateByScan(scan_t, pose)     # returns when queued; the next matchData waits behind it
             m.onMapUpdated()
             gpu_poses.append(pose)
         m.synchronize()  # the last update is only queued when updateByScan returns
+        if nranks > 1:
+            dist.barrier()
         dt = time.perf_counter() - t0
+        if nranks > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            dig = [sharding.map_digest(*m.download_level(lvl)) for lvl in range(levels)]
+            out["replicas"] = {"protocol": "rank 0 matchData -> broadcast [pose, n, scan] (one RCCL broadcast per step) -> "
+                                           "updateByScan replayed on every rank",
+                               "maps_identical_across_ranks": bool(sync.digests_equal(dig)), "level_digests_rank0": dig}
+            out["scaling"] = "strong"  # one SLAM instance: total work does not grow with N (replicas only)
+        if rank != 0:
+            return
         # attribution: matchData alone on the finished map (device idle before each call); the update's share
         # of a step is the rest
         tm = []
@@ -257,7 +297,7 @@ def extra_workload(name: str, args, local_rank: int):
                                  "achieved": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / 1e9,
                                  "frac": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / HBM_PEAK,
                                  "note": "host-call latency of ONE scan (H2D + launch + D2H), not a throughput kernel"}})
-        if not args.no_cpu:
+        if not args.no_cpu and nranks == 1:
             o, kind = cpu_oracle()
             o.proc_set_thresholds(0.0, 0.0)
             for k in range(n_init + 1):
@@ -289,15 +329,15 @@ def extra_workload(name: str, args, local_rank: int):
     m.setUpdateFactorFree(0.4)
     m.setUpdateFactorOccupied(0.9)
     m.build_map(build_poses, build_scans)
-    rng = np.random.default_rng(1236)
+    rng = np.random.default_rng(1236 + 7919 * rank)  # every rank matches its own scans
     nq = max(batch, 64)
     base = synth.loop_trajectory(world, nq, phase=rng.uniform(0, 2 * math.pi)).astype(np.float64)
     base[:, :2] += rng.uniform(-0.5, 0.5, size=(nq, 2)) * (room[0] / 40.0)
     base[:, 2] += rng.uniform(-0.3, 0.3, size=nq)
     truth = base.astype(np.float32)
-    rng_q = np.random.default_rng(1237)
+    rng_q = np.random.default_rng(1237 + 7919 * rank)
     scans = [synth.make_scan(world, p, beams, sfac, rng_q, pad_to_full=True, range_max=rmax) for p in truth]
-    init = synth.perturb_poses(truth, np.random.default_rng(1239), 0.15 if levels > 1 else 0.04,
+    init = synth.perturb_poses(truth, np.random.default_rng(1239 + 7919 * rank), 0.15 if levels > 1 else 0.04,
                                0.05 if levels > 1 else 0.01)
     pts, offs = synth.pack_scans(scans)
 
@@ -371,44 +411,83 @@ def extra_workload(name: str, args, local_rank: int):
         print(json.dumps(out))
         return
 
-    # batched workloads (config3pyr, config4)
+    # batched workloads (config3pyr, config4); N > 1: weak scaling, one all-gather of the [B,3] poses per launch
     B = batch
     d_init = torch.from_numpy(init).to(dev)
     d_pts = torch.from_numpy(pts).to(dev)
     d_offs = torch.from_numpy(offs).to(dev)
     d_pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
     d_cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def step():
-        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), beams, d_pose.data_ptr(),
-                             d_cov.data_ptr(), stream.cuda_stream)
+    def timed(steps, warmup):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gatherer = sharding.AsyncRowGather(B, 3, dev) if nranks > 1 else None
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average duration per launch
+        def step():
+            pose_buf = gatherer.next_local() if gatherer else d_pose
+            m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), beams, pose_buf.data_ptr(),
+                                 d_cov.data_ptr(), stream.cuda_stream)
+            if gatherer:
+                gatherer.launch()
+
+        for _ in range(warmup):
+            step()
+        if nranks > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for k in range(steps):
+            step()
+        ev1.record(stream)
+        if gatherer:
+            gatherer.wait_all()
+        if nranks > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if gatherer:
+            allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
+            d_pose.copy_(allp[rank * B:(rank + 1) * B])
+        if nranks > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, ev0.elapsed_time(ev1) / steps  # back-to-back launches: average duration per launch
+
+    dt, kern_ms = timed(args.steps, args.warmup)
     bytes_per_launch = algorithmic_bytes_per_iteration(beams) * its * B
     gpu_pose = d_pose.cpu().numpy()
-    out.update({"value": B * its * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                "matchdata_per_s": B * args.steps / dt,
-                "config": {"workload": f"{name}: batch={B} concurrent {beams}-beam scans, {levels}-level pyramid on a "
-                                       f"{size}^2 map ({res} m cells, {room[0]:.0f} m x {room[1]:.0f} m room)",
-                           "batch_per_gpu": B, "beams": beams, "map": size, "levels": levels,
-                           "gn_iterations_per_scan": its, "kernel": m.last_launch_config()},
-                "roofline": {"bound": "hbm", "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                             "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
-                             "kernel": ("gn_match_cached_kernel" if m.last_launch_config().get("texel_cache")
-                                        else "gn_match_kernel"), "kernel_ms": kern_ms,
-                             "algorithmic_bytes_per_launch": bytes_per_launch}})
-    if not args.no_cpu:
+    cfg = m.last_launch_config()
+    total = B * nranks
+    out.update({"value": total * its * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                "matchdata_per_s": total * args.steps / dt,
+                "config": {"workload": f"{name}: batch={B}/GPU concurrent {beams}-beam scans, {levels}-level pyramid on a "
+                                       f"{size}^2 map ({res} m cells, {room[0]:.0f} m x {room[1]:.0f} m room)"
+                                       + (" = BASELINE configs[3] at 8 GPUs" if name == "config4" else ""),
+                           "batch_per_gpu": B, "global_batch": total, "beams": beams, "map": size, "levels": levels,
+                           "gn_iterations_per_scan": its, "parallelism": f"dp{nranks}", "kernel": cfg},
+                "roofline": {"bound": "valu" if size <= 2048 else "l2/hbm gather latency", "kernel_ms": kern_ms,
+                             "kernel": "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel",
+                             "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                             "note": "counters for this workload: tools/pmc_config4.sh -> profiles/r02 (DESIGN.md 5)",
+                             "contract": {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_per_launch,
+                                          "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                          "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK}}})
+    if rank == 0 and not args.no_exact:
+        m.set_parity(capi.PARITY_EXACT)
+        steps_x = max(5, args.steps // 3)
+        dtx, kx = timed(steps_x, 2) if nranks == 1 else (None, None)
+        if nranks == 1:
+            exact_pose = d_pose.cpu().numpy().copy()
+            dd = np.abs(gpu_pose.astype(np.float64) - exact_pose)
+            out["exact_parity"] = {"value": B * its * steps_x / dtx, "unit": "GN it/s", "kernel_ms": kx,
+                                   "fast_vs_exact_all_scans": {
+                                       "scans": B, "bit_identical": float((gpu_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
+                                       "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
+                                       "max_abs_dxy_m": float(dd[:, :2].max())}}
+        m.set_parity(capi.PARITY_FAST)
+    if not args.no_cpu and nranks == 1:
         o, kind = cpu_oracle()
         o.build_map(build_poses, build_scans)
         n_cpu = min(B, 1024)
@@ -416,15 +495,133 @@ def extra_workload(name: str, args, local_rank: int):
         t0 = time.perf_counter()
         cpu_pose = o.match_many(init[:n_cpu], pts, offs[:n_cpu + 1])
         dtc = time.perf_counter() - t0
-        cpu2 = o.match_many(cpu_pose, pts, offs[:n_cpu + 1])
-        settled = np.abs(cpu2.astype(np.float64) - cpu_pose)[:, :2].max(1) <= 1e-3
         d = np.abs(cpu_pose.astype(np.float64) - gpu_pose[:n_cpu])
         out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
                                "sample": f"{n_cpu} matchData calls on the same map + scans, {dtc:.1f} s",
-                               "settled_fraction_of_reference": float(settled.mean()),
-                               "max_abs_dxy_m_on_settled": float(d[settled, :2].max()) if settled.any() else None,
-                               "frac_within_1e-4_all": float((d[:, :2].max(1) <= 1e-4).mean())}
-    print(json.dumps(out))
+                               "fast_mode_frac_within_1e-4": float((d[:, :2].max(1) <= 1e-4).mean()),
+                               "fast_mode_bit_identical": float((cpu_pose.view(np.uint32) == gpu_pose[:n_cpu].view(np.uint32)).all(1).mean())}
+        if "exact_parity" in out:
+            out["cpu_baseline"]["exact_mode_bit_identical"] = float(
+                (cpu_pose.view(np.uint32) == exact_pose[:n_cpu].view(np.uint32)).all(1).mean())
+    if rank == 0:
+        print(json.dumps(out))
+
+
+# ---- in-run counters: bench.py re-executes itself (`--leg pmc`) under rocprofv3, one pass per counter group -------------
+PMC_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"))
+
+
+def under_profiler() -> bool:
+    e = os.environ
+    return any(k in e for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH")) or \
+        "rocprof" in e.get("LD_PRELOAD", "")
+
+
+def run_child(extra_args, timeout_s=300, env=None):
+    """a leg of this script in a child process; returns the dict it printed as its last stdout line"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child {' '.join(extra_args)} rc={r.returncode}: {r.stderr.strip()[-300:]}"}
+    return json.loads(lines[-1])
+
+
+def pmc_leg(kernel_name: str, steps: int = 20, warmup: int = 3):
+    """mean counter values per launch of `kernel_name`, collected by rocprofv3 around `bench.py --leg pmc`"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    vals, errors = {}, []
+    for group in PMC_GROUPS:
+        with tempfile.TemporaryDirectory(prefix="hsm_pmc_", dir="/tmp") as d:
+            cmd = [rocprof, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--leg", "pmc", "--steps", str(steps), "--warmup", str(warmup)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=env)
+            except subprocess.TimeoutExpired:
+                errors.append(f"{group[0]}: timeout")
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                errors.append(f"{group[0]}: rc={r.returncode} {r.stderr.strip()[-200:]}")
+                continue
+            acc = {}
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_name in row.get("Kernel_Name", ""):
+                            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c, v in acc.items():
+                v = v[warmup:] if len(v) > warmup else v  # first launches touch cold L2 / page tables
+                vals[c] = sum(v) / len(v)
+                vals[c + "_launches"] = len(v)
+    return (vals or None), ("; ".join(errors) or None)
+
+
+def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pmc, pmc_err, clock_hz):
+    """see the module docstring: VALU-issue utilisation + in-run HBM traffic + the labelled SURVEY 8(d) contract figure"""
+    t = kern_ms * 1e-3
+    # algorithmic fp32 operations: 51 per beam and GN iteration (25 mul + 26 add/sub, unfused by construction) +
+    # ~100 per GN iteration for the 3x3 solve and the pose update; an FMA-capable lane retires 2 per cycle
+    flops = (51 * beams + 100) * its * batch
+    peak_flops = 256 * 128 * 2 * clock_hz  # 256 CUs x 128 fp32 lanes x 2 (FMA) x clock
+    rf = {"kernel": kernel_name, "kernel_ms": kern_ms,
+          "bound": "valu", "unit": "G wave64 VALU instr/s", "achieved": None, "peak": 1024 * clock_hz / 2 / 1e9,
+          "frac": None, "traffic": None,
+          "what_binds": "VALU instruction issue: 65 unfusable fp32/int instructions per beam and GN iteration (bit-exact "
+                        "formulation, no FMA), texels and endpoints served from L2 / LDS / VGPRs; not HBM, not MFMA",
+          "clock_hz": clock_hz,
+          "flops": {"algorithmic_fp32_per_launch": flops, "achieved_tflops": flops / t / 1e12,
+                    "peak_tflops_fp32_vector_fma": peak_flops / 1e12, "frac": flops / t / peak_flops},
+          "contract": {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_per_launch,
+                       "achieved": bytes_per_launch / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                       "frac": bytes_per_launch / t / HBM_PEAK,
+                       "note": "SURVEY.md 8(d) contract figure: (24 N + 60) B per GN iteration / kernel time.  NOT a "
+                               "utilisation: the model counts endpoint re-reads (kept in LDS across the iterations) and "
+                               "texel reads (served by L2) as HBM bytes, hence > 1"}}
+    if pmc:
+        src = "in-run: rocprofv3 --pmc around `bench.py --leg pmc`, one pass per group, mean per launch of this kernel"
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950: reads are tallied at half their size (guide, HBM section)
+            hbm = 2.0 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024
+            rf["traffic"] = hbm
+            rf["hbm"] = {"bytes_per_launch": hbm, "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
+                         "fetch_correction": 2.0, "achieved_GBps": hbm / t / 1e9, "peak_GBps": HBM_PEAK / 1e9,
+                         "frac": hbm / t / HBM_PEAK, "traffic_over_algorithmic": hbm / bytes_per_launch, "source": src}
+        if "SQ_INSTS_VALU" in pmc:
+            clk = clock_hz
+            rf["achieved"] = pmc["SQ_INSTS_VALU"] / t / 1e9
+            rf["frac"] = pmc["SQ_INSTS_VALU"] * 2 / (1024 * clk * t)
+            rf["valu"] = {"SQ_INSTS_VALU_per_launch": pmc["SQ_INSTS_VALU"], "per_wave": pmc["SQ_INSTS_VALU"] / max(pmc.get("SQ_WAVES", batch), 1),
+                          "SQ_ACTIVE_INST_VALU_quadcycles": pmc.get("SQ_ACTIVE_INST_VALU"),
+                          "valu_active_frac_of_simd_time": (pmc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * clk * t)
+                                                            if pmc.get("SQ_ACTIVE_INST_VALU") else None),
+                          "cycles_per_wave64_instr": (pmc["SQ_ACTIVE_INST_VALU"] * 4 / pmc["SQ_INSTS_VALU"]
+                                                      if pmc.get("SQ_ACTIVE_INST_VALU") else None),
+                          "full_rate_cycles_per_wave64_instr": 2, "source": src}
+    if rf["frac"] is None:
+        # no counters in this run (nested profiler, rocprofv3 missing, ...): the committed profile of this workload
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))[kernel_name]
+            rf["traffic"] = tj["hbm_bytes_per_launch"]
+            rf["achieved"] = tj["SQ_INSTS_VALU_per_launch"] / t / 1e9
+            rf["frac"] = tj["SQ_INSTS_VALU_per_launch"] * 2 / (1024 * clock_hz * t)
+            rf["counter_source"] = "profiles/r02/traffic.json (committed PMC profile of this workload; no counters in this run" + \
+                (": " + pmc_err if pmc_err else "") + ")"
+        except (OSError, KeyError, ValueError):
+            rf["counter_source"] = "none" + (": " + pmc_err if pmc_err else "")
+    elif pmc_err:
+        rf["pmc_errors"] = pmc_err
+    return rf
 
 
 def main():
@@ -437,15 +634,17 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="scans per GPU")
     ap.add_argument("--levels", type=int, default=1, help="pyramid levels of the headline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--pyramid", action="store_true",
-                    help="also run the same batch through the full 3-level matchData (extra 'pyramid' field; off by "
-                         "default so that a kernel trace of the default command holds the headline launches only)")
-    ap.add_argument("--no-pyramid", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-pyramid", action="store_true", help="skip the 3-level pyramid leg")
+    ap.add_argument("--pyramid", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--no-exact", action="store_true", help="skip the HSM_PARITY_EXACT leg")
+    ap.add_argument("--leg", default=None, choices=["pmc", "pyramid"],
+                    help="internal: a leg of the default run executed in a child process")
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
-                    help="config3 = the headline (BASELINE configs[2]); others are single-GPU extras")
+                    help="config3 = the headline (BASELINE configs[2]); others are the extra configs")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 200 if args.workload == "config3" else 30
+        args.steps = 200 if args.workload == "config3" and args.leg != "pyramid" else 30
     if args.warmup is None:
         args.warmup = 10 if args.workload == "config3" else 5
 
@@ -458,15 +657,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    if os.environ.get("HSM_BENCH_SHARE_GPU") == "1":
+        # debugging aid for 1-GPU boxes: all ranks on device 0 over gloo (RCCL refuses two ranks on one GPU).  Exercises
+        # the multi-rank code paths only; the numbers mean nothing.
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("HSM_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.workload != "config3":
-        assert world == 1, "the extra workloads are single-GPU measurements"
-        extra_workload(args.workload, args, local_rank)
+        assert world == 1 or args.workload != "config2", "config2 is the single-scan latency measurement"
+        extra_workload(args.workload, args, local_rank, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     B = args.batch
@@ -532,26 +741,56 @@ def main():
         kern_ms = ev0.elapsed_time(ev1) / steps
         return dt, kern_ms, its
 
+    def kernel_of(cfg):
+        if cfg.get("parity") == "exact":
+            return "gn_match_kernel"
+        return "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
+
+    # ---------------- child legs -------------------------------------------------------------------------------
+    if args.leg == "pmc":  # the headline launches only, for the counter passes of the parent
+        matcher = build_matcher(1)
+        run(matcher, d_init_l0, args.steps, args.warmup)
+        return
+    if args.leg == "pyramid":  # full 3-level matchData, SURVEY.md 8(d)'s start errors, both parity modes
+        m3 = build_matcher(3)
+        res = {"levels": 3, "start_error": "+-0.15 m, +-0.05 rad (SURVEY.md 8(d))", "unit": "GN it/s"}
+        poses = {}
+        for mode, name in ((capi.PARITY_FAST, "fast"), (capi.PARITY_EXACT, "exact")):
+            m3.set_parity(mode)
+            steps3 = args.steps if mode == capi.PARITY_FAST else max(5, args.steps // 3)
+            dt3, k3, its3 = run(m3, d_init_pyr, steps3, 3, gather=False)
+            poses[name] = d_pose.cpu().numpy().copy()
+            res[name] = {"value": B * its3 * steps3 / dt3, "matchdata_per_s": B * steps3 / dt3, "kernel_ms": k3,
+                         "kernel": kernel_of(m3.last_launch_config()), "steps": steps3}
+        res["gn_iterations_per_scan"] = its3
+        res["value"] = res["fast"]["value"]
+        if not args.no_cpu:
+            for name in ("fast", "exact"):
+                res[name]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init_pyr, pts, offs, poses[name], 3,
+                                                          budget_s=0.0, n_par=512)
+        d = np.abs(poses["fast"].astype(np.float64) - poses["exact"])
+        res["fast_vs_exact_all_scans"] = {"scans": B, "within_1e-4": float(((d[:, :2].max(1) <= 1e-4) & (d[:, 2] <= 1e-4)).mean()),
+                                          "bit_identical": float((poses["fast"].view(np.uint32) == poses["exact"].view(np.uint32)).all(1).mean()),
+                                          "max_abs_dxy_m": float(d[:, :2].max())}
+        print(json.dumps(res))
+        return
+
+    # ---------------- the headline ---------------------------------------------------------------------------------
     matcher = build_matcher(args.levels)
     dt, kern_ms, its = run(matcher, d_init_l0 if args.levels == 1 else d_init_pyr, args.steps, args.warmup)
     gpu_pose = d_pose.cpu().numpy()
     cfg = matcher.last_launch_config()
     value = total * its * args.steps / dt
     bytes_per_launch = algorithmic_bytes_per_iteration(N_BEAMS) * its * B
-    achieved = bytes_per_launch / (kern_ms * 1e-3)
+    kernel_name = kernel_of(cfg)
+    clock_hz = matcher.device_info()["clock_khz"] * 1e3
 
-    # HBM traffic of the dominant kernel from the committed PMC profile of THIS workload (rocprofv3 cannot run
-    # inside the timed process); null when the run is not the profiled configuration
-    traffic = floor_ms = None
-    kernel_name = "gn_match_kernel"
-    try:
-        kernel_name = "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))[kernel_name]
-        if B == BATCH_PER_GPU and args.levels == 1:
-            traffic = tj["hbm_bytes_per_launch"]
-            floor_ms = tj.get("valu_issue_floor_ms")
-    except (OSError, KeyError, ValueError):
-        pass
+    pmc = pmc_err = None
+    if rank == 0 and world == 1 and not args.no_pmc and B == BATCH_PER_GPU and args.levels == 1:
+        if under_profiler():
+            pmc_err = "this process already runs under a profiler"
+        else:
+            pmc, pmc_err = pmc_leg(kernel_name)
     out = {
         "metric": "scan-match GN iterations/sec (1081-beam, 2048^2 map)",
         "value": value, "unit": "GN it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -561,47 +800,44 @@ def main():
                                f"pairs), {MAP_SIZE}^2 map, {args.levels}-level matchData = {its} GN it/scan",
                    "batch_per_gpu": B, "global_batch": total, "beams": N_BEAMS, "map": MAP_SIZE,
                    "levels": args.levels, "gn_iterations_per_scan": its, "parallelism": f"dp{world}",
+                   "start_error": "+-0.04 m, +-0.01 rad (level-0-only run: no coarse levels to pull a far start in; "
+                                  "the `pyramid` leg uses SURVEY.md 8(d)'s +-0.15 m / +-0.05 rad)",
                    "kernel": cfg},
         "matchdata_per_s": total * args.steps / dt,
-        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 "
-                                     "correction calibrated on known-byte kernels), profiles/r01/traffic.json; the "
-                                     "algorithmic bytes are 13.5x larger because endpoints stay on chip across the 6 "
-                                     "iterations and the texel plane is served from L2 -- frac > 1 is NOT an HBM "
-                                     "utilisation, the kernel is VALU-issue + texture-path bound (DESIGN.md 3.1)",
-                     "kernel": kernel_name, "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "frac_of_measured_copy_bw_6.29TBps": achieved / 6.29e12,
-                     # the limit that actually binds: instruction issue of the bit-exact beam body (measured with
-                     # all lanes on one texel, profiles/r01); frac_of_valu_floor = that floor / this run's kernel time
-                     "hbm_gbps_from_pmc_traffic": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-                     "valu_issue_floor_ms": floor_ms,
-                     "frac_of_valu_floor": (floor_ms / kern_ms) if floor_ms else None},
+        "roofline": roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz),
     }
     conv = np.abs(gpu_pose.astype(np.float64) - truth.astype(np.float64))
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
                           "median_abs_err_theta_rad": float(np.median(conv[:, 2]))}
 
-    if args.pyramid and not args.no_pyramid and args.levels == 1:
-        m3 = build_matcher(3)
-        steps3 = max(3, args.steps // 3)
-        dt3, k3, its3 = run(m3, d_init_pyr, steps3, 2, gather=True)
-        out["pyramid"] = {"levels": 3, "gn_iterations_per_scan": its3,
-                          "value": total * its3 * steps3 / dt3, "unit": "GN it/s",
-                          "matchdata_per_s": total * steps3 / dt3, "kernel_ms": k3,
-                          "start_error": "+-0.15 m, +-0.05 rad"}
-        if rank == 0 and world == 1 and not args.no_cpu:  # parity only (no timing) for the pyramid
-            out["pyramid"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init_pyr, pts, offs,
-                                                           d_pose.cpu().numpy(), 3, budget_s=0.0, n_par=256)
-        m3.close()
-
-    if rank == 0 and world == 1 and not args.no_cpu:
+    single = rank == 0 and world == 1
+    if single and not args.no_exact:
+        matcher.set_parity(capi.PARITY_EXACT)
+        steps_x = max(10, args.steps // 4)
+        dtx, kx, _ = run(matcher, d_init_l0 if args.levels == 1 else d_init_pyr, steps_x, 3)
+        exact_pose = d_pose.cpu().numpy().copy()
+        matcher.set_parity(capi.PARITY_FAST)
+        dd = np.abs(gpu_pose.astype(np.float64) - exact_pose)
+        out["exact_parity"] = {"mode": "HSM_PARITY_EXACT: H/dTr summed in the reference's beam order (9 sequential fp32 "
+                                       "chains per scan); poses bit-identical to the reference",
+                               "value": B * its * steps_x / dtx, "unit": "GN it/s", "kernel_ms": kx, "steps": steps_x,
+                               "kernel": kernel_of({"parity": "exact"}),
+                               "fast_vs_exact_all_scans": {
+                                   "scans": B, "bit_identical": float((gpu_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
+                                   "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
+                                   "max_abs_dxy_m": float(dd[:, :2].max())}}
+        if not args.no_cpu:
+            out["exact_parity"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init if args.levels == 1 else init_pyr,
+                                                                pts, offs, exact_pose, args.levels, budget_s=0.0, n_par=512)
+    if single and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(build_poses, build_scans, init if args.levels == 1 else init_pyr, pts,
                                            offs, gpu_pose, args.levels)
         out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(build_poses, build_scans,
                                                                init if args.levels == 1 else init_pyr, pts, offs,
                                                                args.levels)
+    if single and not args.no_pyramid and args.levels == 1:
+        out["pyramid"] = run_child(["--leg", "pyramid", "--steps", str(max(10, args.steps // 4)), "--batch", str(B)] +
+                                   (["--no-cpu"] if args.no_cpu else []))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -98,6 +98,7 @@ SIGNATURES = {
     "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
+    "hsm_device_info": (_i, [_vp, _i32p]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
     "hsm_last_error": (C.c_char_p, []),
@@ -397,6 +398,11 @@ class MapRepMultiMap:
         _check(self._lib.hsm_match_batch_device(self._h, batch, d_begin, d_pts, d_offsets or None, shared_n,
                                                 d_out_pose, d_out_cov or None, stream or None),
                "hsm_match_batch_device")
+
+    def device_info(self):
+        a = np.empty(4, np.int32)
+        _check(self._lib.hsm_device_info(self._h, a), "hsm_device_info")
+        return {"device": int(a[0]), "compute_units": int(a[1]), "clock_khz": int(a[2]), "memory_clock_khz": int(a[3])}
 
     def gn_iterations_per_match(self) -> int:
         return self._lib.hsm_gn_iterations_per_match(self._h)

@@ -714,6 +714,17 @@ int hsm_set_parity(hsm_ctx* h, int mode) {
 }
 int hsm_parity(const hsm_ctx* h) { return (h && h->exact) ? HSM_PARITY_EXACT : HSM_PARITY_FAST; }
 
+int hsm_device_info(const hsm_ctx* h, int info[4]) {
+  if (!h || !info) return fail(HSM_ERR_INVALID, "null argument");
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, h->device));
+  info[0] = h->device;
+  info[1] = p.multiProcessorCount;
+  info[2] = p.clockRate;        // kHz
+  info[3] = p.memoryClockRate;  // kHz
+  return HSM_OK;
+}
+
 int hsm_gn_iterations_per_match(const hsm_ctx* h) {
   return h ? 6 + 4 * ((int)h->levels.size() - 1) : 0;
 }

@@ -286,6 +286,8 @@ int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
 /* device expf(x) and getGridProbability(x) = e/(e+1) of n values -- numerics test hook */
 int hsm_debug_expf(hsm_ctx* h, int n, const float* x, float* out_exp, float* out_prob);
 
+/* the context's device: {HIP ordinal, compute units, shader clock kHz, memory clock kHz} (roofline arithmetic of bench.py) */
+int hsm_device_info(const hsm_ctx* h, int info[4]);
 /* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
 int hsm_gn_iterations_per_match(const hsm_ctx* h);
 /* effective kernel configuration of the last match launch:

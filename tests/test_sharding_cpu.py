@@ -111,3 +111,51 @@ def test_shard_bounds_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1 and max(sizes) == sharding.max_shard(total, world)
+
+
+def _worker_replica(rank, world, port, q):
+    """configs[4] protocol on CPU: the CPU oracle stands in for the GPU replica (same deterministic updateByScan)"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from hector_slam_amd import sharding, synth
+    from oracle import pyoracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = synth.make_scene(n_beams=181, map_size=128, levels=2, resolution=0.1, n_build=10, n_query=1,
+                              room=(10.0, 8.0), seed=5)
+        rep = pyoracle.Oracle("ho", sc.resolution, sc.map_size, sc.map_size, sc.levels)
+        sync = sharding.ReplicaSync(max_beams=256, device="cpu")
+        pose = sc.build_poses[0].copy()
+        for t in range(8):
+            if rank == 0:  # the scan arrives at rank 0 only, which matches it (a no-op on the still empty map)
+                scan = sc.build_scans[t]
+                hint = pose + (sc.build_poses[t] - sc.build_poses[max(t - 1, 0)])
+                pose = rep.match(hint, scan)[0]
+                pose_b, scan_b = sync.broadcast(pose, scan)
+            else:
+                pose_b, scan_b = sync.broadcast(None, None)
+                rep.match(pose_b, scan_b)  # retains the coarse-level containers like rank 0's matchData did
+            rep.update_by_scan(pose_b, scan_b)
+            rep.on_map_updated()
+        dig = [sharding.map_digest(*rep.download_level(lvl)) for lvl in range(sc.levels)]
+        same = sync.digests_equal(dig)
+        bad = sync.digests_equal([d + rank for d in dig])  # negative control: rank-dependent digests must differ
+        q.put((rank, same, bad, dig))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replica_replay_keeps_maps_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_replica, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(same for _, same, _, _ in res) and not any(bad for _, _, bad, _ in res)
+    assert res[0][3] == res[1][3] and all(d > 0 for d in res[0][3])
