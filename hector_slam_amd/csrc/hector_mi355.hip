@@ -107,6 +107,7 @@ struct hsm_ctx {
   hipEvent_t evt_updates = nullptr, evt_foreign = nullptr;
   bool async_update = true;
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
+  int merged_mark_max = 4096;       // scans below this take the one-launch mark pass (env HSM_MERGED_MARK_MAX, 0 = never)
   float2* h_upd_pinned[2] = {nullptr, nullptr};
   size_t h_upd_cap[2] = {0, 0};
   hipEvent_t upd_evt[2] = {nullptr, nullptr};
@@ -383,14 +384,29 @@ int valid_level(const hsm_ctx* h, int level) {
   return HSM_OK;
 }
 
-// OccGridMapBase::updateByScan on one level (OccGridMapBase.h:121-168).  pts are LEVEL-0
-// endpoints on the device; pt_scale/origo bring them to this level.  h_pts (host copy of
-// the same points) is only used for the touched bounding box.
-// Fills batch.lv[batch.nlev] (and bumps nlev) when the level has work; the launches happen once for all
-// levels in launch_update_batch().
-int update_level(hsm_ctx* h, UpdateBatch& batch, int level, const float pose_world[3], const float2* d_pts,
-                 const float* h_pts, int n, float pt_scale, const float origo_level[2]) {
+// OccGridMapBase::updateByScan on one level (OccGridMapBase.h:121-168), host side, in two steps so that the GPU can
+// start on the scan while the host is still busy:
+//   prepare_level()  counters, the pose transform, the begin cell and everything the MARK pass needs -> batch.lv[]
+//                    (every level with n > 0; the box fields are left empty)
+//   -- the mark pass of all levels is launched here --
+//   level_bbox()     the cell box of everything the scan can touch (what the dense APPLY / texel passes run over):
+//                    computed on the host from the host copy of the endpoints while the mark pass runs, or derived
+//                    from a finer level's box (see below)
+// pts are LEVEL-0 endpoints on the device; pt_scale/origo bring them to this level.
+struct LevelPrep {
+  int level = -1;
+  int slot = -1;          // index in batch.lv, -1 = nothing to launch for this level (empty scan)
+  const float* h_pts = nullptr;
+  int n = 0;
+};
+
+int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, const float pose_world[3],
+                  const float2* d_pts, const float* h_pts, int n, float pt_scale, const float origo_level[2]) {
   Level& L = h->levels[level];
+  prep.level = level;
+  prep.slot = -1;
+  prep.h_pts = h_pts;
+  prep.n = n;
   L.curr_mark_free = L.curr_update_index + 1;
   L.curr_mark_occ = L.curr_update_index + 2;
   float mx, my;
@@ -407,8 +423,6 @@ int update_level(hsm_ctx* h, UpdateBatch& batch, int level, const float pose_wor
   T.t1 = my;
   float bx, by;
   affine_apply_host(T, origo_level[0], origo_level[1], bx, by);
-  const int bxi = (int)(bx + 0.5f);
-  const int byi = (int)(by + 0.5f);
   L.bbox[0] = L.bbox[1] = 0;
   L.bbox[2] = L.bbox[3] = -1;
   if (n > 0) {
@@ -424,70 +438,113 @@ int update_level(hsm_ctx* h, UpdateBatch& batch, int level, const float pose_wor
     P.pts = d_pts;
     P.n = n;
     P.pt_scale = pt_scale;
-    P.bx = bxi;
-    P.by = byi;
+    P.bx = (int)(bx + 0.5f);
+    P.by = (int)(by + 0.5f);
     P.serial = L.serial;
     P.log_odds_free = L.log_odds_free;
     P.log_odds_occ = L.log_odds_occ;
     P.mark_free = L.curr_mark_free;
     P.mark_occ = L.curr_mark_occ;
-    // cell bounding box of everything this scan can touch: the begin cell and every in-map end
-    // cell (a Bresenham line stays inside the box of its end points).  Host, same fp32
-    // expressions as beam_line(); pure index work.
-    const bool begin_in = bxi >= 0 && bxi < L.sx && byi >= 0 && byi < L.sy;
-    int x0 = L.sx, y0 = L.sy, x1 = -1, y1 = -1;
-    if (begin_in) {
-      const float fsx = (float)L.sx + 2.0f, fsy = (float)L.sy + 2.0f;
-      for (int i = 0; i < n; ++i) {
-        float ex, ey;
-        affine_apply_host(T, h_pts[2 * i] * pt_scale, h_pts[2 * i + 1] * pt_scale, ex, ey);
-        ex += 0.5f;
-        ey += 0.5f;
-        if (!(ex > -2.0f && ex < fsx && ey > -2.0f && ey < fsy)) continue;
-        const int exi = (int)ex, eyi = (int)ey;
-        if (exi < 0 || exi >= L.sx || eyi < 0 || eyi >= L.sy) continue;
-        if (exi == bxi && eyi == byi) continue;
-        if (exi < x0) x0 = exi;
-        if (exi > x1) x1 = exi;
-        if (eyi < y0) y0 = eyi;
-        if (eyi > y1) y1 = eyi;
-      }
-    }
-    if (x1 >= 0) {  // at least one beam survives the skips of updateByScan / updateLineBresenhami
-      L.bbox[0] = P.x0 = x0 < bxi ? x0 : bxi;
-      L.bbox[1] = P.y0 = y0 < byi ? y0 : byi;
-      L.bbox[2] = P.x1 = x1 > bxi ? x1 : bxi;
-      L.bbox[3] = P.y1 = y1 > byi ? y1 : byi;
-      if (L.dirty[2] < L.dirty[0]) {
-        for (int k = 0; k < 4; ++k) L.dirty[k] = L.bbox[k];
-      } else {
-        if (L.bbox[0] < L.dirty[0]) L.dirty[0] = L.bbox[0];
-        if (L.bbox[1] < L.dirty[1]) L.dirty[1] = L.bbox[1];
-        if (L.bbox[2] > L.dirty[2]) L.dirty[2] = L.bbox[2];
-        if (L.bbox[3] > L.dirty[3]) L.dirty[3] = L.bbox[3];
-      }
-      batch.lv[batch.nlev++] = P;
-    }
+    P.x0 = P.y0 = 0;
+    P.x1 = P.y1 = -1;  // empty box until level_bbox(): the dense passes skip the level
+    prep.slot = batch.nlev;
+    batch.lv[batch.nlev++] = P;
   }
   L.last_update_index++;     // setUpdated(), GridMapBase.h:343
   L.curr_update_index += 3;  // OccGridMapBase.h:167
   return HSM_OK;
 }
 
-// the four passes of map_update.h, each ONE launch over all levels of the batch (grid.y = level)
-int launch_update_batch(hsm_ctx* h, const UpdateBatch& batch) {
+// Box of level prep.level.  `finer` != nullptr: the level sees the SAME container as the finer level `finer`
+// describes, scaled by a power of two -- then every fp32 value of this level's endpoint arithmetic is exactly the
+// finer level's value times 2^-k (products and sums of exactly scaled operands), so cell = (int)(e * 2^-k + 0.5)
+// with the finer cell (int)(e + 0.5) in [x0, x1] lies in [(x0 >> k) - 1, (x1 >> k) + 1]: a conservative box without
+// touching the endpoints again (a superset only costs the dense passes a few rows of untouched cells).
+void level_bbox(hsm_ctx* h, UpdateBatch& batch, const LevelPrep& prep, const UpdateParams* finer, int shift) {
+  if (prep.slot < 0) return;
+  Level& L = h->levels[prep.level];
+  UpdateParams& P = batch.lv[prep.slot];
+  const int bxi = P.bx, byi = P.by;
+  const bool begin_in = bxi >= 0 && bxi < L.sx && byi >= 0 && byi < L.sy;
+  int x0 = L.sx, y0 = L.sy, x1 = -1, y1 = -1;
+  if (begin_in && finer) {
+    if (finer->x1 >= finer->x0) {
+      x0 = (finer->x0 >> shift) - 1;
+      y0 = (finer->y0 >> shift) - 1;
+      x1 = (finer->x1 >> shift) + 1;
+      y1 = (finer->y1 >> shift) + 1;
+      if (x0 < 0) x0 = 0;
+      if (y0 < 0) y0 = 0;
+      if (x1 > L.sx - 1) x1 = L.sx - 1;
+      if (y1 > L.sy - 1) y1 = L.sy - 1;
+    }
+  } else if (begin_in) {
+    // every in-map end cell (a Bresenham line stays inside the box of its end points).  Same fp32 expressions as
+    // beam_line(); pure index work.  (Beams that end in the begin cell are skipped by the kernels; the begin cell is
+    // in the box anyway.)
+    const float fsx = (float)L.sx + 2.0f, fsy = (float)L.sy + 2.0f;
+    const float* h_pts = prep.h_pts;
+    const float pt_scale = P.pt_scale;
+    for (int i = 0; i < prep.n; ++i) {
+      float ex, ey;
+      affine_apply_host(P.pose, h_pts[2 * i] * pt_scale, h_pts[2 * i + 1] * pt_scale, ex, ey);
+      ex += 0.5f;
+      ey += 0.5f;
+      if (!(ex > -2.0f && ex < fsx && ey > -2.0f && ey < fsy)) continue;
+      const int exi = (int)ex, eyi = (int)ey;
+      if (exi < 0 || exi >= L.sx || eyi < 0 || eyi >= L.sy) continue;
+      if (exi < x0) x0 = exi;
+      if (exi > x1) x1 = exi;
+      if (eyi < y0) y0 = eyi;
+      if (eyi > y1) y1 = eyi;
+    }
+  }
+  if (x1 >= 0) {  // at least one beam ends inside the map
+    L.bbox[0] = P.x0 = x0 < bxi ? x0 : bxi;
+    L.bbox[1] = P.y0 = y0 < byi ? y0 : byi;
+    L.bbox[2] = P.x1 = x1 > bxi ? x1 : bxi;
+    L.bbox[3] = P.y1 = y1 > byi ? y1 : byi;
+    if (L.dirty[2] < L.dirty[0]) {
+      for (int k = 0; k < 4; ++k) L.dirty[k] = L.bbox[k];
+    } else {
+      if (L.bbox[0] < L.dirty[0]) L.dirty[0] = L.bbox[0];
+      if (L.bbox[1] < L.dirty[1]) L.dirty[1] = L.bbox[1];
+      if (L.bbox[2] > L.dirty[2]) L.dirty[2] = L.bbox[2];
+      if (L.bbox[3] > L.dirty[3]) L.dirty[3] = L.bbox[3];
+    }
+  }
+}
+
+// pass 1 of map_update.h for all levels of the batch (grid.y = level): needs no box
+int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
   if (batch.nlev == 0) return HSM_OK;
   int max_n = 0;
+  for (int i = 0; i < batch.nlev; ++i)
+    if (batch.lv[i].n > max_n) max_n = batch.lv[i].n;
+  const unsigned ny = (unsigned)batch.nlev;
+  if (max_n < h->merged_mark_max) {
+    // small scans: end-cell marks and line walks in ONE launch (keyed atomics, map_update.h) -- one dependent launch less
+    const unsigned occ_blocks = (unsigned)(max_n + 255) / 256;
+    hipLaunchKernelGGL(update_mark_kernel, dim3(occ_blocks + (max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch, occ_blocks);
+  } else {
+    hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
+    hipLaunchKernelGGL(update_mark_free_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);  // 4 beams (waves) per block
+  }
+  HIP_TRY(hipGetLastError());
+  return HSM_OK;
+}
+
+// passes 2 (+ 3) over the boxes level_bbox() filled in; levels with an empty box return at once
+int launch_update_apply(hsm_ctx* h, const UpdateBatch& batch) {
   size_t max_box = 0;
   for (int i = 0; i < batch.nlev; ++i) {
     const UpdateParams& P = batch.lv[i];
-    if (P.n > max_n) max_n = P.n;
+    if (P.x1 < P.x0) continue;
     const size_t box = (size_t)(P.x1 - P.x0 + 2) * (size_t)(P.y1 - P.y0 + 2);
     if (box > max_box) max_box = box;
   }
+  if (max_box == 0) return HSM_OK;
   const unsigned ny = (unsigned)batch.nlev;
-  hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
-  hipLaunchKernelGGL(update_mark_free_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);  // 4 beams (waves) per block
   hipLaunchKernelGGL(update_apply_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
   if (h->layout == kLayoutQuad)
     hipLaunchKernelGGL(update_texels_kernel, dim3(grid_for(max_box), ny), dim3(256), 0, h->stream, batch);
@@ -576,6 +633,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
   if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
+  if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -1083,20 +1141,17 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   }
   UpdateBatch batch;
   batch.nlev = 0;
-  if (int rc = update_level(h, batch, 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
-  if (n >= 4096) {
-    // dense scan: start level 0 (the longest) right away; the host-side bounding boxes of the coarse levels
-    // are then computed while the GPU is busy.  Small scans keep all levels in one launch per pass (latency).
-    if (int rc = launch_update_batch(h, batch)) return rc;
-    batch.nlev = 0;
-  }
+  LevelPrep prep[HSM_MAX_LEVELS];
+  if (int rc = prepare_level(h, batch, prep[0], 0, pose_world, d_level0, pts_xy, n, 1.0f, o)) return rc;
   // coarse levels: the containers retained by the last matchData (MapRepMultiMap.h:143)
   const int rn = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
+  bool coarse_same_container = false;  // the usual flow: update with the container that was just matched
   if (h->levels.size() > 1) {
     const float2* d_coarse = nullptr;
     if (rn == n && n > 0 && !h->d_retained_current &&
         memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0) {
-      d_coarse = d_level0;  // the usual flow: update with the container that was just matched
+      d_coarse = d_level0;
+      coarse_same_container = h->retained_origo[0] == o[0] && h->retained_origo[1] == o[1];
     } else {
       if (rn > 0 && !h->d_retained_current) {
         if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)rn)) return rc;
@@ -1109,11 +1164,19 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
     for (size_t l = 1; l < h->levels.size(); ++l) {
       const float factor = (float)(1.0 / pow(2.0, (double)l));
       const float ol[2] = {h->retained_origo[0] * factor, h->retained_origo[1] * factor};  // setFrom :48
-      if (int rc = update_level(h, batch, (int)l, pose_world, d_coarse, h->retained_pts.data(), rn, factor, ol))
+      if (int rc = prepare_level(h, batch, prep[l], (int)l, pose_world, d_coarse, h->retained_pts.data(), rn, factor, ol))
         return rc;
     }
   }
-  if (int rc = launch_update_batch(h, batch)) return rc;
+  // the GPU starts marking (all levels, one launch) while the host works out the boxes of the dense passes
+  if (int rc = launch_update_mark(h, batch)) return rc;
+  level_bbox(h, batch, prep[0], nullptr, 0);
+  for (size_t l = 1; l < h->levels.size(); ++l) {
+    const bool derive = coarse_same_container && prep[0].slot >= 0 && h->levels[l].sx == (h->levels[0].sx >> l) &&
+                        h->levels[l].sy == (h->levels[0].sy >> l);
+    level_bbox(h, batch, prep[l], derive ? &batch.lv[prep[0].slot] : nullptr, (int)l);
+  }
+  if (int rc = launch_update_apply(h, batch)) return rc;
   if (slot >= 0) {
     HIP_TRY(hipEventRecord(h->upd_evt[slot], h->stream));
     h->upd_busy[slot] = true;
@@ -1145,10 +1208,13 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
     HIP_TRY(hipMemcpyAsync(h->d_scan, pts_level_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
   UpdateBatch batch;
   batch.nlev = 0;
-  if (int rc = update_level(h, batch, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
-                            origo_level ? origo_level : zero))
+  LevelPrep prep;
+  if (int rc = prepare_level(h, batch, prep, level, pose_world, h->d_scan, pts_level_xy, n, 1.0f,
+                             origo_level ? origo_level : zero))
     return rc;
-  if (int rc = launch_update_batch(h, batch)) return rc;
+  if (int rc = launch_update_mark(h, batch)) return rc;
+  level_bbox(h, batch, prep, nullptr, 0);
+  if (int rc = launch_update_apply(h, batch)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }

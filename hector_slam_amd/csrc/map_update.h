@@ -166,11 +166,10 @@ __device__ __forceinline__ unsigned int line_cell(const BeamLine& b, unsigned in
 // with the same end cell only the first (lowest beam index = largest key, exactly what atomicMax would keep)
 // issues the atomicMax, and the bits of a run of adjacent lanes with the same bitmap word are OR-ed by a
 // segmented scan so that only the first lane of the run issues the atomicOr.
-__global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch B) {
-  const UpdateParams& P = B.lv[blockIdx.y];
-  const int beam = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void mark_occ_block(const UpdateParams& P, unsigned int block) {
+  const int beam = block * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  if (((int)(blockIdx.x * blockDim.x) + (int)(threadIdx.x & ~63u)) >= P.n) return;  // whole wave beyond the scan
+  if (((int)(block * blockDim.x) + (int)(threadIdx.x & ~63u)) >= P.n) return;  // whole wave beyond the scan
   bool valid = beam < P.n;
   unsigned int c = 0xffffffffu;
   if (valid) {
@@ -197,6 +196,10 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch 
   if (head && valid) atomicOr(&P.lv.occ_bits[w], m);
 }
 
+__global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch B) {
+  mark_occ_block(B.lv[blockIdx.y], blockIdx.x);
+}
+
 // pass 1b: line cells (after 1a has completed).  WHICH beam crossed a cell first only matters
 // where some beam also ENDS (the free-then-occupied revert, OccGridMapBase.h:231-233); everywhere
 // else "some beam of this scan crossed it" is all the apply pass needs.  So a cell that is nobody's
@@ -205,10 +208,15 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch 
 // and only end cells -- a few thousand per scan -- take the atomicMax that keeps the lowest beam
 // index.  A cell is classified by the end-cell bitmap, which pass 1a finalised, so the two kinds of
 // access never mix on one word.
-__global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch B) {
-  const UpdateParams& P = B.lv[blockIdx.y];
+//
+// KEYED = true (scans below 4096 beams, where the whole update is launch-latency bound): every crossed cell takes the
+// atomicMax of the full key, end cell or not, so the pass does not read the end-cell bitmap and no longer depends on
+// pass 1a -- both run in ONE launch (update_mark_kernel) and the update is one dependent launch shorter.  The apply
+// pass reads the same information either way (the serial tag; the beam index only where a beam ends).
+template <bool KEYED>
+__device__ __forceinline__ void mark_free_block(const UpdateParams& P, unsigned int block) {
   const int lane = threadIdx.x & 63;
-  const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int beam = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
       const int sa = b.offset_a > 0 ? (int)i : -(int)i, sb = b.offset_b > 0 ? (int)q : -(int)q;
       const unsigned int cx = (unsigned int)(P.bx + (x_major ? sa : sb)), cy = (unsigned int)(P.by + (x_major ? sb : sa));
       const unsigned int kc = key_free_index(P.lv, cx, cy);
-      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {  // 32x denser than the key plane: stays in L2
+      if (KEYED || ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u)) {  // (the bitmap is 32x denser than the key plane: stays in L2)
         atomicMax(&P.lv.key_free[kc], key);
       } else {
         P.lv.key_free[kc] = tag;
@@ -262,6 +270,20 @@ __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch
       ++pq;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch B) {
+  mark_free_block<false>(B.lv[blockIdx.y], blockIdx.x);
+}
+
+// passes 1a + 1b of a SMALL scan in one launch: the first occ_blocks workgroups of a row mark the end cells, the rest
+// walk the lines with keyed atomics (no dependency between the two, see mark_free_block)
+__global__ void __launch_bounds__(256) update_mark_kernel(const UpdateBatch B, unsigned int occ_blocks) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  if (blockIdx.x < occ_blocks)
+    mark_occ_block(P, blockIdx.x);
+  else
+    mark_free_block<true>(P, blockIdx.x - occ_blocks);
 }
 
 // dense over the box [x0..x1] x [y0..y1]: bresenhamCellFree / bresenhamCellOcc (OccGridMapBase.h:216-241)

@@ -10,6 +10,7 @@
 //   int hooks (bit 0: draw/debug hooks, bit 1: concurrent publisher thread), n_steps; then per step: float hint[3]; int use_last_pose, map_without_matching;
 //   float origo[2]; int n; float pts[2n]
 // output file: per step float pose[3], cov[9]; then hook log; then per level the mirror grid.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
     });
   }
 
+  std::vector<double> update_us;  // wall time of every HectorSlamProcessor::update() call (SLAM_DRIVER_TIMING)
   hectorslam::DataContainer scan;
   std::vector<hectorslam::DataContainer> kept;  // the last scans, for the batch phase
   std::vector<Eigen::Vector3f> keptPose;
@@ -135,7 +137,9 @@ int main(int argc, char** argv) {
     // scanCallback: start estimate = last pose (+ the scenario's odometry delta) or the given hint
     Eigen::Vector3f start(hint[0], hint[1], hint[2]);
     if (use_last) start += slam->getLastScanMatchPose();
+    const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     slam->update(scan, start, mwm != 0);
+    update_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     const Eigen::Vector3f& p = slam->getLastScanMatchPose();
     const Eigen::Matrix3f& c = slam->getLastScanMatchCovariance();
     for (int k = 0; k < 3; ++k) wr(out, p[k]);
@@ -143,6 +147,17 @@ int main(int argc, char** argv) {
     if (t >= steps - 8) {
       kept.push_back(scan);
       keptPose.push_back(p);
+    }
+  }
+  if (const char* tp = getenv("SLAM_DRIVER_TIMING")) {
+    // latency of the node's per-scan call: one JSON line {steps, median_us, p90_us, min_us} (first 5 steps dropped)
+    std::vector<double> v(update_us.begin() + (update_us.size() > 10 ? 5 : 0), update_us.end());
+    std::sort(v.begin(), v.end());
+    if (FILE* tf = fopen(tp, "w")) {
+      if (!v.empty())
+        fprintf(tf, "{\"steps\": %zu, \"median_us\": %.2f, \"p90_us\": %.2f, \"min_us\": %.2f}\n", v.size(),
+                v[v.size() / 2], v[(v.size() * 9) / 10], v[0]);
+      fclose(tf);
     }
   }
   if (publisher.joinable()) {

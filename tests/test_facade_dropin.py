@@ -175,11 +175,11 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
     assert g["batch"].shape == r["batch"].shape == (8, 3)
     assert np.abs(r["batch"][:, :2].astype(np.float64) - g["batch"][:, :2]).max() <= 1e-4
     assert ang_diff(r["batch"][:, 2], g["batch"][:, 2]).max() <= 1e-4
-    # lockers: one lock/unlock pair per update like the reference, plus one per (lazy) mirror refresh (and the
-    # publisher thread's own, which vary from run to run)
+    # lockers: the reference takes a level's locker around every update because the update writes the cells the
+    # publisher reads; the facade's updates write device planes, and the locker is taken where the HOST mirror is
+    # written -- once per (lazy) mirror refresh.  Balanced on both sides, and the level with the locker was refreshed at least once.
     assert g["locks"] == g["unlocks"] and r["locks"] == r["unlocks"]
-    if hooks != 2:
-        assert g["locks"] >= r["locks"]
+    assert g["locks"] >= 1  # (the driver attaches its locker to level 0)
     assert g["scale"] == r["scale"] and len(g["grids"]) == len(r["grids"])
     for a, b in zip(r["grids"], g["grids"]):
         assert (a["sx"], a["sy"], a["cell"], a["update_index"]) == (b["sx"], b["sy"], b["cell"], b["update_index"])
