@@ -382,6 +382,15 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         out["update_latency_us"] = stat(ulat)
         out["update_complete_us"] = stat(ucomp)
         out["slam_cycle_us"] = stat(cyc)
+        # the same cycle where the ROS node sits: the reference's unchanged HectorSlamProcessor::update() in C++, once on
+        # the reference's CPU map representation and once on the drop-in facade (no Python in the timed calls)
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "node_cycle_bench.py"), "400"],
+                               capture_output=True, text=True, timeout=240)
+            out["node_loop_cpp"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:  # the two drivers are prebuilt where /root/reference exists
+            out["node_loop_cpp"] = {"error": str(e)[:200]}
         out.update({"value": its / float(np.median(lat)), "ms_per_step": float(np.median(lat)) * 1e3,
                     "config": {"workload": f"configs[1]: ONE {beams}-beam scan, {levels}-level {size}/{size // 2}/{size // 4} "
                                            f"pyramid, hsm_match host call (H2D + 1 launch + D2H), median of {args.steps}",

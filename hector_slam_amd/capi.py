@@ -79,6 +79,8 @@ SIGNATURES = {
     "hsm_group_set_update_factors": (_i, [_vp, _f, _f]),
     "hsm_group_process_scan": (_i, [_vp, _f32p, _vp, _i, _f32p, _i, _f32p, _f32p]),
     "hsm_group_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
+    "hsm_group_match_batch_device": (_i, [_vp, _i32p, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "hsm_group_synchronize": (_i, [_vp]),
     "hsm_retain_scan": (_i, [_vp, _vp, _i, _f32p]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -511,6 +513,19 @@ class MapRepGroup:
         _check(self._lib.hsm_group_process_scan(self._g, _v(hint_world, 3), p, n, _v(origo, 2), 1 if do_update else 0,
                                                 out, c), "hsm_group_process_scan")
         return out, c
+
+    def match_batch_device(self, counts, d_begin, d_pts, d_offsets, shared_n, root, d_out_pose_all, d_out_cov_all=0):
+        """device-resident shards: per-replica lists of raw device pointers (ints); asynchronous (synchronize() waits)"""
+        R = self.size()
+        cnt = np.ascontiguousarray(counts, np.int32)
+        arr = lambda v: (C.c_void_p * R)(*[C.c_void_p(int(x) if x else None) for x in v])
+        b, p = arr(d_begin), arr(d_pts)
+        o = arr(d_offsets) if d_offsets is not None else None
+        _check(self._lib.hsm_group_match_batch_device(self._g, cnt, b, p, o, shared_n, root, d_out_pose_all,
+                                                      d_out_cov_all or None), "hsm_group_match_batch_device")
+
+    def synchronize(self):
+        _check(self._lib.hsm_group_synchronize(self._g), "hsm_group_synchronize")
 
     def match_batch(self, begin_world, pts, offsets=None, want_cov=True):
         b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 3)

@@ -16,6 +16,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1555,27 +1558,71 @@ int hsm_retain_scan(hsm_ctx* h, const float* pts_xy, int n, const float origo[2]
 
 }  // extern "C"
 
-struct hsm_group {
-  std::vector<hsm_ctx*> members;
+// One persistent host thread per replica beyond the first (replica 0 runs on the calling thread): a job slot guarded by
+// a mutex + condition variable; threads live as long as the group, so a batched match costs no thread creation.
+struct GroupWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, done = false, quit = false;
+  int rc = HSM_OK;
+  std::string err;
 };
 
-// run fn(replica index) on one host thread per replica; first non-zero status wins
+struct hsm_group {
+  std::vector<hsm_ctx*> members;
+  std::vector<std::unique_ptr<GroupWorker>> workers;  // workers[r - 1] serves replica r
+  // device-resident gather (hsm_group_match_batch_device): per replica a result block on ITS device and an event
+  std::vector<float*> d_pose, d_cov;
+  std::vector<size_t> d_cap;  // scans
+  std::vector<hipEvent_t> evt;
+  std::mutex mu;  // one group call at a time
+};
+
+static void group_worker_main(GroupWorker* w) {
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    w->cv.wait(lk, [w] { return w->has_job || w->quit; });
+    if (w->quit) return;
+    std::function<int()> job = std::move(w->job);
+    w->has_job = false;
+    lk.unlock();
+    const int rc = job();
+    std::string err = rc != HSM_OK ? hsm_last_error() : "";  // thread-local text: carry it to the caller's thread
+    lk.lock();
+    w->rc = rc;
+    w->err = std::move(err);
+    w->done = true;
+    w->cv.notify_all();
+  }
+}
+
+// run fn(replica index) on every replica concurrently; first non-zero status wins
 template <typename F>
 static int group_parallel(hsm_group* g, F fn) {
   const int R = (int)g->members.size();
-  std::vector<int> rc(R, HSM_OK);
-  std::vector<std::string> err(R);
-  std::vector<std::thread> th;
-  for (int r = 1; r < R; ++r)
-    th.emplace_back([&, r]() {
-      rc[r] = fn(r);
-      if (rc[r] != HSM_OK) err[r] = hsm_last_error();  // thread-local text: carry it to the caller's thread
-    });
-  rc[0] = fn(0);
-  for (std::thread& t : th) t.join();
-  for (int r = 0; r < R; ++r)
-    if (rc[r] != HSM_OK) return r == 0 ? rc[r] : fail(rc[r], err[r].c_str());
-  return HSM_OK;
+  for (int r = 1; r < R; ++r) {
+    GroupWorker* w = g->workers[(size_t)r - 1].get();
+    std::lock_guard<std::mutex> lk(w->m);
+    w->job = [fn, r]() -> int { return fn(r); };
+    w->has_job = true;
+    w->done = false;
+    w->cv.notify_all();
+  }
+  int rc0 = fn(0);
+  int rc_out = rc0;
+  std::string err_out = rc0 != HSM_OK ? std::string(hsm_last_error()) : std::string();
+  for (int r = 1; r < R; ++r) {
+    GroupWorker* w = g->workers[(size_t)r - 1].get();
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [w] { return w->done; });
+    if (w->rc != HSM_OK && rc_out == HSM_OK) {
+      rc_out = w->rc;
+      err_out = w->err;
+    }
+  }
+  return rc_out == HSM_OK ? HSM_OK : fail(rc_out, err_out.c_str());
 }
 
 
@@ -1599,12 +1646,37 @@ int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned leve
     }
     g->members.push_back(h);
   }
+  for (int i = 1; i < n_devices; ++i) {
+    g->workers.emplace_back(new GroupWorker());
+    GroupWorker* w = g->workers.back().get();
+    w->th = std::thread(group_worker_main, w);
+  }
+  g->d_pose.assign((size_t)n_devices, nullptr);
+  g->d_cov.assign((size_t)n_devices, nullptr);
+  g->d_cap.assign((size_t)n_devices, 0);
+  g->evt.assign((size_t)n_devices, nullptr);
   *out = g;
   return HSM_OK;
 }
 
 void hsm_group_destroy(hsm_group* g) {
   if (!g) return;
+  for (auto& w : g->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->quit = true;
+      w->cv.notify_all();
+    }
+    if (w->th.joinable()) w->th.join();
+  }
+  for (size_t r = 0; r < g->members.size(); ++r) {
+    if (g->members[r]) (void)hipSetDevice(g->members[r]->device);
+    if (r < g->d_pose.size()) {
+      (void)hipFree(g->d_pose[r]);
+      (void)hipFree(g->d_cov[r]);
+      if (g->evt[r]) (void)hipEventDestroy(g->evt[r]);
+    }
+  }
   for (hsm_ctx* h : g->members) hsm_destroy(h);
   delete g;
 }
@@ -1627,6 +1699,7 @@ int hsm_group_set_update_factors(hsm_group* g, float free_factor, float occupied
 int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float* pts_xy, int n, const float origo[2],
                            int do_update, float out_pose_world[3], float cov[9]) {
   if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
+  std::lock_guard<std::mutex> glk(g->mu);
   if (int rc = hsm_match(g->members[0], hint_world, pts_xy, n, origo, out_pose_world, cov)) return rc;
   if (!do_update) return HSM_OK;
   return group_parallel(g, [&](int r) -> int {
@@ -1637,11 +1710,76 @@ int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float*
   });
 }
 
+int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* const* d_begin_world,
+                                 const float* const* d_pts_xy, const int* const* d_scan_offsets, int shared_n, int root,
+                                 float* d_out_pose_all, float* d_out_cov_all) {
+  if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
+  const int R = (int)g->members.size();
+  if (!counts || !d_begin_world || !d_pts_xy || !d_out_pose_all || root < 0 || root >= R)
+    return fail(HSM_ERR_INVALID, "hsm_group_match_batch_device: bad argument");
+  std::lock_guard<std::mutex> glk(g->mu);
+  std::vector<size_t> first((size_t)R + 1, 0);
+  for (int r = 0; r < R; ++r) {
+    if (counts[r] < 0 || (counts[r] > 0 && (!d_begin_world[r] || !d_pts_xy[r])))
+      return fail(HSM_ERR_INVALID, "hsm_group_match_batch_device: bad shard");
+    first[(size_t)r + 1] = first[(size_t)r] + (size_t)counts[r];
+  }
+  const int root_dev = g->members[(size_t)root]->device;
+  // every replica: match its shard on its own stream, then push the poses (and H) to the root's device with a peer
+  // copy on the same stream -- 12 (+36) bytes per scan over xGMI, no host staging, no host wait
+  int rc = group_parallel(g, [&](int r) -> int {
+    hsm_ctx* h = g->members[(size_t)r];
+    const size_t n = (size_t)counts[r];
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc2 = select_device(h)) return rc2;
+    if (!g->evt[(size_t)r]) HIP_TRY(hipEventCreateWithFlags(&g->evt[(size_t)r], hipEventDisableTiming));
+    if (n > 0) {
+      if (n > g->d_cap[(size_t)r]) {
+        (void)hipFree(g->d_pose[(size_t)r]);
+        (void)hipFree(g->d_cov[(size_t)r]);
+        g->d_pose[(size_t)r] = g->d_cov[(size_t)r] = nullptr;
+        g->d_cap[(size_t)r] = 0;
+        HIP_TRY(hipMalloc((void**)&g->d_pose[(size_t)r], n * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&g->d_cov[(size_t)r], n * 9 * sizeof(float)));
+        g->d_cap[(size_t)r] = n;
+      }
+      if (int rc2 = match_batch_device_nolock(h, (int)n, d_begin_world[r], d_pts_xy[r],
+                                              d_scan_offsets ? d_scan_offsets[r] : nullptr, shared_n, g->d_pose[(size_t)r],
+                                              d_out_cov_all ? g->d_cov[(size_t)r] : nullptr, h->stream))
+        return rc2;
+      HIP_TRY(hipMemcpyPeerAsync(d_out_pose_all + 3 * first[(size_t)r], root_dev, g->d_pose[(size_t)r], h->device,
+                                 n * 3 * sizeof(float), h->stream));
+      if (d_out_cov_all)
+        HIP_TRY(hipMemcpyPeerAsync(d_out_cov_all + 9 * first[(size_t)r], root_dev, g->d_cov[(size_t)r], h->device,
+                                   n * 9 * sizeof(float), h->stream));
+    }
+    HIP_TRY(hipEventRecord(g->evt[(size_t)r], h->stream));
+    return HSM_OK;
+  });
+  if (rc != HSM_OK) return rc;
+  // the root's stream waits for every shard: work queued on it afterwards (and hsm_synchronize on the root member) sees
+  // the complete gather
+  hsm_ctx* hr = g->members[(size_t)root];
+  std::lock_guard<std::mutex> lk(hr->mu);
+  if (int rc2 = select_device(hr)) return rc2;
+  for (int r = 0; r < R; ++r)
+    if (r != root) HIP_TRY(hipStreamWaitEvent(hr->stream, g->evt[(size_t)r], 0));
+  return HSM_OK;
+}
+
+int hsm_group_synchronize(hsm_group* g) {
+  if (!g) return fail(HSM_ERR_INVALID, "null group");
+  for (hsm_ctx* h : g->members)
+    if (int rc = hsm_synchronize(h)) return rc;
+  return HSM_OK;
+}
+
 int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, const float* pts_xy,
                           const int* scan_offsets, int shared_n, float* out_pose, float* out_cov) {
   if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
   if (batch < 0 || !begin_world || !out_pose) return fail(HSM_ERR_INVALID, "hsm_group_match_batch: bad argument");
   const int R = (int)g->members.size();
+  std::lock_guard<std::mutex> glk(g->mu);
   return group_parallel(g, [&](int r) -> int {
     const int b = (int)((long long)batch * r / R), e = (int)((long long)batch * (r + 1) / R);
     if (e == b) return HSM_OK;

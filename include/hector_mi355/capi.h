@@ -149,10 +149,12 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
 
 /* ---- single-process multi-GPU group (extension; the reference has no multi-device path) ------------------
  * One replica of the pyramid per listed device (a device may be listed more than once).  Batched matching is
- * sharded contiguously over the replicas, one host thread per replica, results written straight into the
- * caller's arrays (the "gather" of the poses is the D2H copy of each shard); map updates are replayed on every
- * replica -- updateByScan is deterministic, so the replicas stay bit-identical.  (bench.py uses the other
- * deployment shape: one process per GPU and an RCCL all-gather of device-resident poses.) */
+ * sharded contiguously over the replicas, one PERSISTENT host thread per replica (created with the group), each
+ * replica on its own stream.  Two forms: host arrays in/out (hsm_group_match_batch: the "gather" of the poses is the
+ * D2H copy of each shard into the caller's arrays) and device-resident shards (hsm_group_match_batch_device: the
+ * gather is a peer copy of each shard's [n,3] poses over xGMI to the root replica's device, no host staging).  Map
+ * updates are replayed on every replica -- updateByScan is deterministic, so the replicas stay bit-identical.
+ * (bench.py uses the other deployment shape: one process per GPU and an RCCL all-gather of device-resident poses.) */
 typedef struct hsm_group hsm_group;
 int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
                      const int* devices, int n_devices, hsm_group** out);
@@ -164,6 +166,18 @@ int hsm_group_set_update_factors(hsm_group* g, float free_factor, float occupied
  * updateByScan with the matched pose on EVERY replica (each retains the scan first, like its own matchData would) */
 int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float* pts_xy, int n, const float origo[2],
                            int do_update, float out_pose_world[3], float cov[9]);
+/* Device-resident sharded match: replica r matches counts[r] scans that already live on ITS device (d_begin_world[r],
+ * d_pts_xy[r], d_scan_offsets[r]: CSR offsets relative to the shard, or d_scan_offsets == NULL / entries NULL for
+ * pose hypotheses of one shared scan of shared_n beams per replica).  The poses of all shards are gathered, in replica
+ * order, into d_out_pose_all [sum(counts) * 3] on replica `root`'s device (and the Hessians into d_out_cov_all
+ * [sum * 9] unless NULL) by hipMemcpyPeerAsync on each replica's own stream.  Asynchronous: returns when everything
+ * is queued; root's context stream is ordered behind the gather (hsm_synchronize(hsm_group_member(g, root)) or
+ * hsm_group_synchronize wait for it). */
+int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* const* d_begin_world,
+                                 const float* const* d_pts_xy, const int* const* d_scan_offsets, int shared_n, int root,
+                                 float* d_out_pose_all, float* d_out_cov_all);
+/* wait for all queued work of every replica */
+int hsm_group_synchronize(hsm_group* g);
 /* hsm_match_batch over all replicas: scans [B*r/R, B*(r+1)/R) go to replica r */
 int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, const float* pts_xy,
                           const int* scan_offsets, int shared_n, float* out_pose, float* out_cov);

@@ -672,12 +672,16 @@ def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
 
 
 def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
-    """hsm_group_*: R replicas in one process (here all on device 0 -- the sharding, threading and replica
-    consistency logic is the same as with R devices).  Batched matching over the group == one context, bit for
-    bit and in order; the SLAM cycle keeps every replica's map identical to a single context's and to the oracle's"""
+    """hsm_group_*: R replicas in one process -- on R DISTINCT devices where the box has them (peer copies, per-device
+    contexts and streams), else all on device 0 (the sharding, the persistent worker threads and the replica consistency
+    logic are the same).  Batched matching over the group == one context, bit for bit and in order; the SLAM cycle
+    keeps every replica's map identical to a single context's and to the oracle's"""
+    import torch
     from hector_slam_amd import synth
     sc = pyramid_scene
-    grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, [0, 0, 0])
+    ndev = torch.cuda.device_count()
+    devices = [0, 1 % ndev, 2 % ndev]
+    grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, devices)
     assert grp.size() == 3
     grp.set_update_factors(0.4, 0.9)
     one = make_gpu(capi, sc, build=False)
@@ -713,6 +717,27 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
     p2, _ = grp.match_batch(sc.query_init[:2], *synth.pack_scans(sc.query_scans[:2]))
     assert np.array_equal(bits(p2), bits(pb[:2]))
     assert grp.match_batch(np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), np.zeros(1, np.int32))[0].shape == (0, 3)
+    # device-resident shards (uneven: 5 / 0 / 11 scans), gathered on replica 2's device by peer copies; repeated so
+    # that the persistent workers and the per-replica result blocks are reused
+    bounds = [(0, 5), (5, 5), (5, 16)]
+    shards = []
+    for r, (b, e) in enumerate(bounds):
+        dev = torch.device("cuda", devices[r])
+        sh_pts, sh_offs = synth.pack_scans(sc.query_scans[b:e]) if e > b else (np.zeros((0, 2), np.float32), np.zeros(1, np.int32))
+        shards.append([torch.from_numpy(np.ascontiguousarray(sc.query_init[b:e])).to(dev), torch.from_numpy(sh_pts).to(dev),
+                       torch.from_numpy(sh_offs).to(dev)])
+    root = 2
+    rdev = torch.device("cuda", devices[root])
+    for rep in range(3):
+        d_all = torch.zeros((16, 3), dtype=torch.float32, device=rdev)
+        d_cov = torch.zeros((16, 9), dtype=torch.float32, device=rdev)
+        torch.cuda.synchronize()
+        grp.match_batch_device([e - b for b, e in bounds], [t[0].data_ptr() if t[0].numel() else 0 for t in shards],
+                               [t[1].data_ptr() if t[1].numel() else 0 for t in shards], [t[2].data_ptr() for t in shards],
+                               0, root, d_all.data_ptr(), d_cov.data_ptr())
+        grp.synchronize()
+        assert np.array_equal(bits(d_all.cpu().numpy()), bits(pb)), rep
+        assert np.array_equal(bits(d_cov.cpu().numpy()), bits(cb)), rep
     grp.close()
 
 
