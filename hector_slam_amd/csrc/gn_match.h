@@ -729,12 +729,25 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
 // read by the same lane only, so no barrier is ever needed (SPB * BPL * 512 B per workgroup).  Same
 // arithmetic on the same texel values in the same order as gn_match_kernel: identical bits.
 // One wave per scan, quad layout, no trace.
-#ifndef HSM_CACHE_CHUNK
-#define HSM_CACHE_CHUNK 3
+// beams per pipeline stage of the texel-cache form.  Measured on MI355X (profiles/r02/README.md): 1 -> 57.1 us on the
+// headline workload, 2 -> 58.3 (128 VGPRs), no pipeline with chunks of 3 (round 1) -> 58.4
+#ifndef HSM_CACHE_PIPE_CHUNK
+#define HSM_CACHE_PIPE_CHUNK 1
 #endif
-constexpr int kCacheChunk = HSM_CACHE_CHUNK;
+constexpr int kCachePipeChunk = HSM_CACHE_PIPE_CHUNK;
 
-template <int SPB, int BPL>
+// a wave-uniform value moved to an SGPR
+__device__ __forceinline__ float uniform_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// 8-byte load from a 4-byte aligned address (two neighbouring cells of a row of the probability plane): one
+// global_load_dwordx2 -- the hardware handles dword-aligned wide loads
+struct __attribute__((packed, aligned(4))) CellPair {
+  float a, b;
+};
+
+template <int SPB, int BPL, int LAYOUT = kLayoutQuad>
 __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const MatchParams P) {
   __shared__ f2 lds_pts[SPB][BPL][64];
   const int lane = threadIdx.x & 63;
@@ -776,7 +789,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
     eth = pw2;
     const float ps = L.pt_scale;
     const int gn_steps = L.gn_steps;
-    const LevelRegs R = level_regs<kLayoutQuad>(L);
+    const LevelRegs R = level_regs<LAYOUT>(L);
     const float ratio = ps / reg_scale;  // powers of two: exact (see gn_match_kernel)
     reg_scale = ps;
 #pragma unroll
@@ -788,60 +801,83 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
-      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
-      // chunks of kCacheChunk beams: locate them all (offsets, the masked gathers of the lanes that moved to
-      // another cell), then consume them in beam order -- the few gathers that remain overlap each other
-#pragma unroll
-      for (int k0 = 0; k0 < BPL; k0 += kCacheChunk) {
-        BeamSample b[kCacheChunk];
-        BeamRot r[kCacheChunk];
-        f2 pc[kCacheChunk];
-#pragma unroll
-        for (int u = 0; u < kCacheChunk; ++u)  // the chunk's LDS reads back to back: one wait instead of one per beam
-          if (k0 + u < BPL) pc[u] = mine[k0 + u][lane];
-#pragma unroll
-        for (int u = 0; u < kCacheChunk; ++u) {
-          const int k = k0 + u;
-          if (k < BPL) {
-            const f2 p = pc[u];
-            r[u].r.x = cs.x * p.x - sc.x * p.y;
-            r[u].r.y = cs.y * p.x + sc.y * p.y;
-            const f2 c = f2{e2.x + r[u].r.x, e2.y + r[u].r.y};
-            const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, R.limx);
-            const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, R.limy);
-            const bool oob = (sx_ != c.x) | (sy_ != c.y);
-            const unsigned ix = (unsigned)(int)sx_;
-            const unsigned iy = (unsigned)(int)sy_;
-            b[u].X.y = __builtin_amdgcn_fractf(sx_);
-            b[u].Y.y = __builtin_amdgcn_fractf(sy_);
-            unsigned idx = quad_index(ix, iy, R.tiles_x, R.sx);
-            asm volatile("" : "+v"(idx));  // computed unconditionally: a select below, not a branch
+      // the step's pose and rotation are wave-uniform: held in SGPRs (4 VGPRs less in a kernel that has none to spare)
+      const f2 e2 = f2{uniform_f32(ex), uniform_f32(ey)};
+      const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
+      // "locate" a beam: rotate, bounds test, cell offset, fractions, and -- only in the lanes whose cell changed since
+      // the previous step -- the gather of its texel straight into the beam's cache registers
+      auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) {
+        r.r.x = cs.x * p.x - sc.x * p.y;
+        r.r.y = cs.y * p.x + sc.y * p.y;
+        const f2 c = f2{e2.x + r.r.x, e2.y + r.r.y};
+        const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, R.limx);
+        const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, R.limy);
+        const bool oob = (sx_ != c.x) | (sy_ != c.y);
+        const unsigned ix = (unsigned)(int)sx_;
+        const unsigned iy = (unsigned)(int)sy_;
+        fx = __builtin_amdgcn_fractf(sx_);
+        fy = __builtin_amdgcn_fractf(sy_);
+        unsigned idx = LAYOUT == kLayoutQuad ? quad_index(ix, iy, R.tiles_x, R.sx) : __umul24(iy, (unsigned)R.sx) + ix;
+        asm volatile("" : "+v"(idx));  // computed unconditionally: a select below, not a branch
 #if defined(HSM_EXP_CACHE_FLOOR)  // experiment: every lane always hits its cached texel after the first gather
-            const unsigned off = ((oob ? (unsigned)R.zero_index : idx) & 0u) + 4096u;
+        const unsigned off = ((oob ? (unsigned)R.zero_index : idx) & 0u) + 4096u;
 #else
-            const unsigned off = (oob ? (unsigned)R.zero_index : idx) << 4;
+        const unsigned off = (oob ? (unsigned)R.zero_index : idx) << (LAYOUT == kLayoutQuad ? 4 : 2);
 #endif
-            if (off != toff[k]) {
-              tq[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R.quad) + (size_t)off);
-              toff[k] = off;
-            }
+        if (off != toff[k]) {
+          if (LAYOUT == kLayoutQuad) {
+            tq[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R.quad) + (size_t)off);
+          } else {
+            // the probability plane itself (4 B per cell: a quarter of the texel plane's footprint, so far more of
+            // a map that outgrows the L2 stays in it): rows iy and iy + 1, two cells each
+            const char* row = reinterpret_cast<const char*>(R.prob) + (size_t)off;
+            const CellPair lo = *reinterpret_cast<const CellPair*>(row);
+            const CellPair hi = *reinterpret_cast<const CellPair*>(row + ((size_t)R.sx << 2));
+            tq[k] = make_float4(lo.a, lo.b, hi.a, hi.b);
           }
+          toff[k] = off;
         }
+      };
+      auto consume = [&](int k, const BeamRot& r, float fx, float fy) {
+        BeamSample b;
+        b.X = f2{1.0f - fx, fx};
+        b.Y = f2{1.0f - fy, fy};
+        b.lo = f2{tq[k].x, tq[k].y};
+        b.hi = f2{tq[k].z, tq[k].w};
+        beam_finish(b, r, acc);
+      };
+      // Software pipeline over chunks of kCachePipeChunk beams: the texel gathers of chunk c+1 are ISSUED before chunk c
+      // is consumed, so a gather has the arithmetic of a whole chunk (and the other waves' share of the SIMD) to land
+      // in.  The gathers write the beams' own cache registers, so the only extra state in flight is the second
+      // chunk's (rot, fx, fy).  Same arithmetic in the same beam order: identical bits.  (Worth 2 % on the headline
+      // workload and nothing on the pyramid ones: what the gathers cost is line-request THROUGHPUT of the L1/L2 path
+      // in the first two steps of a level, where most lanes change cell -- not latency.)
+      {
+        constexpr int CH = kCachePipeChunk;
+        BeamRot rc[CH], rn[CH];
+        float fxc[CH], fyc[CH], fxn[CH], fyn[CH];
 #pragma unroll
-        for (int u = 0; u < kCacheChunk; ++u) {
-          const int k = k0 + u;
-          if (k < BPL) {
-            b[u].X.x = 1.0f - b[u].X.y;
-            b[u].Y.x = 1.0f - b[u].Y.y;
-            b[u].lo = f2{tq[k].x, tq[k].y};
-            b[u].hi = f2{tq[k].z, tq[k].w};
-            beam_finish(b[u], r[u], acc);
+        for (int u = 0; u < CH; ++u)
+          if (u < BPL) locate(u, mine[u][lane], rc[u], fxc[u], fyc[u]);
+#pragma unroll
+        for (int k0 = 0; k0 < BPL; k0 += CH) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+            if (k0 + CH + u < BPL) locate(k0 + CH + u, mine[k0 + CH + u][lane], rn[u], fxn[u], fyn[u]);
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+            if (k0 + u < BPL) consume(k0 + u, rc[u], fxc[u], fyc[u]);
+          asm volatile(""
+                       : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
+                       :
+                       : "memory");
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            rc[u] = rn[u];
+            fxc[u] = fxn[u];
+            fyc[u] = fyn[u];
           }
         }
-        asm volatile(""
-                     : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
-                     :
-                     : "memory");
       }
       // a scan longer than the 64 * BPL cached beams (BPL comes from a host-side length HINT): the rest streams
       // from memory like gn_match_kernel's loop, in the same per-lane order (wave-uniform trip count)
@@ -849,7 +885,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       for (int i = 64 * BPL + (n > 64 * BPL ? lane_id_now() : 0); i < n; i += 64) {
         const float2 p = pts[i];
         BeamRot r;
-        const BeamSample b = beam_fetch<kLayoutQuad>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+        const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
         beam_finish(b, r, acc);
       }
 #endif

@@ -285,8 +285,11 @@ int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
   const int grid = (P.batch + SPB - 1) / SPB;
   if constexpr (WPS == 1 && (BPL == 9 || BPL == 17)) {
     // throughput launches of long scans: the texel-cache form (gn_match.h)
-    if (h->texel_cache && h->layout == kLayoutQuad && P.begin_world && !P.trace) {
-      hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL>), dim3(grid), dim3(block), 0, stream, P);
+    if (h->texel_cache && P.begin_world && !P.trace) {
+      if (h->layout == kLayoutQuad)
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+      else
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
       HIP_TRY(hipGetLastError());
       h->last_cfg[0] = h->layout;
       h->last_cfg[1] = WPS;

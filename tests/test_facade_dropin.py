@@ -179,7 +179,8 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
     # publisher reads; the facade's updates write device planes, and the locker is taken where the HOST mirror is
     # written -- once per (lazy) mirror refresh.  Balanced on both sides, and the level with the locker was refreshed at least once.
     assert g["locks"] == g["unlocks"] and r["locks"] == r["unlocks"]
-    assert g["locks"] >= 1  # (the driver attaches its locker to level 0)
+    if hooks == 2:  # the publisher thread fetched the grid while the loop ran: at least one refresh under the locker
+        assert g["locks"] >= 1  # (plain run: the driver reports the counts BEFORE it reads the grids, so none yet)
     assert g["scale"] == r["scale"] and len(g["grids"]) == len(r["grids"])
     for a, b in zip(r["grids"], g["grids"]):
         assert (a["sx"], a["sy"], a["cell"], a["update_index"]) == (b["sx"], b["sy"], b["cell"], b["update_index"])

@@ -1,0 +1,24 @@
+#!/bin/bash
+# full gpu suite + the default bench line + rocprofv3 kernel stats of the same command
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/full
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd "$ROOT"
+HSM_PARITY_STATS=$OUT/parity_stats.jsonl timeout 1500 python -m pytest tests -m gpu -q --durations=8 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
+tail -14 "$OUT/pytest.log"
+timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python $ROOT/bench.py > "$OUT/bench_default_under_rocprof.json" 2> "$OUT/stats.err"
+for f in $(find "$OUT/stats" -name "*kernel_stats.csv"); do echo "== $f"; head -5 $f | cut -c1-160; done
+cd "$ROOT"
+for w in config3pyr config4 config2 config5; do
+  timeout 600 python bench.py --workload $w > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
+done
+python - <<PY
+import json,glob
+for f in sorted(glob.glob("$OUT/bench_*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], round(d["value"]/1e6,2), "M it/s", d.get("ms_per_step"))
+    except Exception as e: print(f, "ERR", e)
+PY
