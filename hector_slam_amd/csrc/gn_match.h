@@ -909,6 +909,132 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   }
 }
 
+// ---- HSM_PARITY_EXACT for batches: wave-specialised -----------------------------------------------------------------
+// In exact_round() nine lanes of a wavefront run the nine sequential chains while the other 55 idle: 64 dependent adds
+// (+ the LDS traffic) per 64 beams, about as much issue time as the beam arithmetic itself.  A batch has many scans, so
+// this form lets ONE consumer wavefront run the chains of SEVEN scans side by side -- lane 9 j + t adds term t of scan
+// j -- while seven producer wavefronts (one scan each) compute the products: the chain cost per scan drops 7x and it
+// overlaps the producers' arithmetic.  Per round of 64 beams every producer writes its 9 x 64 products into its slice
+// of a double-buffered LDS stage and the workgroup meets at one barrier; the consumer then sums round r while the
+// producers already compute round r + 1 (buffer reuse is safe: the consumer reaches barrier r + 1 only after chain r).
+// After the last round the consumer publishes the 7 x 9 totals; every producer picks up its nine and solves.  The
+// round count is the workgroup's longest scan (shorter scans pad with +-0 products, which leave a sum unchanged).
+// Summation order per scan: beam 0 .. n-1, one fp32 chain per term -- the reference's (OccGridMapUtil.h:76-98), so the
+// results are bit-identical to gn_match_kernel<..., EXACT> and to the reference.
+constexpr int kExactScans = 7;  // producers per workgroup; 7 x 9 = 63 chain lanes in the consumer wavefront
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batch_kernel(const MatchParams P) {
+  constexpr int ROW = 64 + kExactPad;
+  __shared__ float stage[2][kExactScans][9][ROW];
+  __shared__ float tot[kExactScans][9];
+  __shared__ int nmax_s;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool consumer = wave == kExactScans;
+  const int scan = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kExactScans + wave);
+  const bool active = !consumer && scan < P.batch;
+  int beg = 0, n = 0;
+  float pw0 = 0.0f, pw1 = 0.0f, pw2 = 0.0f;
+  if (active) {
+    n = P.shared_n;
+    if (P.offsets) {
+      beg = P.offsets[scan];
+      n = P.offsets[scan + 1] - beg;
+    }
+    pw0 = P.begin_world[3 * scan + 0];
+    pw1 = P.begin_world[3 * scan + 1];
+    pw2 = P.begin_world[3 * scan + 2];
+  }
+  const float b0 = pw0, b1 = pw1, b2 = pw2;  // an empty scan passes its start estimate through untouched (ScanMatcher.h:68,189)
+  if (threadIdx.x == 0) nmax_s = 0;
+  __syncthreads();
+  if (lane == 0 && n > 0) atomicMax(&nmax_s, n);
+  __syncthreads();
+  const int rounds = (nmax_s + 63) >> 6;  // workgroup-uniform
+  if (rounds == 0) {                      // nothing but empty scans
+    if (active && lane == 0) {
+      P.out_pose[3 * scan + 0] = b0;
+      P.out_pose[3 * scan + 1] = b1;
+      P.out_pose[3 * scan + 2] = b2;
+    }
+    return;
+  }
+  const float2* __restrict__ pts = P.pts + beg;
+  Acc9 acc;
+  acc.zero();
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<LAYOUT>(L);
+    for (int it = 0; it < gn_steps; ++it) {
+      if (consumer) {
+        float run = 0.0f;
+        const int j = lane / 9, t = lane - 9 * j;  // lane 63: j = 7, idle
+        for (int r = 0; r < rounds; ++r) {
+          __syncthreads();  // the producers' products of round r are in stage[r & 1]
+          if (lane < 9 * kExactScans) {
+            const float* row = &stage[r & 1][j][t][0];
+#pragma unroll 4
+            for (int q = 0; q < 64; q += 4) {
+              const float4 v = *reinterpret_cast<const float4*>(row + q);
+              run += v.x;
+              run += v.y;
+              run += v.z;
+              run += v.w;
+            }
+          }
+        }
+        if (lane < 9 * kExactScans) tot[j][t] = run;
+        __syncthreads();  // totals published
+      } else {
+        float sinRot, cosRot;
+        sincos_f32(eth, sinRot, cosRot);
+        const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+        for (int r = 0; r < rounds; ++r) {
+          const int i = (r << 6) + lane;
+          const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products
+          BeamRot rot;
+          const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, rot);
+          float pr[9];
+          beam_products(b, rot, pr);
+          float* st = &stage[r & 1][wave][0][lane];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) st[t * ROW] = pr[t];
+          __syncthreads();
+        }
+        __syncthreads();  // the consumer has published the totals
+        const float* tt = &tot[wave][0];
+        acc.d01 = f2{tt[0], tt[1]}; acc.d2 = tt[2];
+        acc.hd = f2{tt[3], tt[4]}; acc.h22 = tt[5];
+        acc.h01 = tt[6]; acc.hr = f2{tt[7], tt[8]};
+        gn_solve_and_step(acc, ex, ey, eth);
+      }
+    }
+    if (!consumer) {
+      eth = normalize_angle(eth);
+      affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+      pw2 = eth;
+    }
+  }
+  if (active && lane == 0) {
+    const bool empty = n == 0;
+    P.out_pose[3 * scan + 0] = empty ? b0 : pw0;
+    P.out_pose[3 * scan + 1] = empty ? b1 : pw1;
+    P.out_pose[3 * scan + 2] = empty ? b2 : pw2;
+    if (P.out_cov && !empty) {
+      float* c = P.out_cov + 9 * scan;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
+    }
+  }
+}
+
 // ---- one DENSE scan on many CUs --------------------------------------------------------------------
 // gn_match_kernel keeps a scan inside one workgroup (<= 16 waves on ONE CU): right for batches, but a
 // single 16k-beam scan then uses 1/256 of the chip (11 us per GN step).  This variant spreads the beams of

@@ -159,6 +159,7 @@ struct hsm_ctx {
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
+  bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -334,6 +335,25 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
 template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+  // throughput launches: seven producer wavefronts + one consumer wavefront per workgroup (gn_match.h).  Measured
+  // (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch, 235 vs 275 us through its 3-level pyramid,
+  // but 334 vs 317 us on the 4096^2 pyramid, whose gathers miss the L2 and want more wavefronts in flight per CU than
+  // eight-wave workgroups with 34 KB of LDS leave -- so maps beyond 2^23 cells keep the one-wavefront-per-scan form.
+  if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form && h->levels[0].cells() <= ((size_t)1 << 23)) {
+    const int grid = (P.batch + kExactScans - 1) / kExactScans, block = 64 * (kExactScans + 1);
+    if (h->layout == kLayoutPlane)
+      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
+    else
+      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+    HIP_TRY(hipGetLastError());
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = 1;
+    h->last_cfg[2] = block;
+    h->last_cfg[3] = grid;
+    h->last_cfg[4] = 0;
+    h->last_cfg[5] = 0;
+    return HSM_OK;
+  }
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
   if (h->layout == kLayoutPlane)
@@ -640,6 +660,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
   if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
+  if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
