@@ -1244,11 +1244,31 @@ __global__ void gn_beam_terms_kernel(const LevelView L, const float2* __restrict
 // as the matcher without the gradient.  One wavefront per state, beams strided over the lanes, the
 // texel gather and the zero-texel treatment of out-of-map beams shared with the matcher (an
 // out-of-map beam reads M = 0, i.e. funval = 1, exactly the reference's `return 0.0f`).
-template <int LAYOUT>
+// One residual chain in the reference's order (getResidualForState: residual += funval, i = 0 .. n-1), the
+// HSM_PARITY_EXACT counterpart of the wave all-reduce below: a round of 64 beams writes its funvals to the wavefront's
+// LDS row and lane 0 adds them left to right (same idea as exact_round, one term instead of nine).  Every lane returns
+// the running sum that is only meaningful in lane 0.
+__device__ __forceinline__ float exact_residual_round(float funval, float* __restrict__ row, int lane, float run) {
+  row[lane] = funval;
+  if (lane == 0) {
+#pragma unroll 4
+    for (int q = 0; q < 64; q += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + q);
+      run += v.x;
+      run += v.y;
+      run += v.z;
+      run += v.w;
+    }
+  }
+  return run;
+}
+
+template <int LAYOUT, bool EXACT = false>
 __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, const float* __restrict__ states,
                                                          int batch, const float2* __restrict__ pts, int n,
                                                          float pt_scale, float* __restrict__ out_lh,
                                                          float* __restrict__ out_residual) {
+  __shared__ float rows[EXACT ? 4 : 1][EXACT ? 64 : 1];
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= batch) return;
@@ -1258,14 +1278,31 @@ __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, cons
   const LevelRegs R = level_regs<LAYOUT>(L);
   const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
   float residual = 0.0f;
-  for (int i = lane; i < n; i += 64) {
-    const float2 p = pts[i];
-    BeamRot r;
-    const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
-    const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
-    residual += 1.0f - M;
+  if (EXACT) {
+    float* row = rows[(threadIdx.x >> 6) & 3];
+    for (int base = 0; base < n; base += 64) {  // wave-uniform trip count
+      const int i = base + lane;
+      // padding beyond the scan: funval = +0 (M is only ever 0 .. 1, so no sum is -0 and +0 changes nothing)
+      float funval = 0.0f;
+      if (i < n) {
+        const float2 p = pts[i];
+        BeamRot r;
+        const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+        const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+        funval = 1.0f - M;
+      }
+      residual = exact_residual_round(funval, row, lane, residual);
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) {
+      const float2 p = pts[i];
+      BeamRot r;
+      const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+      const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+      residual += 1.0f - M;
+    }
+    residual = wave_allreduce(residual);
   }
-  residual = wave_allreduce(residual);
   if (lane == 0) {
     if (out_lh) out_lh[b] = 1 - (residual / (float)n);
     if (out_residual) out_residual[b] = residual;  // getResidualForState (:205-221)
@@ -1276,7 +1313,7 @@ __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, cons
 // (:162-188): 7 sigma points around a MAP-frame pose (+-1.5 cells, +-0.05 rad, the pose itself), their
 // likelihoods weight a sample mean and a 3x3 sample covariance.  One workgroup per pose, wave w scores
 // sigma point w (same sampler as above), thread 0 does the 7-term statistics in the source's order.
-template <int LAYOUT>
+template <int LAYOUT, bool EXACT = false>
 __global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L, const float* __restrict__ poses,
                                                               int batch, const float2* __restrict__ pts, int n,
                                                               float pt_scale, float cell_length,
@@ -1284,6 +1321,7 @@ __global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L,
                                                               float* __restrict__ out_cov_world,
                                                               float* __restrict__ out_lh7) {
   __shared__ float lh[7];
+  __shared__ float rows[EXACT ? 7 : 1][EXACT ? 64 : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.x;
   const float deltaTransX = 1.5f, deltaTransY = 1.5f, deltaAng = 0.05f;
@@ -1300,14 +1338,29 @@ __global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L,
     const LevelRegs R = level_regs<LAYOUT>(L);
     const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
     float residual = 0.0f;
-    for (int i = lane; i < n; i += 64) {
-      const float2 p = pts[i];
-      BeamRot r;
-      const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
-      const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
-      residual += 1.0f - M;
+    if (EXACT) {
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        float funval = 0.0f;
+        if (i < n) {
+          const float2 p = pts[i];
+          BeamRot r;
+          const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+          const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+          funval = 1.0f - M;
+        }
+        residual = exact_residual_round(funval, rows[w], lane, residual);
+      }
+    } else {
+      for (int i = lane; i < n; i += 64) {
+        const float2 p = pts[i];
+        BeamRot r;
+        const BeamSample s = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * pt_scale, p.y * pt_scale}, r);
+        const float M = ((s.lo.x * s.X.x + s.lo.y * s.X.y) * (s.Y.x)) + ((s.hi.x * s.X.x + s.hi.y * s.X.y) * (s.Y.y));
+        residual += 1.0f - M;
+      }
+      residual = wave_allreduce(residual);
     }
-    residual = wave_allreduce(residual);
     if (lane == 0) lh[w] = 1 - (residual / (float)n);
   }
   __syncthreads();

@@ -452,8 +452,8 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
   L.bbox[0] = L.bbox[1] = 0;
   L.bbox[2] = L.bbox[3] = -1;
   if (n > 0) {
-    if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than 65535 beams");
-    if (++L.serial > 0xFFFFu) {  // key generation wrapped: clear the key planes once
+    if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than HSM_MAX_UPDATE_BEAMS beams");
+    if (++L.serial > kSerialMax) {  // key generation wrapped: clear the key planes once
       HIP_TRY(hipMemsetAsync(L.d_key_free, 0, key_free_cells(L.sx, L.sy) * sizeof(unsigned int), h->stream));
       HIP_TRY(hipMemsetAsync(L.d_key_occ, 0, L.cells() * sizeof(unsigned int), h->stream));
       L.serial = 1;
@@ -1439,12 +1439,15 @@ static int score_states(hsm_ctx* h, int level, int batch, const float* states_ma
   const float factor = (float)(1.0 / pow(2.0, (double)level));
   const LevelView v = level_view(h->levels[level], factor, 1);
   const int grid = (batch + 3) / 4;
-  if (h->layout == kLayoutPlane)
-    hipLaunchKernelGGL((likelihood_kernel<kLayoutPlane>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
-                       n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr);
-  else
-    hipLaunchKernelGGL((likelihood_kernel<kLayoutQuad>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan,
-                       n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr);
+#define HSM_LAUNCH_LH(LAY, EX)                                                                                         \
+  hipLaunchKernelGGL((likelihood_kernel<LAY, EX>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan, \
+                     n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr)
+  if (h->layout == kLayoutPlane) {
+    if (h->exact) HSM_LAUNCH_LH(kLayoutPlane, true); else HSM_LAUNCH_LH(kLayoutPlane, false);
+  } else {
+    if (h->exact) HSM_LAUNCH_LH(kLayoutQuad, true); else HSM_LAUNCH_LH(kLayoutQuad, false);
+  }
+#undef HSM_LAUNCH_LH
   HIP_TRY(hipGetLastError());
   if (out_lh) HIP_TRY(hipMemcpyAsync(out_lh, d_lh, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   if (out_residual)
@@ -1484,12 +1487,15 @@ int hsm_covariance_for_poses(hsm_ctx* h, int level, int batch, const float* pose
   const float factor = (float)(1.0 / pow(2.0, (double)level));
   const Level& Lv = h->levels[level];
   const LevelView v = level_view(Lv, factor, 1);
-  if (h->layout == kLayoutPlane)
-    hipLaunchKernelGGL((pose_covariance_kernel<kLayoutPlane>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch,
-                       h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7);
-  else
-    hipLaunchKernelGGL((pose_covariance_kernel<kLayoutQuad>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch,
-                       h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7);
+#define HSM_LAUNCH_COV(LAY, EX)                                                                                     \
+  hipLaunchKernelGGL((pose_covariance_kernel<LAY, EX>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch, \
+                     h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7)
+  if (h->layout == kLayoutPlane) {
+    if (h->exact) HSM_LAUNCH_COV(kLayoutPlane, true); else HSM_LAUNCH_COV(kLayoutPlane, false);
+  } else {
+    if (h->exact) HSM_LAUNCH_COV(kLayoutQuad, true); else HSM_LAUNCH_COV(kLayoutQuad, false);
+  }
+#undef HSM_LAUNCH_COV
   HIP_TRY(hipGetLastError());
   if (out_cov_map)
     HIP_TRY(hipMemcpyAsync(out_cov_map, d_map, (size_t)batch * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

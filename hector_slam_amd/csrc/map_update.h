@@ -12,7 +12,7 @@
 //
 // Parallel formulation (bit-exact with the sequential reference):
 //   pass 1 "mark" (per beam), two launches: (a) every beam atomicMax'es
-//       key = (scan serial << 16) | (0xFFFF - beam index) into the occ-key plane at its end cell,
+//       key = (scan serial << 20) | (0xFFFFF - beam index) into the occ-key plane at its end cell,
 //       which leaves the FIRST beam (lowest index) ending there; (b) one wavefront per beam, lane k
 //       owns Bresenham steps k, k+64, ... -- the cell of step i has a closed form (minor steps =
 //       floor((e0 + i*db)/da)), so no lane walks the line sequentially -- and tags every crossed
@@ -26,7 +26,7 @@
 //   pass 3 "texels" (per cell, dense over the box grown by one):  rebuilds the float4 texels
 //       {P(x,y),P(x+1,y),P(x,y+1),P(x+1,y+1)} the matcher samples.
 // Keys of earlier scans are always smaller than the current ones, so the key planes never need
-// clearing (only when the 16-bit serial wraps, every 65535 updates).
+// clearing (only when the 12-bit serial wraps, every 4095 updates).
 //
 // Traffic: mark = one 4-byte load (+ rarely an atomic) per visited cell; apply = 12 B
 // read + 12 B written per touched cell of the box; texels = 16 B written per cell of the box.
@@ -74,6 +74,13 @@ __device__ __forceinline__ unsigned int key_free_index(const LevelRW& L, unsigne
 #endif
 }
 
+// Key = (generation of the scan << kBeamBits) | (kBeamMask - beam index): atomicMax keeps the newest scan and, within
+// it, the LOWEST beam index.  20 bits of beam index (scans of up to 1 048 575 beams; the reference has no limit, and
+// neither has any sensor), 12 bits of generation: the key planes are cleared once every 4095 updates of a level.
+constexpr unsigned int kBeamBits = 20;
+constexpr unsigned int kBeamMask = (1u << kBeamBits) - 1u;
+constexpr unsigned int kSerialMax = (1u << (32 - kBeamBits)) - 1u;
+
 struct UpdateParams {
   LevelRW lv;
   Affine2 pose;           // Translation(mapPose.xy) * Rotation(mapPose.theta), host sinf/cosf
@@ -81,7 +88,7 @@ struct UpdateParams {
   int n;
   float pt_scale;         // 2^-level (exact), DataPointContainer.h:46-58
   int bx, by;             // scanBeginMapi (OccGridMapBase.h:137)
-  unsigned int serial;    // 1..65535
+  unsigned int serial;    // 1..kSerialMax
   float log_odds_free, log_odds_occ;
   int mark_free, mark_occ;  // currMarkFreeIndex / currMarkOccIndex (OccGridMapBase.h:123-124)
   int x0, y0, x1, y1;       // inclusive cell bounding box of everything this scan can touch
@@ -179,7 +186,7 @@ __device__ __forceinline__ void mark_occ_block(const UpdateParams& P, unsigned i
   }
   const unsigned int c_prev = (unsigned int)__shfl_up((int)c, 1);
   const bool first_of_cell = valid && (lane == 0 || c_prev != c);
-  if (first_of_cell) atomicMax(&P.lv.key_occ[c], (P.serial << 16) | (0xFFFFu - (unsigned int)beam));
+  if (first_of_cell) atomicMax(&P.lv.key_occ[c], (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam));
   // bitmap: runs of adjacent valid lanes with the same word
   const unsigned int w = valid ? (c >> 5) : (0xfffffff0u - (unsigned int)lane);  // invalid lanes never join a run
   const unsigned int w_prev = (unsigned int)__shfl_up((int)w, 1);
@@ -220,8 +227,8 @@ __device__ __forceinline__ void mark_free_block(const UpdateParams& P, unsigned 
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
-  const unsigned int tag = P.serial << 16;
-  const unsigned int key = tag | (0xFFFFu - (unsigned int)beam);
+  const unsigned int tag = P.serial << kBeamBits;
+  const unsigned int key = tag | (kBeamMask - (unsigned int)beam);
   if ((unsigned int)lane >= b.abs_da) return;
   // Lane k visits steps k, k+64, ...: instead of one integer division per step (line_cell), carry the
   // quotient/remainder of (e0 + i*db) / da forward by the per-64-step increment -- two divisions per lane.
@@ -311,21 +318,21 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
       const unsigned int word = P.lv.occ_bits[c >> 5];
       occ = (word >> (c & 31u)) & 1u;
       ko = occ ? P.lv.key_occ[c] : 0u;
-      occ = occ && (ko >> 16) == P.serial;  // (a bit without this scan's key cannot occur; cheap to insist)
+      occ = occ && (ko >> kBeamBits) == P.serial;  // (a bit without this scan's key cannot occur; cheap to insist)
       if (word != 0u && (c & 31u) == 0) P.lv.occ_bits[c >> 5] = 0u;
     } else {
       // every set bit lies inside the box, so zeroing each word that overlaps it is exact
       if ((c & 31u) == 0 || x == P.x0) P.lv.occ_bits[c >> 5] = 0u;
       ko = P.lv.key_occ[c];
-      occ = (ko >> 16) == P.serial;
+      occ = (ko >> kBeamBits) == P.serial;
     }
-    const bool fre = (kf >> 16) == P.serial;
+    const bool fre = (kf >> kBeamBits) == P.serial;
     if (!fre && !occ) continue;
     float l = P.lv.logodds[c];
     int stamp;
     if (occ) {
       // free-touched by an earlier beam of this scan: applied, then reverted (:231-233)
-      if (fre && (0xFFFFu - (kf & 0xFFFFu)) < (0xFFFFu - (ko & 0xFFFFu))) {
+      if (fre && (kBeamMask - (kf & kBeamMask)) < (kBeamMask - (ko & kBeamMask))) {
         l += P.log_odds_free;
         l -= P.log_odds_free;
       }

@@ -41,7 +41,7 @@ enum {
 };
 
 #define HSM_MAX_LEVELS 8
-#define HSM_MAX_UPDATE_BEAMS 65535
+#define HSM_MAX_UPDATE_BEAMS 1048575
 
 /* probability sampling layout used by the GN kernel (DESIGN.md "data layout"):
  *   QUAD  float4 texel plane {P(x,y),P(x+1,y),P(x,y+1),P(x+1,y+1)}: one 16-byte gather per beam; best for batched matching
@@ -289,7 +289,7 @@ int hsm_eval_beams(hsm_ctx* h, int level, const float pose_map[3], const float* 
 int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const float* pts_level_xy,
                     int n, int max_iterations, float out_pose_world[3], float cov[9]);
 
-/* test hook: set the 16-bit per-scan generation counter of `level`'s key planes (it wraps every 65535
+/* test hook: set the 12-bit per-scan generation counter of `level`'s key planes (it wraps every 4095
  * updates -- 27 minutes at 40 Hz -- and the wrap path has to be exercised without running that long) */
 int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial);
 /* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by

@@ -297,3 +297,28 @@ def test_committed_golden_vectors_bit_identical(capi):
     for q in range(8):
         pose, cov = g.matchData(g2["init"][q], g2[f"q{q}_pts"])
         assert same(pose, g2["pose"][q]) and same(cov, g2["cov"][q]), q
+
+
+@pytest.mark.parametrize("layout", ["quad", "plane"])
+def test_likelihood_residual_and_sigma_point_covariance_bit_identical(capi, oracle_mod, pyramid_scene, kind, layout):
+    """f3 in exact mode: getResidualForState's chain (residual += funval, beam 0 .. n-1) in the reference's order ->
+    residuals, likelihoods, the seven sigma-point likelihoods and both covariance matrices bit for bit"""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o, layout=capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE)
+    rng = np.random.default_rng(9)
+    for lvl in range(sc.levels):
+        f = np.float32(1.0 / 2 ** lvl)
+        for q in range(3):
+            pm = o.map_coords_pose(lvl, sc.query_truth[q])
+            cloud = (pm[None, :] + rng.normal(0, [2.0, 2.0, 0.05], (1500, 3))).astype(np.float32)
+            far = np.array([[-50.0, 3.0, 0.1], [1e6, 1e6, 0.0]], np.float32)  # (almost) everything out of the map
+            states = np.concatenate([pm[None, :], cloud, far])
+            pts = sc.query_scans[q][: [1081, 700, 65][q]]
+            assert same(g.likelihood_states(lvl, states, pts), o.likelihood_states(lvl, states, pts * f)), (lvl, q)
+            assert same(g.residual_states(lvl, states, pts), o.residual_states(lvl, states, pts * f)), (lvl, q)
+            poses = states[:40]
+            cm, cw, lh = g.covariance_for_poses(lvl, poses, pts)
+            om, ow, ol = o.covariance_for_poses(lvl, poses, pts * f)
+            assert same(lh, ol), (lvl, q)
+            assert same(cm, om) and same(cw, ow), (lvl, q)

@@ -473,8 +473,8 @@ def test_capi_error_paths_fail_loudly(capi, small_scene):
     assert b"bad argument" in lib.hsm_last_error()
     assert lib.hsm_level_info(g._h, 7, None, None, None, None) == -1 and b"level" in lib.hsm_last_error()
     assert lib.hsm_update_by_scan_level(g._h, -1, f3, pts.ctypes.data, 4, np.zeros(2, np.float32)) == -1
-    big = np.zeros((70000, 2), np.float32)
-    assert lib.hsm_update_by_scan(g._h, f3, big.ctypes.data, 70000, np.zeros(2, np.float32)) == -4  # HSM_ERR_TOO_LARGE
+    big = np.zeros((1_048_576, 2), np.float32)  # HSM_MAX_UPDATE_BEAMS + 1
+    assert lib.hsm_update_by_scan(g._h, f3, big.ctypes.data, big.shape[0], np.zeros(2, np.float32)) == -4  # HSM_ERR_TOO_LARGE
     h = C.c_void_p()
     opts = capi.HsmOpts(-1, 0, 0)
     assert lib.hsm_create(0.05, 64, 64, 9, 0.5, 0.5, C.byref(opts), C.byref(h)) == -1      # > HSM_MAX_LEVELS
@@ -646,9 +646,9 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
 
 
 def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
-    """the key planes carry a 16-bit per-scan generation; after 65535 updates (27 min at 40 Hz) it wraps and the
-    planes are cleared once.  Updates straddling the wrap -- with stale keys of generation 65533..65535 left in the
-    planes -- must still be bit-exact."""
+    """the key planes carry a 12-bit per-scan generation (the other 20 bits are the beam index); after 4095 updates
+    (100 s at 40 Hz) it wraps and the planes are cleared once.  Updates straddling the wrap -- with stale keys of
+    generation 4093..4095 left in the planes -- must still be bit-exact."""
     sc = pyramid_scene
     g = make_gpu(capi, sc, build=False)
     o = make_oracle(oracle_mod, kind, sc, build=False)
@@ -656,7 +656,7 @@ def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
     for t in range(24):
         if t == 6:
             for lvl in range(sc.levels):
-                capi._check(lib.hsm_debug_set_update_serial(g._h, lvl, 65533 - lvl), "set serial")  # wraps at t = 8..10
+                capi._check(lib.hsm_debug_set_update_serial(g._h, lvl, 4093 - lvl), "set serial")  # wraps at t = 8..10
         o.match(sc.build_poses[t], sc.build_scans[t])
         g.matchData(sc.build_poses[t], sc.build_scans[t])
         o.update_by_scan(sc.build_poses[t], sc.build_scans[t])
@@ -669,6 +669,47 @@ def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
     pg, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
     po, _ = o.match(sc.query_init[0], sc.query_scans[0])
     assert_pose_close(pg, po, "after the wrap")
+
+
+def test_update_with_more_than_65535_beams_is_bit_exact(capi, oracle_mod, kind):
+    """the reference has no limit on the scan length; the update keys carry 20 bits of beam index (1 048 575 beams).
+    A 150 000-beam scan (a 3D sensor projected into the plane), three poses, two levels: maps bit-identical, and the
+    matcher takes the same scan (fast mode: tolerance; exact mode: bits)"""
+    from hector_slam_amd import synth
+    res, size, levels = 0.05, 1024, 2
+    world = synth.World.make(40.0, 30.0, seed=7)
+    s = float(np.float32(1.0) / np.float32(res))
+    rng = np.random.default_rng(5)
+    poses = synth.loop_trajectory(world, 3).astype(np.float32)
+    ang = np.linspace(-np.pi, np.pi, 150_000, endpoint=False)
+    scans = []
+    for p in poses:
+        r = world.raycast(p, ang) + rng.normal(0, 0.01, ang.size)
+        keep = (r > 0.3) & (r < 29.9)
+        scans.append(np.stack([np.cos(ang[keep]) * r[keep] * s, np.sin(ang[keep]) * r[keep] * s], 1).astype(np.float32))
+    assert min(sc.shape[0] for sc in scans) > 100_000
+    g = capi.MapRepMultiMap(res, size, size, levels)
+    o = oracle_mod.Oracle(kind, res, size, size, levels)
+    for m in (g.setUpdateFactorFree, o.set_update_factor_free):
+        m(0.4)
+    for m in (g.setUpdateFactorOccupied, o.set_update_factor_occupied):
+        m(0.9)
+    for p, sc in zip(poses, scans):
+        o.match(p, sc)
+        g.matchData(p, sc)
+        o.update_by_scan(p, sc)
+        g.updateByScan(sc, p)
+        o.on_map_updated()
+    for lvl in range(levels):
+        a, b = g.download_level(lvl), o.download_level(lvl)
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
+    init = poses[1] + np.array([0.05, -0.04, 0.01], np.float32)
+    po, co = o.match(init, scans[1])
+    pg, _ = g.matchData(init, scans[1])
+    assert_pose_close(pg, po, "150k-beam scan")
+    g.set_parity(capi.PARITY_EXACT)
+    px, cx = g.matchData(init, scans[1])
+    assert np.array_equal(bits(px), bits(po)) and np.array_equal(bits(cx), bits(co))
 
 
 def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
