@@ -21,6 +21,9 @@ Extra evidence in the same line (N = 1 only):
   pyramid       the same batch through the full 3-level 2048/1024/512 schedule (14 iterations, SURVEY.md 8(d)'s start
                 errors +-0.15 m / +-0.05 rad), fast and exact mode, parity fractions vs the reference -- measured in a
                 child process (`--leg pyramid`), so that a kernel trace of this process holds the headline launches only
+  pipelined     independent 4096-scan batches round-robin on 4 caller-owned HIP streams (child process): the throughput when
+                launches overlap -- one launch is one generation of wavefronts, so its tail and its gather-heavy first GN
+                steps leave issue slots that the next batch fills.  The headline `value` stays one launch at a time.
   cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and scans, single
                 thread (the reference is single threaded), bounded sample, plus the GPU-vs-CPU pose deviation on
                 that sample (parity evidence, tolerance 1e-4) and the fraction of bit-identical poses;
@@ -647,7 +650,9 @@ def main():
     ap.add_argument("--pyramid", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-exact", action="store_true", help="skip the HSM_PARITY_EXACT leg")
-    ap.add_argument("--leg", default=None, choices=["pmc", "pyramid"],
+    ap.add_argument("--streams", type=int, default=4, help="caller-owned streams of the `pipelined` leg")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream leg")
+    ap.add_argument("--leg", default=None, choices=["pmc", "pyramid", "pipelined"],
                     help="internal: a leg of the default run executed in a child process")
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
                     help="config3 = the headline (BASELINE configs[2]); others are the extra configs")
@@ -760,6 +765,39 @@ def main():
         matcher = build_matcher(1)
         run(matcher, d_init_l0, args.steps, args.warmup)
         return
+    if args.leg == "pipelined":
+        # Independent batches issued round-robin on S caller-owned streams (hsm_match_batch_device is asynchronous on the
+        # stream it is given).  One launch of 4096 scans is ONE generation of wavefronts -- one per scan, four per SIMD --
+        # so ~16 % of its duration is tail (waves that finish early leave their slots empty) and the early, gather-heavy
+        # GN steps of all waves coincide; with several launches in flight the next batch fills those slots and the
+        # phases of different batches interleave.  Same kernels, same results (checked bit for bit against stream 0).
+        S = max(1, args.streams)
+        res = {"streams": S, "unit": "GN it/s", "note": "throughput of INDEPENDENT 4096-scan batches overlapped on several HIP "
+               "streams; the headline `value` keeps one launch at a time (the latency of one batch)"}
+        for levels, d_init, name in ((1, d_init_l0, "level0"), (3, d_init_pyr, "pyramid")):
+            mm = build_matcher(levels)
+            its = mm.gn_iterations_per_match()
+            streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+            poses = [torch.zeros((B, 3), dtype=torch.float32, device=dev) for _ in range(S)]
+
+            def pstep(k):
+                mm.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS,
+                                      poses[k % S].data_ptr(), 0, streams[k % S].cuda_stream)
+            for k in range(3 * S):
+                pstep(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                pstep(k)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            same = all(bool(torch.equal(poses[0], p)) for p in poses[1:])
+            res[name] = {"value": B * its * args.steps / dtp, "us_per_batch": dtp / args.steps * 1e6, "steps": args.steps,
+                         "gn_iterations_per_scan": its, "all_streams_bit_identical": same}
+            mm.close()
+        res["value"] = res["level0"]["value"]
+        print(json.dumps(res))
+        return
     if args.leg == "pyramid":  # full 3-level matchData, SURVEY.md 8(d)'s start errors, both parity modes
         m3 = build_matcher(3)
         res = {"levels": 3, "start_error": "+-0.15 m, +-0.05 rad (SURVEY.md 8(d))", "unit": "GN it/s"}
@@ -847,6 +885,9 @@ def main():
     if single and not args.no_pyramid and args.levels == 1:
         out["pyramid"] = run_child(["--leg", "pyramid", "--steps", str(max(10, args.steps // 4)), "--batch", str(B)] +
                                    (["--no-cpu"] if args.no_cpu else []))
+    if single and not args.no_pipelined and args.levels == 1:
+        out["pipelined"] = run_child(["--leg", "pipelined", "--steps", str(max(40, args.steps)), "--batch", str(B),
+                                      "--streams", str(args.streams)])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
