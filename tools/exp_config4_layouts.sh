@@ -2,7 +2,7 @@
 # config4 (4096^2 pyramid): time + HBM-side fetch for layout / tiling variants
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/j
+OUT=$ROOT/gpurun_out/exp_c4
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 run() { # name, env...

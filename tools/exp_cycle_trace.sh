@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/e
+OUT=$ROOT/gpurun_out/exp_trace
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 HSM_LAYOUT=plane timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python $ROOT/bench.py --workload config2 --steps 100 --no-cpu > "$OUT/c2.json" 2>"$OUT/c2.err"

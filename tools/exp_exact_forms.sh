@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/l
+OUT=$ROOT/gpurun_out/exp_exact
 mkdir -p "$OUT"
 cd "$ROOT"
 timeout 900 python -m pytest tests/test_gpu_exact_parity.py tests/test_gpu_full_size.py -m gpu -q -x 2>&1 | tail -6

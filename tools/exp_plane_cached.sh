@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/k
+OUT=$ROOT/gpurun_out/exp_pc
 mkdir -p "$OUT"
 cd $ROOT
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "texel_cache or hint or batch" 2>&1 | tail -3
