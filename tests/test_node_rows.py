@@ -213,7 +213,7 @@ def test_ingest_point_cloud_bit_exact(capi, oracle_mod, pyramid_scene):
                                       20.0, None, C.byref(cnt), None) == -1
     assert lib.hsm_ingest_laser_scan_tf(g._h, None, 5, 0.0, 0.1, 0.1, 30.0, 30.0, rigid_rows(rng).ctypes.data, 0.16,
                                         900.0, -1.0, 1.0, 20.0, None, C.byref(cnt), None) == -1
-    assert lib.hsm_ingest_point_cloud(g._h, c3.ctypes.data, 70000, rigid_rows(rng).ctypes.data, 0.16, 900.0, -1.0,
+    assert lib.hsm_ingest_point_cloud(g._h, c3.ctypes.data, 1_048_576, rigid_rows(rng).ctypes.data, 0.16, 900.0, -1.0,
                                       1.0, 20.0, None, C.byref(cnt), None) == -1 and cnt.value == -7
     # alternating entries share the geometry-table cache: the float2 and double2 tables must not be confused
     r = synthetic_ranges(rng, 1081)
