@@ -508,6 +508,23 @@ __device__ __forceinline__ void gn_solve_and_step(const Acc9& a, float& ex, floa
   }
 }
 
+// The SIMD's issue arbiter favours its oldest wavefront.  In a throughput launch -- one wavefront per scan, four per
+// SIMD, all started within 2 us -- the four therefore finish one after another (time stamps of a headline launch:
+// ~33 / 42 / 50 / 52 us) and the last ones run with too few neighbours to cover their gathers.  Rotating the priority
+// from GN step to GN step (slot id of the wave + step counter, two SALU instructions) keeps them in step: headline
+// 57.1 -> 55.4 us, 3-level pyramid 118.7 -> 110 us, 4096^2 pyramid 150 -> 142 us (profiles/r02/README.md).  Used by the
+// texel-cache form only: the form that gathers every beam in every step loses 4 % with it (67 -> 69.5 us).
+__device__ __forceinline__ void rotate_wave_priority(int step) {
+  unsigned hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));  // bits 3:0 = wave slot on its SIMD
+  switch (((hwid & 0xFu) + (unsigned)step) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // One team (WPS wavefronts) per scan; SPB scans per workgroup (SPB > 1 only when WPS == 1,
 // where no barrier is ever executed so the wavefronts of a block are fully independent).
 //
@@ -798,6 +815,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       toff[k] = 0xffffffffu;  // never a texel offset (not a multiple of 16): every beam gathers in the first step
     }
     for (int it = 0; it < gn_steps; ++it) {
+      rotate_wave_priority(it + l);
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();

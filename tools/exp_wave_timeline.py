@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Per-wave start/end time stamps of ONE headline launch (library built with -DHSM_EXP_TIMESTAMPS: the kernel writes
+them over the covariance output): how do finish times spread over XCDs / CUs?  usage: HSM_LIB=... python tools/exp_wave_timeline.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    import torch
+    from hector_slam_amd import capi
+    dev = torch.device("cuda", 0)
+    B = 4096
+    bp, bs, truth, init, init_pyr, pts, offs = bench.make_inputs(0, B)
+    m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, 1, device=0)
+    m.setUpdateFactorFree(0.4)
+    m.setUpdateFactorOccupied(0.9)
+    m.build_map(bp, bs)
+    d_init, d_pts, d_offs = (torch.from_numpy(a).to(dev) for a in (init, pts, offs))
+    pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+    cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream()
+    for rep in range(4):
+        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+    u = cov.cpu().numpy().view(np.uint32)
+    t0 = u[:, 0].astype(np.uint64) | (u[:, 1].astype(np.uint64) << np.uint64(32))
+    t1 = u[:, 2].astype(np.uint64) | (u[:, 3].astype(np.uint64) << np.uint64(32))
+    base = t0.min()
+    b = (t0 - base).astype(np.float64) / 100.0  # 100 MHz -> us
+    e = (t1 - base).astype(np.float64) / 100.0
+    hwid, xcc, blk = u[:, 4], u[:, 5] & 0xF, u[:, 6]
+    cu = (hwid >> 8) & 0xF
+    se = (hwid >> 13) & 0x7
+    print(f"waves {B}: start min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f} us; end min/median/p90/max "
+          f"{e.min():.1f}/{np.median(e):.1f}/{np.percentile(e, 90):.1f}/{e.max():.1f} us; lifetime median {np.median(e - b):.1f}")
+    for x in range(8):
+        sel = xcc == x
+        if sel.any():
+            print(f"  XCC {x}: waves {sel.sum():4d} start max {b[sel].max():5.1f} end median {np.median(e[sel]):5.1f} max {e[sel].max():5.1f}  blocks {blk[sel].min()}..{blk[sel].max()} (mod 8 = {sorted(set((blk[sel] % 8).tolist()))})")
+    # per CU finish (xcc, se, cu)
+    key = xcc.astype(np.int64) * 1000 + se.astype(np.int64) * 100 + cu.astype(np.int64)
+    fin = {k: e[key == k].max() for k in np.unique(key)}
+    f = np.array(list(fin.values()))
+    print(f"  per-CU finish: {len(f)} CUs, min {f.min():.1f} median {np.median(f):.1f} p90 {np.percentile(f, 90):.1f} max {f.max():.1f} us; "
+          f"mean idle before the launch ends {np.mean(f.max() - f):.1f} us")
+    hist, edges = np.histogram(e, bins=12)
+    print("  end-time histogram:", [(round(edges[i], 1), int(hist[i])) for i in range(len(hist))])
+
+
+if __name__ == "__main__":
+    main()
