@@ -1026,11 +1026,21 @@ __global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batc
         float sinRot, cosRot;
         sincos_f32(eth, sinRot, cosRot);
         const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+        // two-deep software pipeline: the endpoint of round r + 2 and the texel of round r + 1 are in flight while
+        // the products of round r are computed, so the barrier of a round does not wait for a memory round trip
+        const float2 pad = make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products
+        float2 p_next = lane < n ? pts[lane] : pad;
+        BeamRot rot_next;
+        BeamSample b_next = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next);
+        p_next = 64 + lane < n ? pts[64 + lane] : pad;
         for (int r = 0; r < rounds; ++r) {
-          const int i = (r << 6) + lane;
-          const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products
-          BeamRot rot;
-          const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, rot);
+          const BeamSample b = b_next;
+          const BeamRot rot = rot_next;
+          if (r + 1 < rounds) {
+            b_next = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next);
+            const int i2 = ((r + 2) << 6) + lane;
+            p_next = i2 < n ? pts[i2] : pad;
+          }
           float pr[9];
           beam_products(b, rot, pr);
           float* st = &stage[r & 1][wave][0][lane];
