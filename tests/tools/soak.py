@@ -1,34 +1,66 @@
 #!/usr/bin/env python
-"""Long-run soak (one-off evidence, not part of the suite): N match+update steps around the room, the same poses fed
-to the GPU path and to the oracle, so the maps must stay BIT-IDENTICAL throughout -- through the natural wrap of the
-16-bit key generation (65535 updates) and the saturation of the log-odds clamp.  Prints one JSON line."""
-import json, os, sys, time
+"""Long-run soak (one-off evidence, not part of the suite): N match+update steps around the room on the GPU path and on
+the CPU checker; prints one JSON line.
+
+  default      the same (ground-truth) poses are fed to both map updates, so the maps must stay BIT-IDENTICAL
+               throughout -- through the wraps of the update path's 12-bit key generation (every 4095 updates) and the
+               saturation of the log-odds clamp; the matched poses are compared step by step
+  --free-run   every side updates its map with its OWN matched pose and starts the next match from it: nothing is shared
+               but the scans.  With --exact (HSM_PARITY_EXACT) poses AND maps must still be bit-identical after N steps --
+               one differing bit anywhere would send the two SLAM states apart.
+
+usage: soak.py [N] [--exact] [--free-run]"""
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np
-from hector_slam_amd import synth, capi
-from oracle import pyoracle
+import numpy as np  # noqa: E402
+
+from hector_slam_amd import capi, synth  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
 pyoracle.build()
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 70000
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if args else 70000
+exact, free_run = "--exact" in sys.argv, "--free-run" in sys.argv
+kind = "hr" if pyoracle.available("hr") else "ho"
 sc = synth.make_scene(n_beams=1081, map_size=1024, levels=3, resolution=0.05, n_build=400, n_query=4, room=(40.0, 30.0), seed=5)
-g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
-o = pyoracle.Oracle("ho", sc.resolution, sc.map_size, sc.map_size, sc.levels)
-for m in (g.setUpdateFactorFree, o.set_update_factor_free): m(0.4)
-for m in (g.setUpdateFactorOccupied, o.set_update_factor_occupied): m(0.9)
-worst = 0.0; ident = 0; tg = tc = 0.0
+g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, parity=capi.PARITY_EXACT if exact else capi.PARITY_FAST)
+o = pyoracle.Oracle(kind, sc.resolution, sc.map_size, sc.map_size, sc.levels)
+for m in (g.setUpdateFactorFree, o.set_update_factor_free):
+    m(0.4)
+for m in (g.setUpdateFactorOccupied, o.set_update_factor_occupied):
+    m(0.9)
+worst = 0.0
+ident = 0
+tg = tc = 0.0
+pose_g = pose_o = sc.build_poses[0].copy()
 for t in range(N):
     k = t % 400
+    step = sc.build_poses[k] - sc.build_poses[k - 1] if t else np.zeros(3, np.float32)
+    hint_g = pose_g + step if free_run and t >= 8 else sc.build_poses[k]   # the first scans are mapped at their true poses
+    hint_o = pose_o + step if free_run and t >= 8 else sc.build_poses[k]
     a = time.perf_counter()
-    pg, _ = g.matchData(sc.build_poses[k], sc.build_scans[k]); g.updateByScan(sc.build_scans[k], sc.build_poses[k])
+    pg, _ = g.matchData(hint_g, sc.build_scans[k])
+    g.updateByScan(sc.build_scans[k], pg if free_run and t >= 8 else sc.build_poses[k])
     b = time.perf_counter()
-    po, _ = o.match(sc.build_poses[k], sc.build_scans[k]); o.update_by_scan(sc.build_poses[k], sc.build_scans[k]); o.on_map_updated()
+    po, _ = o.match(hint_o, sc.build_scans[k])
+    o.update_by_scan(po if free_run and t >= 8 else sc.build_poses[k], sc.build_scans[k])
+    o.on_map_updated()
     c = time.perf_counter()
-    tg += b - a; tc += c - b
+    tg += b - a
+    tc += c - b
+    pose_g, pose_o = pg, po
     worst = max(worst, float(np.abs(pg.astype(np.float64) - po)[:2].max()))
     ident += int(np.array_equal(pg.view(np.uint32), po.view(np.uint32)))
-maps_equal = True; sat = 0
+maps_equal = True
+sat = 0
 for lvl in range(sc.levels):
     a_, b_ = g.download_level(lvl), o.download_level(lvl)
     maps_equal &= bool(np.array_equal(a_[0].view(np.uint32), b_[0].view(np.uint32)) and np.array_equal(a_[1], b_[1]))
     sat += int((b_[0] >= 50.0).sum())
-print(json.dumps({"steps": N, "maps_bit_identical": maps_equal, "cells_at_clamp": sat, "worst_pose_dev_m": worst,
+print(json.dumps({"steps": N, "mode": "exact" if exact else "fast", "free_run": free_run, "checker": kind,
+                  "maps_bit_identical": maps_equal, "cells_at_clamp": sat, "worst_pose_dev_m": worst,
                   "bit_identical_pose_fraction": ident / N, "gpu_ms_per_step": tg / N * 1e3, "cpu_ms_per_step": tc / N * 1e3}))
