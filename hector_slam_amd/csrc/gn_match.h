@@ -207,6 +207,7 @@ __device__ __forceinline__ LevelRegs level_regs(const LevelView& L) {
 // worth 1.6 scalar ones, which the v_mov shuffles needed to form pairs eat up again.  So the
 // arithmetic below is plain scalar fp32 and the library is built with -fno-slp-vectorize.
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));  // a native 128-bit register tuple (inline-asm operand)
 
 struct BeamSample {
   f2 lo, hi;  // (P(ix,iy), P(ix+1,iy)), (P(ix,iy+1), P(ix+1,iy+1))
@@ -226,16 +227,65 @@ struct BeamSample {
 // and the clamped value doubles as the finite stand-in coordinate of an outside beam.  A NaN
 // coordinate never equals its clamp, so it counts as outside (the reference would index the map
 // with (int)NaN there and crash).  v_fract_f32(x) == x - (float)(int)x exactly for 0 <= x < 2^23.
+// Bounds test of one map coordinate pair.  HSM_BOUNDS_BITS=1 (default): 0 <= x <= lim on the BIT PATTERNS -- for
+// x >= +0 the unsigned pattern of an fp32 value is monotonic in the value, every negative value (sign bit set) and
+// every NaN compares above any non-negative limit, so `bits(x) <= bits(lim)` is the whole test in ONE v_cmp_le_u32
+// per axis (the clamp form costs v_med3 + v_cmp_neq per axis).  The one value the pattern test would judge
+// differently is -0.0 (inside for the reference: -0.0 < 0 is false); c = e + r is -0.0 only if e AND r are -0.0,
+// and the callers pass e + 0.0f (wave-uniform, once per GN step; changes no other sum), so it cannot occur.
+// Outside beams keep their raw coordinate: v_cvt_i32_f32 saturates and v_fract_f32 of a finite value is finite,
+// which is all the all-zero texel needs to yield +-0 products.
+#ifndef HSM_BOUNDS_BITS
+#define HSM_BOUNDS_BITS 1
+#endif
+// the estimate's map coordinates as the beam loop adds them to the rotated endpoints: -0.0 -> +0.0 (see above; for
+// every other value x + 0.0f == x, and (+0.0) + r == (-0.0) + r unless r is -0.0 too)
+__device__ __forceinline__ f2 step_origin(float ex, float ey) {
+#if HSM_BOUNDS_BITS
+  return f2{ex + 0.0f, ey + 0.0f};
+#else
+  return f2{ex, ey};
+#endif
+}
+
+struct CellCoord {
+  unsigned ix, iy;
+  float fx, fy;
+  bool oob;
+};
+
+__device__ __forceinline__ CellCoord cell_coord(const LevelRegs& L, f2 c) {
+  CellCoord q;
+#if HSM_BOUNDS_BITS
+  q.oob = (int)(__float_as_uint(c.x) > __float_as_uint(L.limx)) | (int)(__float_as_uint(c.y) > __float_as_uint(L.limy));
+  const float sx_ = c.x, sy_ = c.y;
+#else
+  const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, L.limx);
+  const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, L.limy);
+  q.oob = (sx_ != c.x) | (sy_ != c.y);
+#endif
+#if HSM_BOUNDS_BITS
+  // truncation, OccGridMapUtil.h:295.  The instruction itself (saturating, defined for every input) rather than a
+  // C++ cast, whose result is undefined for the raw coordinate of an outside beam.
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(q.ix) : "v"(sx_));
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(q.iy) : "v"(sy_));
+#else
+  q.ix = (unsigned)(int)sx_;  // truncation, OccGridMapUtil.h:295
+  q.iy = (unsigned)(int)sy_;
+#endif
+  q.fx = __builtin_amdgcn_fractf(sx_);  // :298
+  q.fy = __builtin_amdgcn_fractf(sy_);
+  return q;
+}
+
 template <int LAYOUT>
 __device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
   BeamSample b;
-  const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, L.limx);
-  const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, L.limy);
-  const bool oob = (sx_ != c.x) | (sy_ != c.y);
-  const unsigned ix = (unsigned)(int)sx_;  // truncation, OccGridMapUtil.h:295
-  const unsigned iy = (unsigned)(int)sy_;
-  b.X.y = __builtin_amdgcn_fractf(sx_);  // :298
-  b.Y.y = __builtin_amdgcn_fractf(sy_);
+  const CellCoord q = cell_coord(L, c);
+  const bool oob = q.oob;
+  const unsigned ix = q.ix, iy = q.iy;
+  b.X.y = q.fx;
+  b.Y.y = q.fy;
   b.X.x = 1.0f - b.X.y;  // :338-339
   b.Y.x = 1.0f - b.Y.y;
   if (LAYOUT == kLayoutQuad) {
@@ -352,7 +402,7 @@ __device__ __forceinline__ float beam_accumulate(const LevelRegs& L, float ex, f
                                                  float cosRot, float px, float py, Acc9& a,
                                                  BeamTerms* terms_out = nullptr) {
   BeamRot r;
-  const BeamSample b = beam_fetch<LAYOUT>(L, f2{ex, ey}, f2{cosRot, sinRot}, f2{sinRot, cosRot}, f2{px, py}, r);
+  const BeamSample b = beam_fetch<LAYOUT>(L, step_origin(ex, ey), f2{cosRot, sinRot}, f2{sinRot, cosRot}, f2{px, py}, r);
   return beam_finish(b, r, a, terms_out);
 }
 
@@ -433,7 +483,73 @@ __device__ __forceinline__ float wave_allreduce(float v) {
   return v;
 }
 
+// The nine totals at once, "folded": a butterfly level that pairs lanes i and p(i) needs the sum of a value only in
+// ONE lane of each pair if the other lane of the pair carries a second value -- so each level halves the number of
+// live registers instead of keeping nine.  v_permlane32_swap / v_permlane16_swap do exactly that for two registers
+// (swap + add = 2 instructions per PAIR of values instead of mov + swap + add per value), the two row levels do it with
+// DPP bank masks (v_add_f32_dpp writes only the enabled banks of its destination), and the last two levels run on
+// the single register that is left.  25 instructions + 9 v_readlane_b32 (the totals end up in SGPRs, identical in
+// every lane) instead of 90.  Level order 32, 16, row_mirror, row_half_mirror, lane^2, lane^1 -- the same pairing
+// tree for all nine values.
+#ifndef HSM_REDUCE_FOLD
+#define HSM_REDUCE_FOLD 1
+#endif
+
+__device__ __forceinline__ float fold_swap32(float a, float b) {  // lanes 0..31: a[i] + a[i+32];  32..63: b[i-32] + b[i]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_swap16(float a, float b) {  // rows 0, 2: a (row + row^1);  rows 1, 3: b
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+__device__ __forceinline__ void wave_allreduce9_folded(Acc9& a) {
+  // level 32 and level 16: the totals over the four rows, per column of 16
+  const float a0 = fold_swap32(a.d01.x, a.d01.y);  // rows 0,1: dTr0   rows 2,3: dTr1
+  const float a1 = fold_swap32(a.d2, a.hd.x);      //           dTr2             H00
+  const float a2 = fold_swap32(a.hd.y, a.h22);     //           H11              H22
+  const float a3 = fold_swap32(a.h01, a.hr.x);     //           H01              H02
+  const float a4 = fold_swap32(a.hr.y, a.hr.y);    // H12 everywhere
+  float b0 = fold_swap16(a0, a1);                  // rows: dTr0, dTr2, dTr1, H00
+  float b1 = fold_swap16(a2, a3);                  // rows: H11,  H01,  H22,  H02
+  float b2 = fold_swap16(a4, a4);                  // H12 in every row
+  // row levels.  s_nop: the hazard recogniser does not look into inline asm (a DPP operand needs two wait states
+  // after the VALU write of its register)
+  asm("s_nop 1\n\t"
+      // row_mirror (lane i <-> 15 - i): banks 2,3 of b1 keep b1's sums, banks 0,1 of b1 take b0's; b2 plain
+      "v_add_f32_dpp %[b1], %[b1], %[b1] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %[b1], %[b0], %[b0] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %[b2], %[b2], %[b2] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      // row_half_mirror (i <-> 7 - i inside each half row): banks 1,3 of b2 keep H12, banks 0,2 take b1's
+      "v_add_f32_dpp %[b2], %[b2], %[b2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %[b2], %[b1], %[b1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[b2], %[b2], %[b2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %[b2], %[b2], %[b2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : [b1] "+v"(b1), [b2] "+v"(b2)
+      : [b0] "v"(b0));
+  // where the totals sit: lane 16 * row + 4 * bank.  bank 0 <- b0's rows, bank 2 <- b1's rows, banks 1, 3 <- H12
+  auto lane_value = [&](int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), lane)); };
+  a.d01.x = lane_value(0);
+  a.d2 = lane_value(16);
+  a.d01.y = lane_value(32);
+  a.hd.x = lane_value(48);
+  a.hd.y = lane_value(8);
+  a.h01 = lane_value(24);
+  a.h22 = lane_value(40);
+  a.hr.x = lane_value(56);
+  a.hr.y = lane_value(4);
+}
+
 __device__ __forceinline__ void wave_allreduce9(Acc9& a) {
+#if HSM_REDUCE_FOLD
+  wave_allreduce9_folded(a);
+  return;
+#endif
   a.d01.x = wave_allreduce(a.d01.x);
   a.d01.y = wave_allreduce(a.d01.y);
   a.d2 = wave_allreduce(a.d2);
@@ -615,7 +731,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
-      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
       if (in_regs) {
 #if HSM_PIPELINE
         // Software pipeline of depth one (experiment switch): the texel gather of beam k+1 is issued
@@ -752,6 +868,15 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
 #define HSM_CACHE_PIPE_CHUNK 1
 #endif
 constexpr int kCachePipeChunk = HSM_CACHE_PIPE_CHUNK;
+#ifndef HSM_ASM_GATHER   // counted waits for the masked texel gathers (see locate())
+#define HSM_ASM_GATHER 1
+#endif
+#ifndef HSM_LDS_AHEAD    // endpoint of beam k+2 read from LDS while beam k is consumed
+#define HSM_LDS_AHEAD 1
+#endif
+#ifndef HSM_ZERO_VGPR
+#define HSM_ZERO_VGPR 1
+#endif
 
 // a wave-uniform value moved to an SGPR
 __device__ __forceinline__ float uniform_f32(float v) {
@@ -797,7 +922,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 #if defined(HSM_EXP_TIMESTAMPS)  // experiment (tools/exp_wave_timeline.py): per-wave start / end stamps of the 100 MHz clock
   const unsigned long long ts_begin = wall_clock64();
 #endif
-  float4 tq[BPL];
+  f4v tq[BPL];
   unsigned toff[BPL];
   Acc9 acc;
   acc.zero();
@@ -817,46 +942,91 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       if (ratio != 1.0f) mine[k][lane] *= f2{ratio, ratio};
       toff[k] = 0xffffffffu;  // never a texel offset (not a multiple of 16): every beam gathers in the first step
     }
+    // byte offset of the all-zero texel, pinned in a VGPR (as an SGPR it costs a v_mov per beam in front of the select)
+    unsigned zero_off = (unsigned)R.zero_index << (LAYOUT == kLayoutQuad ? 4 : 2);
+#if HSM_ZERO_VGPR
+    asm volatile("" : "+v"(zero_off));
+#endif
     for (int it = 0; it < gn_steps; ++it) {
       rotate_wave_priority(it + l);
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
       // the step's pose and rotation are wave-uniform: held in SGPRs (4 VGPRs less in a kernel that has none to spare)
-      const f2 e2 = f2{uniform_f32(ex), uniform_f32(ey)};
+      const f2 o2 = step_origin(ex, ey);
+      const f2 e2 = f2{uniform_f32(o2.x), uniform_f32(o2.y)};
       const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
       // "locate" a beam: rotate, bounds test, cell offset, fractions, and -- only in the lanes whose cell changed since
       // the previous step -- the gather of its texel straight into the beam's cache registers
-      auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) {
+      auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) -> unsigned long long {
         r.r.x = cs.x * p.x - sc.x * p.y;
         r.r.y = cs.y * p.x + sc.y * p.y;
-        const f2 c = f2{e2.x + r.r.x, e2.y + r.r.y};
-        const float sx_ = __builtin_amdgcn_fmed3f(c.x, 0.0f, R.limx);
-        const float sy_ = __builtin_amdgcn_fmed3f(c.y, 0.0f, R.limy);
-        const bool oob = (sx_ != c.x) | (sy_ != c.y);
-        const unsigned ix = (unsigned)(int)sx_;
-        const unsigned iy = (unsigned)(int)sy_;
-        fx = __builtin_amdgcn_fractf(sx_);
-        fy = __builtin_amdgcn_fractf(sy_);
-        unsigned idx = LAYOUT == kLayoutQuad ? quad_index(ix, iy, R.tiles_x, R.sx) : __umul24(iy, (unsigned)R.sx) + ix;
+        const CellCoord q = cell_coord(R, f2{e2.x + r.r.x, e2.y + r.r.y});
+        fx = q.fx;
+        fy = q.fy;
+        unsigned idx = LAYOUT == kLayoutQuad ? quad_index(q.ix, q.iy, R.tiles_x, R.sx) : __umul24(q.iy, (unsigned)R.sx) + q.ix;
         asm volatile("" : "+v"(idx));  // computed unconditionally: a select below, not a branch
 #if defined(HSM_EXP_CACHE_FLOOR)  // experiment: every lane always hits its cached texel after the first gather
-        const unsigned off = ((oob ? (unsigned)R.zero_index : idx) & 0u) + 4096u;
+        const unsigned off = ((q.oob ? zero_off : idx) & 0u) + 4096u;
 #else
-        const unsigned off = (oob ? (unsigned)R.zero_index : idx) << (LAYOUT == kLayoutQuad ? 4 : 2);
+        const unsigned off = q.oob ? zero_off : idx << (LAYOUT == kLayoutQuad ? 4 : 2);
 #endif
+        if (LAYOUT == kLayoutQuad && HSM_ASM_GATHER) {
+          // The masked gather as ONE instruction sequence under the wave's own control.  The compiler's form of
+          // `if (off != toff[k]) load` waits with vmcnt(0) before the PREVIOUS beam is consumed -- it cannot count
+          // loads that sit behind a branch -- which puts the gather just issued on the critical path and defeats the
+          // software pipeline below.  Here the wave records whether the gather was issued (the mask of the lanes that
+          // moved, wave-uniform) and texel_ready() waits for exactly the load it needs.  No C++ control flow: the
+          // compiler sees straight-line code and keeps tq[k] where it is (it does not know about the asynchronous
+          // write; texel_ready(k) is ordered before every read of tq[k] through its "+v" operand).
+          unsigned long long moved, saved;
+          asm volatile(
+              "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
+              "s_mov_b64 %[mv], vcc\n\t"
+              "s_and_saveexec_b64 %[sv], vcc\n\t"
+              "s_cbranch_execz 1f\n\t"
+              "global_load_dwordx4 %[t], %[o], %[b]\n\t"
+              "v_mov_b32 %[to], %[o]\n\t"
+              "1:\n\t"
+              "s_mov_b64 exec, %[sv]"
+              : [t] "+v"(tq[k]), [to] "+v"(toff[k]), [sv] "=&s"(saved), [mv] "=&s"(moved)
+              : [o] "v"(off), [b] "s"(R.quad)
+              : "vcc", "memory");
+          return moved;
+        }
         if (off != toff[k]) {
           if (LAYOUT == kLayoutQuad) {
-            tq[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(R.quad) + (size_t)off);
+            tq[k] = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(R.quad) + (size_t)off);
           } else {
             // the probability plane itself (4 B per cell: a quarter of the texel plane's footprint, so far more of
             // a map that outgrows the L2 stays in it): rows iy and iy + 1, two cells each
             const char* row = reinterpret_cast<const char*>(R.prob) + (size_t)off;
             const CellPair lo = *reinterpret_cast<const CellPair*>(row);
             const CellPair hi = *reinterpret_cast<const CellPair*>(row + ((size_t)R.sx << 2));
-            tq[k] = make_float4(lo.a, lo.b, hi.a, hi.b);
+            tq[k] = f4v{lo.a, lo.b, hi.a, hi.b};
           }
           toff[k] = off;
+        }
+        return 0ull;
+      };
+      // beam k's texel has landed.  `next_moved` = the mask returned by the locate() of the only gather that may have
+      // been issued after beam k's (wave-uniform): loads return in order, so with it in flight vmcnt(1) is enough.
+      auto texel_ready = [&](int k, unsigned long long next_moved, bool has_next) {
+        if (!(LAYOUT == kLayoutQuad && HSM_ASM_GATHER)) return;
+        if (has_next) {
+          asm volatile(
+              "s_cmp_eq_u64 %[m], 0\n\t"
+              "s_cbranch_scc1 1f\n\t"
+              "s_waitcnt vmcnt(1)\n\t"
+              "s_branch 2f\n\t"
+              "1:\n\t"
+              "s_waitcnt vmcnt(0)\n\t"
+              "2:"
+              : "+v"(tq[k])
+              : [m] "s"(next_moved)
+              : "scc", "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(tq[k]) : : "memory");
         }
       };
       auto consume = [&](int k, const BeamRot& r, float fx, float fy) {
@@ -867,37 +1037,31 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
         b.hi = f2{tq[k].z, tq[k].w};
         beam_finish(b, r, acc);
       };
-      // Software pipeline over chunks of kCachePipeChunk beams: the texel gathers of chunk c+1 are ISSUED before chunk c
-      // is consumed, so a gather has the arithmetic of a whole chunk (and the other waves' share of the SIMD) to land
-      // in.  The gathers write the beams' own cache registers, so the only extra state in flight is the second
-      // chunk's (rot, fx, fy).  Same arithmetic in the same beam order: identical bits.  (Worth 2 % on the headline
-      // workload and nothing on the pyramid ones: what the gathers cost is line-request THROUGHPUT of the L1/L2 path
-      // in the first two steps of a level, where most lanes change cell -- not latency.)
+      // Software pipeline: the texel gather of beam k+1 is ISSUED before beam k is consumed, so a gather has the
+      // arithmetic of a whole beam (and the other waves' share of the SIMD) to land in.  The gathers write the beams'
+      // own cache registers, so the only extra state in flight is the next beam's (rot, fx, fy); the endpoint of beam
+      // k+2 is read from LDS before beam k+1 is located (HSM_LDS_AHEAD), so the LDS latency is off the chain too.
+      // Same arithmetic in the same beam order: identical bits.
       {
-        constexpr int CH = kCachePipeChunk;
-        BeamRot rc[CH], rn[CH];
-        float fxc[CH], fyc[CH], fxn[CH], fyn[CH];
+        BeamRot rc, rn;
+        float fxc, fyc, fxn = 0.0f, fyn = 0.0f;
+        f2 p_next = mine[BPL > 1 ? 1 : 0][lane];
+        unsigned long long next_moved = 0ull;
+        locate(0, mine[0][lane], rc, fxc, fyc);
 #pragma unroll
-        for (int u = 0; u < CH; ++u)
-          if (u < BPL) locate(u, mine[u][lane], rc[u], fxc[u], fyc[u]);
-#pragma unroll
-        for (int k0 = 0; k0 < BPL; k0 += CH) {
-#pragma unroll
-          for (int u = 0; u < CH; ++u)
-            if (k0 + CH + u < BPL) locate(k0 + CH + u, mine[k0 + CH + u][lane], rn[u], fxn[u], fyn[u]);
-#pragma unroll
-          for (int u = 0; u < CH; ++u)
-            if (k0 + u < BPL) consume(k0 + u, rc[u], fxc[u], fyc[u]);
+        for (int k = 0; k < BPL; ++k) {
+          const f2 p_cur = p_next;
+          if (HSM_LDS_AHEAD && k + 2 < BPL) p_next = mine[k + 2][lane];
+          if (k + 1 < BPL) next_moved = locate(k + 1, HSM_LDS_AHEAD ? p_cur : mine[k + 1][lane], rn, fxn, fyn);
+          texel_ready(k, next_moved, k + 1 < BPL);
+          consume(k, rc, fxc, fyc);
           asm volatile(""
                        : "+v"(acc.d01), "+v"(acc.d2), "+v"(acc.hd), "+v"(acc.h22), "+v"(acc.h01), "+v"(acc.hr)
                        :
                        : "memory");
-#pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            rc[u] = rn[u];
-            fxc[u] = fxn[u];
-            fyc[u] = fyn[u];
-          }
+          rc = rn;
+          fxc = fxn;
+          fyc = fyn;
         }
       }
       // a scan longer than the 64 * BPL cached beams (BPL comes from a host-side length HINT): the rest streams
@@ -1025,7 +1189,7 @@ __global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batc
       } else {
         float sinRot, cosRot;
         sincos_f32(eth, sinRot, cosRot);
-        const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+        const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
         // two-deep software pipeline: the endpoint of round r + 2 and the texel of round r + 1 are in flight while
         // the products of round r are computed, so the barrier of a round does not wait for a memory round trip
         const float2 pad = make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products
@@ -1135,7 +1299,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
-      const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
       for (int i = g0; i < n; i += stride) {
         const float2 p = pts[i];
         BeamRot r;
@@ -1223,7 +1387,7 @@ __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const 
   acc.zero();
   const LevelRegs R = level_regs<LAYOUT>(L);
   if (EXACT) {
-    const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+    const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
     float run = 0.0f;
     for (int base = 0; base < n; base += 1024) {
       const int i = base + (int)threadIdx.x;
@@ -1317,7 +1481,7 @@ __global__ void __launch_bounds__(256) likelihood_kernel(const LevelView L, cons
   float sinRot, cosRot;
   sincos_f32(states[3 * b + 2], sinRot, cosRot);
   const LevelRegs R = level_regs<LAYOUT>(L);
-  const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+  const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
   float residual = 0.0f;
   if (EXACT) {
     float* row = rows[(threadIdx.x >> 6) & 3];
@@ -1377,7 +1541,7 @@ __global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L,
     float sinRot, cosRot;
     sincos_f32(ea, sinRot, cosRot);
     const LevelRegs R = level_regs<LAYOUT>(L);
-    const f2 e2 = f2{ex, ey}, cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+    const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
     float residual = 0.0f;
     if (EXACT) {
       for (int base = 0; base < n; base += 64) {
