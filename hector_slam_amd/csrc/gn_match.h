@@ -39,6 +39,7 @@
 // in beam order, i = 0 .. n-1, exactly the reference's fp32 chains.  sinf/cosf/expf are
 // glibc's algorithms operation for operation (libm_exact.h): identical bits.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
 
@@ -878,6 +879,52 @@ constexpr int kCachePipeChunk = HSM_CACHE_PIPE_CHUNK;
 #define HSM_ZERO_VGPR 1
 #endif
 
+#ifndef HSM_PEEL_FIRST   // first GN step takes the endpoints from their load registers (see the kernel)
+#define HSM_PEEL_FIRST 1
+#endif
+#ifndef HSM_EP_AHEAD     // endpoint loads in flight ahead of the beam being located in the peeled step
+#define HSM_EP_AHEAD 4
+#endif
+
+// Issue order of the loads of the peeled first step: endpoints E_0 .. E_d up front, the gather G_0, then per beam j
+// the endpoint E_{j+1+d} and the gather G_{j+1}.  pos*[k] = index in that order; total = number of loads.
+struct PeelSchedule {
+  int posE[32], posG[32], total;
+};
+constexpr PeelSchedule peel_schedule(int bpl, int d) {
+  PeelSchedule s{};
+  int c = 0;
+  for (int k = 0; k <= d && k < bpl; ++k) s.posE[k] = c++;
+  s.posG[0] = c++;
+  for (int j = 0; j < bpl; ++j) {
+    if (j + 1 + d < bpl) s.posE[j + 1 + d] = c++;
+    if (j + 1 < bpl) s.posG[j + 1] = c++;
+  }
+  s.total = c;
+  return s;
+}
+
+// s_waitcnt vmcnt(n) for the inline-asm loads, ordered before every later use of `x` (the register the awaited load
+// writes).  n is a compile-time constant after unrolling; anything above the cases waits for everything.
+template <class T>
+__device__ __forceinline__ void wait_vmcnt(int n, T& x) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(x) : : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(x) : : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(x) : : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(x) : : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(x) : : "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(x) : : "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" : "+v"(x) : : "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(x) : : "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" : "+v"(x) : : "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(x) : : "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" : "+v"(x) : : "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" : "+v"(x) : : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x) : : "memory"); break;
+  }
+}
+
 // a wave-uniform value moved to an SGPR
 __device__ __forceinline__ float uniform_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -896,6 +943,9 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   const int wave = threadIdx.x >> 6;
   // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
   const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + wave);
+#if defined(HSM_EXP_TIMESTAMPS)
+  const unsigned long long ts_entry = wall_clock64();
+#endif
   if (scan >= P.batch) return;
   int beg = 0, n = P.shared_n;
   if (P.offsets) {
@@ -913,11 +963,27 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   }
   const float2* __restrict__ pts = P.pts + beg;
   f2(*mine)[64] = lds_pts[wave];
+  // Endpoint staging.  Every wave of a launch starts at the same time and needs its 8.6 KB of endpoints first: 35 MB for
+  // 4096 scans, 6.5 us during which no wave has anything to compute if all endpoints are staged before the first GN
+  // step (measured per wave with HSM_EXP_TIMESTAMPS, profiles/r02/README.md).  So the FIRST GN step of the first level
+  // is peeled (kPeel): its beam k takes its endpoint straight from the register of a load issued kEpAhead beams
+  // earlier and writes it to LDS for the later steps, so the arithmetic and the texel gathers of step one run while
+  // the endpoints are still streaming in.  All loads of that step -- endpoints and (unmasked: every lane gathers in a
+  // level's first step) texels -- are inline asm with counted waits: loads return in order, and peel_schedule() gives
+  // the position of every load in the wave's issue order, hence how many younger loads may still be in flight when a
+  // given one is needed.  Out-of-range lanes read the scan's last endpoint (exec stays full, so every load is issued
+  // and the counts are static) and are replaced by the padding value.
+  constexpr bool kPeel = LAYOUT == kLayoutQuad && HSM_ASM_GATHER && HSM_PEEL_FIRST;
+  constexpr int kEpAhead = HSM_EP_AHEAD < BPL ? HSM_EP_AHEAD : BPL - 1;
+  constexpr PeelSchedule kSched = peel_schedule(BPL, kEpAhead);
+  const bool peel = kPeel && P.lv[P.first_level].gn_steps > 0;  // wave-uniform
+  if (!peel) {
 #pragma unroll
-  for (int k = 0; k < BPL; ++k) {
-    const int i = lane + k * 64;
-    const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: see gn_match_kernel
-    mine[k][lane] = f2{q.x, q.y};
+    for (int k = 0; k < BPL; ++k) {
+      const int i = lane + k * 64;
+      const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: see gn_match_kernel
+      mine[k][lane] = f2{q.x, q.y};
+    }
   }
 #if defined(HSM_EXP_TIMESTAMPS)  // experiment (tools/exp_wave_timeline.py): per-wave start / end stamps of the 100 MHz clock
   const unsigned long long ts_begin = wall_clock64();
@@ -937,9 +1003,10 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
     const LevelRegs R = level_regs<LAYOUT>(L);
     const float ratio = ps / reg_scale;  // powers of two: exact (see gn_match_kernel)
     reg_scale = ps;
+    const bool peel_here = peel && l == P.first_level;  // the peeled step stages the endpoints, scaled for this level
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
-      if (ratio != 1.0f) mine[k][lane] *= f2{ratio, ratio};
+      if (!peel_here && ratio != 1.0f) mine[k][lane] *= f2{ratio, ratio};
       toff[k] = 0xffffffffu;  // never a texel offset (not a multiple of 16): every beam gathers in the first step
     }
     // byte offset of the all-zero texel, pinned in a VGPR (as an SGPR it costs a v_mov per beam in front of the select)
@@ -947,7 +1014,22 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 #if HSM_ZERO_VGPR
     asm volatile("" : "+v"(zero_off));
 #endif
-    for (int it = 0; it < gn_steps; ++it) {
+    // one GN step; FIRST = the peeled step (compile-time)
+    auto gn_step = [&](auto FIRST, int it) {
+      constexpr bool kFirst = decltype(FIRST)::value;
+      // peeled step: the endpoint registers live only here.  The byte offset is made opaque so that its computation
+      // stays at the load (hoisted out of the level loop, 17 offsets would sit in VGPRs for the whole kernel).
+      f2 pq[kFirst ? BPL : 1];
+      auto endpoint_issue = [&](int k) {
+        int i = min((int)lane_id_now() + 64 * k, n - 1);
+        asm volatile("" : "+v"(i));
+        const unsigned byte_off = (unsigned)i << 3;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pq[kFirst ? k : 0]) : "v"(byte_off), "s"(pts) : "memory");
+      };
+      if (kFirst) {
+#pragma unroll
+        for (int k = 0; k <= kEpAhead; ++k) endpoint_issue(k);
+      }
       rotate_wave_priority(it + l);
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
@@ -971,6 +1053,11 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 #else
         const unsigned off = q.oob ? zero_off : idx << (LAYOUT == kLayoutQuad ? 4 : 2);
 #endif
+        if (kFirst) {  // a level's first step: every lane gathers (toff[] holds no offset yet)
+          asm volatile("global_load_dwordx4 %[t], %[o], %[b]" : [t] "=v"(tq[k]) : [o] "v"(off), [b] "s"(R.quad) : "memory");
+          toff[k] = off;
+          return ~0ull;
+        }
         if (LAYOUT == kLayoutQuad && HSM_ASM_GATHER) {
           // The masked gather as ONE instruction sequence under the wave's own control.  The compiler's form of
           // `if (off != toff[k]) load` waits with vmcnt(0) before the PREVIOUS beam is consumed -- it cannot count
@@ -1013,7 +1100,9 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       // been issued after beam k's (wave-uniform): loads return in order, so with it in flight vmcnt(1) is enough.
       auto texel_ready = [&](int k, unsigned long long next_moved, bool has_next) {
         if (!(LAYOUT == kLayoutQuad && HSM_ASM_GATHER)) return;
-        if (has_next) {
+        if (kFirst) {  // static schedule: everything issued after beam k's gather may still be in flight
+          wait_vmcnt((has_next ? kSched.posG[k + 1] + 1 : kSched.total) - kSched.posG[k] - 1, tq[k]);
+        } else if (has_next) {
           asm volatile(
               "s_cmp_eq_u64 %[m], 0\n\t"
               "s_cbranch_scc1 1f\n\t"
@@ -1028,6 +1117,14 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
         } else {
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(tq[k]) : : "memory");
         }
+      };
+      // peeled step: endpoint k from its load register (padding lanes replaced), scaled for this level, into LDS
+      auto endpoint_take = [&](int k) -> f2 {
+        wait_vmcnt(kSched.posG[k] - kSched.posE[k] - 1, pq[k]);  // beam k's gather is the next load in issue order
+        const bool pad = (int)lane_id_now() + 64 * k >= n;
+        const f2 p = f2{(pad ? 1.0e30f : pq[k].x) * ps, (pad ? 1.0e30f : pq[k].y) * ps};
+        mine[k][lane] = p;
+        return p;
       };
       auto consume = [&](int k, const BeamRot& r, float fx, float fy) {
         BeamSample b;
@@ -1045,14 +1142,24 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       {
         BeamRot rc, rn;
         float fxc, fyc, fxn = 0.0f, fyn = 0.0f;
-        f2 p_next = mine[BPL > 1 ? 1 : 0][lane];
+        f2 p_next = f2{0.0f, 0.0f};
         unsigned long long next_moved = 0ull;
-        locate(0, mine[0][lane], rc, fxc, fyc);
+        if (kFirst) {
+          locate(0, endpoint_take(0), rc, fxc, fyc);
+        } else {
+          p_next = mine[BPL > 1 ? 1 : 0][lane];
+          locate(0, mine[0][lane], rc, fxc, fyc);
+        }
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-          const f2 p_cur = p_next;
-          if (HSM_LDS_AHEAD && k + 2 < BPL) p_next = mine[k + 2][lane];
-          if (k + 1 < BPL) next_moved = locate(k + 1, HSM_LDS_AHEAD ? p_cur : mine[k + 1][lane], rn, fxn, fyn);
+          if (kFirst) {
+            if (k + 1 + kEpAhead < BPL) endpoint_issue(k + 1 + kEpAhead);
+            if (k + 1 < BPL) next_moved = locate(k + 1, endpoint_take(k + 1), rn, fxn, fyn);
+          } else {
+            const f2 p_cur = p_next;
+            if (HSM_LDS_AHEAD && k + 2 < BPL) p_next = mine[k + 2][lane];
+            if (k + 1 < BPL) next_moved = locate(k + 1, HSM_LDS_AHEAD ? p_cur : mine[k + 1][lane], rn, fxn, fyn);
+          }
           texel_ready(k, next_moved, k + 1 < BPL);
           consume(k, rc, fxc, fyc);
           asm volatile(""
@@ -1076,7 +1183,13 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 #endif
       wave_allreduce9(acc);
       gn_solve_and_step(acc, ex, ey, eth);
+    };
+    int it = 0;
+    if (kPeel && peel_here) {
+      gn_step(std::true_type{}, 0);
+      it = 1;
     }
+    for (; it < gn_steps; ++it) gn_step(std::false_type{}, it);
     eth = normalize_angle(eth);
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw2 = eth;
@@ -1094,7 +1207,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       unsigned* u = reinterpret_cast<unsigned*>(c);
       u[0] = (unsigned)ts_begin; u[1] = (unsigned)(ts_begin >> 32); u[2] = (unsigned)ts_end; u[3] = (unsigned)(ts_end >> 32);
-      u[4] = hwid; u[5] = xcc; u[6] = blockIdx.x; u[7] = 0; u[8] = 0;
+      u[4] = hwid; u[5] = xcc; u[6] = blockIdx.x; u[7] = (unsigned)(ts_begin - ts_entry); u[8] = 0;
 #else
       c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;

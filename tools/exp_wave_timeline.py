@@ -27,6 +27,12 @@ def main():
     for rep in range(4):
         m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
         torch.cuda.synchronize()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a_.record()
+    m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
+    b_.record()
+    torch.cuda.synchronize()
+    print(f"event time of one launch: {a_.elapsed_time(b_) * 1e3:.1f} us")
     u = cov.cpu().numpy().view(np.uint32)
     t0 = u[:, 0].astype(np.uint64) | (u[:, 1].astype(np.uint64) << np.uint64(32))
     t1 = u[:, 2].astype(np.uint64) | (u[:, 3].astype(np.uint64) << np.uint64(32))
@@ -34,6 +40,11 @@ def main():
     b = (t0 - base).astype(np.float64) / 100.0  # 100 MHz -> us
     e = (t1 - base).astype(np.float64) / 100.0
     hwid, xcc, blk = u[:, 4], u[:, 5] & 0xF, u[:, 6]
+    stage = u[:, 7].astype(np.float64) / 100.0  # kernel entry -> endpoints staged in LDS
+    entry = b - stage
+    print(f"endpoint staging (entry -> LDS resident): min/median/p90/max {stage.min():.2f}/{np.median(stage):.2f}/"
+          f"{np.percentile(stage, 90):.2f}/{stage.max():.2f} us; first entry {entry.min():.2f} us, last entry {entry.max():.2f} us "
+          f"(relative to the first staged wave)")
     cu = (hwid >> 8) & 0xF
     se = (hwid >> 13) & 0x7
     print(f"waves {B}: start min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f} us; end min/median/p90/max "
@@ -48,6 +59,18 @@ def main():
     f = np.array(list(fin.values()))
     print(f"  per-CU finish: {len(f)} CUs, min {f.min():.1f} median {np.median(f):.1f} p90 {np.percentile(f, 90):.1f} max {f.max():.1f} us; "
           f"mean idle before the launch ends {np.mean(f.max() - f):.1f} us")
+    # per SIMD: the four co-resident waves' finish times in order (HW_ID: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13)
+    simd = (hwid >> 4) & 0x3
+    skey = key * 10 + simd.astype(np.int64)
+    order = []
+    for k in np.unique(skey):
+        ee = np.sort(e[skey == k])
+        if len(ee) == 4:
+            order.append(ee)
+    if order:
+        o = np.array(order)
+        print(f"  per-SIMD finish order ({len(o)} SIMDs with 4 waves): mean 1st..4th {o.mean(0).round(1).tolist()} us; "
+              f"SIMD busy-slot fraction {float((o.sum(1) / (4 * e.max())).mean()):.3f}")
     hist, edges = np.histogram(e, bins=12)
     print("  end-time histogram:", [(round(edges[i], 1), int(hist[i])) for i in range(len(hist))])
 
