@@ -879,6 +879,9 @@ constexpr int kCachePipeChunk = HSM_CACHE_PIPE_CHUNK;
 #define HSM_ZERO_VGPR 1
 #endif
 
+#ifndef HSM_GATHER_ALWAYS  // 1: every beam issues its (masked) gather with lane 0 enabled -- static load counts, no branches; measured neutral (49.5 / 95.7 / 133 us either way), off
+#define HSM_GATHER_ALWAYS 0
+#endif
 #ifndef HSM_PEEL_FIRST   // first GN step takes the endpoints from their load registers (see the kernel)
 #define HSM_PEEL_FIRST 1
 #endif
@@ -1067,6 +1070,21 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
           // compiler sees straight-line code and keeps tq[k] where it is (it does not know about the asynchronous
           // write; texel_ready(k) is ordered before every read of tq[k] through its "+v" operand).
           unsigned long long moved, saved;
+#if HSM_GATHER_ALWAYS
+          // lane 0 always re-reads its texel (same value: the map does not change under the kernel), so every beam
+          // issues exactly ONE load and the waits are static -- no branch around the load, none around the wait
+          asm volatile(
+              "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
+              "s_or_b32 vcc_lo, vcc_lo, 1\n\t"
+              "s_and_saveexec_b64 %[sv], vcc\n\t"
+              "global_load_dwordx4 %[t], %[o], %[b]\n\t"
+              "v_mov_b32 %[to], %[o]\n\t"
+              "s_mov_b64 exec, %[sv]"
+              : [t] "+v"(tq[k]), [to] "+v"(toff[k]), [sv] "=&s"(saved)
+              : [o] "v"(off), [b] "s"(R.quad)
+              : "vcc", "scc", "memory");
+          moved = ~0ull;
+#else
           asm volatile(
               "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
               "s_mov_b64 %[mv], vcc\n\t"
@@ -1078,7 +1096,8 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
               "s_mov_b64 exec, %[sv]"
               : [t] "+v"(tq[k]), [to] "+v"(toff[k]), [sv] "=&s"(saved), [mv] "=&s"(moved)
               : [o] "v"(off), [b] "s"(R.quad)
-              : "vcc", "memory");
+              : "vcc", "scc", "memory");
+#endif
           return moved;
         }
         if (off != toff[k]) {
@@ -1102,6 +1121,8 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
         if (!(LAYOUT == kLayoutQuad && HSM_ASM_GATHER)) return;
         if (kFirst) {  // static schedule: everything issued after beam k's gather may still be in flight
           wait_vmcnt((has_next ? kSched.posG[k + 1] + 1 : kSched.total) - kSched.posG[k] - 1, tq[k]);
+        } else if (has_next && HSM_GATHER_ALWAYS) {
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(tq[k]) : : "memory");
         } else if (has_next) {
           asm volatile(
               "s_cmp_eq_u64 %[m], 0\n\t"
