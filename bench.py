@@ -589,7 +589,7 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
     rf = {"kernel": kernel_name, "kernel_ms": kern_ms,
           "bound": "valu", "unit": "G wave64 VALU instr/s", "achieved": None, "peak": 1024 * clock_hz / 2 / 1e9,
           "frac": None, "traffic": None,
-          "what_binds": "VALU instruction issue: 65 unfusable fp32/int instructions per beam and GN iteration (bit-exact "
+          "what_binds": "VALU instruction issue: 61 unfusable fp32/int instructions per beam and GN iteration (bit-exact "
                         "formulation, no FMA), texels and endpoints served from L2 / LDS / VGPRs; not HBM, not MFMA",
           "clock_hz": clock_hz,
           "flops": {"algorithmic_fp32_per_launch": flops, "achieved_tflops": flops / t / 1e12,
