@@ -1250,17 +1250,23 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 // round count is the workgroup's longest scan (shorter scans pad with +-0 products, which leave a sum unchanged).
 // Summation order per scan: beam 0 .. n-1, one fp32 chain per term -- the reference's (OccGridMapUtil.h:76-98), so the
 // results are bit-identical to gn_match_kernel<..., EXACT> and to the reference.
-constexpr int kExactScans = 7;  // producers per workgroup; 7 x 9 = 63 chain lanes in the consumer wavefront
+// Workgroup shape <NPROD producers, NCONS consumers>: a consumer wavefront runs the chains of NPROD / NCONS <= 7 scans.
+// <7, 1> fills the consumer (63 chain lanes); <8, 2> makes a 4096-scan batch 512 workgroups = exactly two per CU --
+// with <7, 1> it is 586 workgroups, 74 of the 256 CUs get three of them and the launch lasts as long as those.
+constexpr int kExactScans = 7;  // <7, 1>: producers per workgroup; 7 x 9 = 63 chain lanes in the consumer wavefront
 
-template <int LAYOUT>
-__global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batch_kernel(const MatchParams P) {
+template <int LAYOUT, int NPROD = kExactScans, int NCONS = 1>
+__global__ void __launch_bounds__(64 * (NPROD + NCONS), 8) gn_match_exact_batch_kernel(const MatchParams P) {
+  constexpr int kExactScans = NPROD;  // shadows the namespace constant: scans (= producer wavefronts) per workgroup
+  constexpr int SPC = NPROD / NCONS;  // scans per consumer wavefront
+  static_assert(NPROD % NCONS == 0 && SPC <= 7, "a consumer wavefront has 64 lanes for 9 chains per scan");
   constexpr int ROW = 64 + kExactPad;
   __shared__ float stage[2][kExactScans][9][ROW];
   __shared__ float tot[kExactScans][9];
   __shared__ int nmax_s;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const bool consumer = wave == kExactScans;
+  const bool consumer = wave >= kExactScans;
   const int scan = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kExactScans + wave);
   const bool active = !consumer && scan < P.batch;
   int beg = 0, n = 0;
@@ -1303,10 +1309,11 @@ __global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batc
     for (int it = 0; it < gn_steps; ++it) {
       if (consumer) {
         float run = 0.0f;
-        const int j = lane / 9, t = lane - 9 * j;  // lane 63: j = 7, idle
+        const int jl = lane / 9, t = lane - 9 * jl;  // lanes >= 9 * SPC idle
+        const int j = (wave - kExactScans) * SPC + (jl < SPC ? jl : 0);
         for (int r = 0; r < rounds; ++r) {
           __syncthreads();  // the producers' products of round r are in stage[r & 1]
-          if (lane < 9 * kExactScans) {
+          if (lane < 9 * SPC) {
             const float* row = &stage[r & 1][j][t][0];
 #pragma unroll 4
             for (int q = 0; q < 64; q += 4) {
@@ -1318,7 +1325,7 @@ __global__ void __launch_bounds__(64 * (kExactScans + 1), 8) gn_match_exact_batc
             }
           }
         }
-        if (lane < 9 * kExactScans) tot[j][t] = run;
+        if (lane < 9 * SPC) tot[j][t] = run;
         __syncthreads();  // totals published
       } else {
         float sinRot, cosRot;

@@ -160,6 +160,7 @@ struct hsm_ctx {
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
+  int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -340,11 +341,24 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
   // but 334 vs 317 us on the 4096^2 pyramid, whose gathers miss the L2 and want more wavefronts in flight per CU than
   // eight-wave workgroups with 34 KB of LDS leave -- so maps beyond 2^23 cells keep the one-wavefront-per-scan form.
   if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form && h->levels[0].cells() <= ((size_t)1 << 23)) {
-    const int grid = (P.batch + kExactScans - 1) / kExactScans, block = 64 * (kExactScans + 1);
-    if (h->layout == kLayoutPlane)
+    // workgroup shape: 7 producers + 1 consumer, or 8 + 2.  All workgroups of a launch are resident at once, so the
+    // launch lasts as long as the CU with the most producer wavefronts: pick the shape whose fullest of the 256 CUs
+    // carries fewer (4096 scans: 586 workgroups of 7 = three on 74 CUs = 21 producers, against 512 workgroups of 8 =
+    // two everywhere = 16).  env HSM_EXACT_SHAPE=7|8 pins it.
+    const auto worst_cu = [&](int per_wg) { return ((P.batch + per_wg - 1) / per_wg + 255) / 256 * per_wg; };
+    int per_wg = worst_cu(8) < worst_cu(kExactScans) ? 8 : kExactScans;
+    if (h->exact_shape == 7 || h->exact_shape == 8) per_wg = h->exact_shape;
+    const int grid = (P.batch + per_wg - 1) / per_wg, block = per_wg == 8 ? 64 * 10 : 64 * (kExactScans + 1);
+    if (per_wg == 8) {
+      if (h->layout == kLayoutPlane)
+        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
+      else
+        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
+    } else if (h->layout == kLayoutPlane) {
       hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
-    else
+    } else {
       hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+    }
     HIP_TRY(hipGetLastError());
     h->last_cfg[0] = h->layout;
     h->last_cfg[1] = 1;
@@ -661,6 +675,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \

@@ -121,16 +121,18 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
         assert same(pg, po) and same(cg, co), it
 
 
-@pytest.mark.parametrize("form", ["auto", "throughput", "throughput-plane", "one-wave-per-scan"])
+@pytest.mark.parametrize("form", ["auto", "throughput", "throughput-8+2", "throughput-plane", "one-wave-per-scan"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
     a small batch picks by itself ("auto"), the wave-specialised throughput form (seven producer wavefronts + one
-    chain wavefront per workgroup; 17 scans = 3 workgroups, the last one partial), and the one-wavefront-per-scan form"""
+    chain wavefront per workgroup; 17 scans = 3 workgroups, the last one partial -- or eight producers + two chain
+    wavefronts, the shape full-size batches pick), and the one-wavefront-per-scan form"""
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
     if form == "one-wave-per-scan":
         monkeypatch.setenv("HSM_EXACT_BATCH", "0")
+    monkeypatch.setenv("HSM_EXACT_SHAPE", "8" if form == "throughput-8+2" else "7")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
     if form == "throughput-plane":
         kw["layout"] = capi.LAYOUT_PLANE
@@ -150,7 +152,7 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     pts, offs = synth.pack_scans(scans)
     pb, cb = g.match_batch(init, pts, offs)
     if form.startswith("throughput"):
-        assert g.last_launch_config()["block"] == 512, g.last_launch_config()
+        assert g.last_launch_config()["block"] == (640 if form == "throughput-8+2" else 512), g.last_launch_config()
     for q, sq in enumerate(scans):
         po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
         assert same(pb[q], po), (q, sq.shape[0])
