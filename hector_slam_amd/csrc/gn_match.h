@@ -108,11 +108,30 @@ __device__ __forceinline__ void publish_done(const MatchParams& P) {
 // correct), and every XCD has its own 4 MiB L2.  A batch is usually spatially ordered (consecutive scans of a
 // trajectory, hypotheses around one pose), so handing each XCD a CONTIGUOUS eighth of the batch keeps the map
 // region its L2 has to hold eight times smaller than the round-robin default would.  Bijective for any grid.
+// (HSM_XCD_SWIZZLE: 0 = hardware order, 1 = one contiguous eighth per XCD, 2 = chunked cyclic, the default: headline
+// 50.5 -> 49.2 us, 3-level and 4096^2 pyramid unchanged against 1; profiles/r02/README.md)
 #ifndef HSM_XCD_SWIZZLE
-#define HSM_XCD_SWIZZLE 1
+#define HSM_XCD_SWIZZLE 2
+#endif
+#ifndef HSM_XCD_CHUNK
+#define HSM_XCD_CHUNK 16  // workgroups per chunk of the chunked-cyclic mapping (HSM_XCD_SWIZZLE == 2)
 #endif
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
-#if HSM_XCD_SWIZZLE
+#if HSM_XCD_SWIZZLE == 2
+  // chunked cyclic: XCD x takes chunks x, x + 8, x + 16, ... of HSM_XCD_CHUNK consecutive workgroups.  How long a scan
+  // takes depends on where it was taken (per-wave time stamps: 37.6 .. 44.1 us between sixteenths of the spatially
+  // ordered bench batch), so one contiguous eighth per XCD leaves whole XCDs with the slow stretches; chunks keep an
+  // XCD's L2 working set compact (a chunk is 64 consecutive scans) and give every XCD a sample of the whole batch.
+  constexpr int CH = HSM_XCD_CHUNK;
+  const int main_blocks = nblocks / (8 * CH) * (8 * CH);
+  if (b < main_blocks) {
+    const int xcd = b & 7, j = b >> 3;
+    return ((j / CH) * 8 + xcd) * CH + j % CH;
+  }
+  const int rb = b - main_blocks, rn = nblocks - main_blocks;
+  const int xcd = rb & 7, idx = rb >> 3, q = rn >> 3, r = rn & 7;
+  return main_blocks + xcd * q + (xcd < r ? xcd : r) + idx;
+#elif HSM_XCD_SWIZZLE
   const int xcd = b & 7, idx = b >> 3, q = nblocks >> 3, r = nblocks & 7;
   return xcd * q + (xcd < r ? xcd : r) + idx;
 #else

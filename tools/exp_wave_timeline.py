@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Per-wave start/end time stamps of ONE headline launch (library built with -DHSM_EXP_TIMESTAMPS: the kernel writes
-them over the covariance output): how do finish times spread over XCDs / CUs?  usage: HSM_LIB=... python tools/exp_wave_timeline.py"""
+"""Per-wave start/end time stamps of headline launches (library built with -DHSM_EXP_TIMESTAMPS: the kernel writes them
+over the covariance output): how do finish times spread over XCDs / CUs / SIMDs, how long does the endpoint staging
+take, and is a wave's lifetime a property of its scan (data) or of where it ran (hardware)?
+usage: HSM_LIB=.../libhector_mi355_ts.so python tools/exp_wave_timeline.py [--shuffle]"""
 import os
 import sys
 
@@ -10,41 +12,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
-def main():
-    import torch
-    from hector_slam_amd import capi
-    dev = torch.device("cuda", 0)
-    B = 4096
-    bp, bs, truth, init, init_pyr, pts, offs = bench.make_inputs(0, B)
-    m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, 1, device=0)
-    m.setUpdateFactorFree(0.4)
-    m.setUpdateFactorOccupied(0.9)
-    m.build_map(bp, bs)
-    d_init, d_pts, d_offs = (torch.from_numpy(a).to(dev) for a in (init, pts, offs))
-    pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
-    cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
-    s = torch.cuda.current_stream()
-    for rep in range(4):
-        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
-        torch.cuda.synchronize()
-    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a_.record()
-    m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
-    b_.record()
-    torch.cuda.synchronize()
-    print(f"event time of one launch: {a_.elapsed_time(b_) * 1e3:.1f} us")
-    u = cov.cpu().numpy().view(np.uint32)
+def cu_finish(key, e):
+    ks = np.unique(key)
+    return np.array([e[key == k].max() for k in ks]) if len(ks) == 256 else np.zeros(256)
+
+
+def analyse(u, B, prev):
     t0 = u[:, 0].astype(np.uint64) | (u[:, 1].astype(np.uint64) << np.uint64(32))
     t1 = u[:, 2].astype(np.uint64) | (u[:, 3].astype(np.uint64) << np.uint64(32))
     base = t0.min()
     b = (t0 - base).astype(np.float64) / 100.0  # 100 MHz -> us
     e = (t1 - base).astype(np.float64) / 100.0
     hwid, xcc, blk = u[:, 4], u[:, 5] & 0xF, u[:, 6]
-    stage = u[:, 7].astype(np.float64) / 100.0  # kernel entry -> endpoints staged in LDS
+    stage = u[:, 7].astype(np.float64) / 100.0  # kernel entry -> endpoints staged (peeled form: -> first step begins)
     entry = b - stage
-    print(f"endpoint staging (entry -> LDS resident): min/median/p90/max {stage.min():.2f}/{np.median(stage):.2f}/"
+    print(f"kernel entry -> first GN step: min/median/p90/max {stage.min():.2f}/{np.median(stage):.2f}/"
           f"{np.percentile(stage, 90):.2f}/{stage.max():.2f} us; first entry {entry.min():.2f} us, last entry {entry.max():.2f} us "
-          f"(relative to the first staged wave)")
+          f"(relative to the first wave's first step)")
     cu = (hwid >> 8) & 0xF
     se = (hwid >> 13) & 0x7
     print(f"waves {B}: start min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f} us; end min/median/p90/max "
@@ -71,8 +55,52 @@ def main():
         o = np.array(order)
         print(f"  per-SIMD finish order ({len(o)} SIMDs with 4 waves): mean 1st..4th {o.mean(0).round(1).tolist()} us; "
               f"SIMD busy-slot fraction {float((o.sum(1) / (4 * e.max())).mean()):.3f}")
+    life = e - b
+    print("  lifetime by batch sixteenth (scan index):", [round(float(life[i * B // 16:(i + 1) * B // 16].mean()), 1) for i in range(16)])
+    print("  lifetime by XCC:", [round(float(life[xcc == x].mean()), 1) for x in range(8)])
+    if prev is not None:
+        p_life, p_key, p_e = prev
+        same_place = float((p_key == key).mean())
+        print(f"  two launches of the same batch: correlation of per-scan lifetime {float(np.corrcoef(life, p_life)[0, 1]):.3f}, "
+              f"of per-CU finish time {float(np.corrcoef(cu_finish(key, e), cu_finish(p_key, p_e))[0, 1]):.3f}; "
+              f"{same_place:.2f} of the scans ran on the same CU")
     hist, edges = np.histogram(e, bins=12)
-    print("  end-time histogram:", [(round(edges[i], 1), int(hist[i])) for i in range(len(hist))])
+    print("  end-time histogram:", [(round(float(edges[i]), 1), int(hist[i])) for i in range(len(hist))])
+    return life, key, e
+
+
+def main():
+    import torch
+    from hector_slam_amd import capi
+    dev = torch.device("cuda", 0)
+    B = 4096
+    bp, bs, truth, init, init_pyr, pts, offs = bench.make_inputs(0, B)
+    m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, 1, device=0)
+    m.setUpdateFactorFree(0.4)
+    m.setUpdateFactorOccupied(0.9)
+    m.build_map(bp, bs)
+    if "--shuffle" in sys.argv:  # the same scans in a random order: does the slow region move with the data?
+        order = np.random.default_rng(3).permutation(B)
+        scans = [pts[offs[i]:offs[i + 1]] for i in order]
+        pts = np.concatenate(scans)
+        offs = np.concatenate([[0], np.cumsum([len(s_) for s_ in scans])]).astype(offs.dtype)
+        init = init[order]
+    d_init, d_pts, d_offs = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (init, pts, offs))
+    pose = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+    cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream()
+    for rep in range(4):
+        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+    prev = None
+    for rep in range(2):
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        m.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS, pose.data_ptr(), cov.data_ptr(), s.cuda_stream)
+        b_.record()
+        torch.cuda.synchronize()
+        print(f"== launch {rep}: event time {a_.elapsed_time(b_) * 1e3:.1f} us")
+        prev = analyse(cov.cpu().numpy().view(np.uint32), B, prev)
 
 
 if __name__ == "__main__":
