@@ -881,13 +881,9 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
 // at 4 waves per SIMD (<= 128 VGPRs) the endpoints move from VGPRs to LDS: slot [wave][k][lane], written and
 // read by the same lane only, so no barrier is ever needed (SPB * BPL * 512 B per workgroup).  Same
 // arithmetic on the same texel values in the same order as gn_match_kernel: identical bits.
-// One wave per scan, quad layout, no trace.
-// beams per pipeline stage of the texel-cache form.  Measured on MI355X (profiles/r02/README.md): 1 -> 57.1 us on the
-// headline workload, 2 -> 58.3 (128 VGPRs), no pipeline with chunks of 3 (round 1) -> 58.4
-#ifndef HSM_CACHE_PIPE_CHUNK
-#define HSM_CACHE_PIPE_CHUNK 1
-#endif
-constexpr int kCachePipeChunk = HSM_CACHE_PIPE_CHUNK;
+// One wave per scan, no trace.  The gathers run ONE beam ahead of their use (measured, profiles/r02/README.md: one
+// ahead 57.1 us on the headline workload, two ahead 58.3 at 128 VGPRs, chunks of 3 without a pipeline 58.4).
+// Compile-time switches of the measured variants (each A/B in profiles/r02/README.md):
 #ifndef HSM_ASM_GATHER   // counted waits for the masked texel gathers (see locate())
 #define HSM_ASM_GATHER 1
 #endif
