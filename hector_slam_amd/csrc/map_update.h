@@ -301,6 +301,11 @@ __global__ void __launch_bounds__(256) update_mark_kernel(const UpdateBatch B, u
 // that is only safe when every reader of a word sits in the SAME wavefront (reads program-ordered before the
 // store), which holds when rows are a multiple of 64 cells: the pass then runs over the box widened to 64-cell
 // column boundaries (the extra cells carry no key of this scan).  Other map widths keep the plain form.
+// SCATTER_TEXELS (quad layout): the cell's new probability goes straight into the four texels it is a
+// corner of -- component 0 of texel (x,y), 1 of (x-1,y), 2 of (x,y-1), 3 of (x-1,y-1), with update_texels_kernel's
+// edge replication at the last column / row -- so the texel pass and its launch disappear.  Every texel component
+// has exactly one writer (the thread of its cell), untouched components keep their value: same bits as the rebuild.
+template <bool SCATTER_TEXELS>
 __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
   if (P.x1 < P.x0) return;  // this level has nothing to apply
@@ -344,7 +349,23 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
     }
     P.lv.logodds[c] = l;
     P.lv.update_index[c] = stamp;
-    P.lv.prob[c] = grid_probability(l);
+    const float p = grid_probability(l);
+    P.lv.prob[c] = p;
+    if (SCATTER_TEXELS) {
+      float* q = reinterpret_cast<float*>(P.lv.quad);
+      const int sx = P.lv.sx, sy = P.lv.sy;
+      const bool lastx = x == sx - 1, lasty = y == sy - 1;
+      auto put = [&](int tx, int ty, int comp) { q[4 * (size_t)quad_index(tx, ty, P.lv.tiles_x, sx) + comp] = p; };
+      put(x, y, 0);
+      if (x > 0) put(x - 1, y, 1);
+      if (lastx) put(x, y, 1);
+      if (y > 0) put(x, y - 1, 2);
+      if (lasty) put(x, y, 2);
+      if (x > 0 && y > 0) put(x - 1, y - 1, 3);
+      if (lastx && y > 0) put(x, y - 1, 3);
+      if (lasty && x > 0) put(x - 1, y, 3);
+      if (lastx && lasty) put(x, y, 3);
+    }
   }
 }
 
