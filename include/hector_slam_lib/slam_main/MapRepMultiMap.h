@@ -58,12 +58,13 @@ public:
     , debugInterface(debugInterfaceIn)
   {
     static_assert(sizeof(LogOddsCell) == 8, "mirror cells are {float logOddsVal; int updateIndex}");
-    // hector_mapping matches and updates ONE scan at a time: the plane layout (no texel plane to rebuild after
-    // every update, 16 B/cell less memory) gives the shorter match + update cycle there (69 vs 73 us for a
-    // 1081-beam scan); the environment variable HSM_LAYOUT=quad|plane still decides when it is set.
+    // the library's default layout (float4 texels: one gather per beam; the apply pass of the update writes them, so
+    // there is no separate texel pass any more): 41.0 us per HectorSlamProcessor::update against 43.3 us with the
+    // plane layout (1081-beam scans, 3 levels).  HSM_LAYOUT=plane in the environment selects the plane layout
+    // (16 B/cell less memory; the faster one for dense 16 k-beam scans, whose cost is the update).
     hsm_opts opts;
     opts.device = -1;
-    opts.layout = std::getenv("HSM_LAYOUT") ? HSM_LAYOUT_AUTO : HSM_LAYOUT_PLANE;
+    opts.layout = HSM_LAYOUT_AUTO;
     opts.waves_per_scan = 0;
     if (hsm_create(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords.x(), startCoords.y(), &opts, &ctx) != HSM_OK) {
       throw std::runtime_error(std::string("hector_mi355: ") + hsm_last_error());
