@@ -1270,8 +1270,13 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 // with <7, 1> it is 586 workgroups, 74 of the 256 CUs get three of them and the launch lasts as long as those.
 constexpr int kExactScans = 7;  // <7, 1>: producers per workgroup; 7 x 9 = 63 chain lanes in the consumer wavefront
 
+#ifndef HSM_EXACT_DEEP  // <8, 2> shape: two texel gathers in flight per producer (needs > 64 VGPRs: 5 waves per SIMD)
+#define HSM_EXACT_DEEP 1
+#endif
 template <int LAYOUT, int NPROD = kExactScans, int NCONS = 1>
-__global__ void __launch_bounds__(64 * (NPROD + NCONS), 8) gn_match_exact_batch_kernel(const MatchParams P) {
+__global__ void __launch_bounds__(64 * (NPROD + NCONS), (NPROD == 8 && HSM_EXACT_DEEP) ? 5 : 8)
+gn_match_exact_batch_kernel(const MatchParams P) {
+  constexpr bool kDeep = NPROD == 8 && HSM_EXACT_DEEP;
   constexpr int kExactScans = NPROD;  // shadows the namespace constant: scans (= producer wavefronts) per workgroup
   constexpr int SPC = NPROD / NCONS;  // scans per consumer wavefront
   static_assert(NPROD % NCONS == 0 && SPC <= 7, "a consumer wavefront has 64 lanes for 9 chains per scan");
@@ -1350,13 +1355,25 @@ __global__ void __launch_bounds__(64 * (NPROD + NCONS), 8) gn_match_exact_batch_
         // the products of round r are computed, so the barrier of a round does not wait for a memory round trip
         const float2 pad = make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products
         float2 p_next = lane < n ? pts[lane] : pad;
-        BeamRot rot_next;
-        BeamSample b_next = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next);
+        BeamRot rot_next, rot_next2;
+        BeamSample b_next = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next), b_next2 = b_next;
         p_next = 64 + lane < n ? pts[64 + lane] : pad;
+        if (kDeep) {  // three-deep: texels of rounds r + 1 and r + 2 and the endpoint of round r + 3 in flight
+          b_next2 = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next2);
+          p_next = 128 + lane < n ? pts[128 + lane] : pad;
+        }
         for (int r = 0; r < rounds; ++r) {
           const BeamSample b = b_next;
           const BeamRot rot = rot_next;
-          if (r + 1 < rounds) {
+          if (kDeep) {
+            b_next = b_next2;
+            rot_next = rot_next2;
+            if (r + 2 < rounds) {
+              b_next2 = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next2);
+              const int i3 = ((r + 3) << 6) + lane;
+              p_next = i3 < n ? pts[i3] : pad;
+            }
+          } else if (r + 1 < rounds) {
             b_next = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p_next.x * ps, p_next.y * ps}, rot_next);
             const int i2 = ((r + 2) << 6) + lane;
             p_next = i2 < n ? pts[i2] : pad;
