@@ -98,6 +98,8 @@ struct MatchParams {
   unsigned* done_flag;       // nullptr, or a host-visible word that receives done_seq (system-scope release)
   unsigned done_seq;         // after the single-scan results are written: the host polls it instead of
                              // waiting for the end-of-kernel signal
+  int xcd_chunk;             // workgroup -> scan mapping (xcd_block): 0 = one contiguous eighth of the batch per XCD,
+                             // c > 0 = chunks of c workgroups dealt to the XCDs in turn
 };
 
 __device__ __forceinline__ void publish_done(const MatchParams& P) {
@@ -106,36 +108,36 @@ __device__ __forceinline__ void publish_done(const MatchParams& P) {
 
 // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md; used for speed only -- any placement is
 // correct), and every XCD has its own 4 MiB L2.  A batch is usually spatially ordered (consecutive scans of a
-// trajectory, hypotheses around one pose), so handing each XCD a CONTIGUOUS eighth of the batch keeps the map
-// region its L2 has to hold eight times smaller than the round-robin default would.  Bijective for any grid.
-// (HSM_XCD_SWIZZLE: 0 = hardware order, 1 = one contiguous eighth per XCD, 2 = chunked cyclic, the default: headline
-// 50.5 -> 49.2 us, 3-level and 4096^2 pyramid unchanged against 1; profiles/r02/README.md)
+// trajectory, hypotheses around one pose).  Two mappings, chosen per launch by the host (MatchParams::xcd_chunk):
+//   contiguous (xcd_chunk == 0): each XCD takes one CONTIGUOUS eighth of the batch, so the map region its L2 has to hold
+//     is eight times smaller than with the hardware's round robin -- the mapping for maps whose touched region
+//     outgrows the L2s (4096^2 pyramid: 135 vs 138 us, exact form 308 vs 319 us);
+//   chunked cyclic (xcd_chunk == c): XCD x takes chunks x, x + 8, x + 16, ... of c consecutive workgroups.  How long a
+//     scan takes depends on where it was taken (per-wave time stamps: 37.6 .. 44.1 us between sixteenths of the bench
+//     batch), so contiguous eighths leave whole XCDs with the slow stretches; chunks keep an XCD's working set
+//     compact (16 workgroups = 64 consecutive scans) and give every XCD a sample of the whole batch (2048^2 headline:
+//     49.2 vs 50.5 us).
+// Bijective for any grid.  -DHSM_XCD_SWIZZLE=0 keeps the hardware order.
 #ifndef HSM_XCD_SWIZZLE
-#define HSM_XCD_SWIZZLE 2
+#define HSM_XCD_SWIZZLE 1
 #endif
-#ifndef HSM_XCD_CHUNK
-#define HSM_XCD_CHUNK 16  // workgroups per chunk of the chunked-cyclic mapping (HSM_XCD_SWIZZLE == 2)
-#endif
-__device__ __forceinline__ int xcd_block(int b, int nblocks) {
-#if HSM_XCD_SWIZZLE == 2
-  // chunked cyclic: XCD x takes chunks x, x + 8, x + 16, ... of HSM_XCD_CHUNK consecutive workgroups.  How long a scan
-  // takes depends on where it was taken (per-wave time stamps: 37.6 .. 44.1 us between sixteenths of the spatially
-  // ordered bench batch), so one contiguous eighth per XCD leaves whole XCDs with the slow stretches; chunks keep an
-  // XCD's L2 working set compact (a chunk is 64 consecutive scans) and give every XCD a sample of the whole batch.
-  constexpr int CH = HSM_XCD_CHUNK;
-  const int main_blocks = nblocks / (8 * CH) * (8 * CH);
-  if (b < main_blocks) {
-    const int xcd = b & 7, j = b >> 3;
-    return ((j / CH) * 8 + xcd) * CH + j % CH;
+__device__ __forceinline__ int xcd_block(int b, int nblocks, int chunk) {
+#if HSM_XCD_SWIZZLE
+  int base = 0;
+  if (chunk > 0) {
+    const int main_blocks = nblocks / (8 * chunk) * (8 * chunk);
+    if (b < main_blocks) {
+      const int xcd = b & 7, j = b >> 3;
+      return ((j / chunk) * 8 + xcd) * chunk + j % chunk;
+    }
+    base = main_blocks;  // the remainder of the grid: contiguous
   }
-  const int rb = b - main_blocks, rn = nblocks - main_blocks;
+  const int rb = b - base, rn = nblocks - base;
   const int xcd = rb & 7, idx = rb >> 3, q = rn >> 3, r = rn & 7;
-  return main_blocks + xcd * q + (xcd < r ? xcd : r) + idx;
-#elif HSM_XCD_SWIZZLE
-  const int xcd = b & 7, idx = b >> 3, q = nblocks >> 3, r = nblocks & 7;
-  return xcd * q + (xcd < r ? xcd : r) + idx;
+  return base + xcd * q + (xcd < r ? xcd : r) + idx;
 #else
   (void)nblocks;
+  (void)chunk;
   return b;
 #endif
 }
@@ -681,7 +683,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   const int wave = threadIdx.x >> 6;
   const int team = wave / WPS;
   const int wit = wave - team * WPS;
-  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + team);  // wave-uniform
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + team);  // wave-uniform
   if (scan >= P.batch) return;  // whole team exits together
 
   int beg = 0, n = P.shared_n;
@@ -960,7 +962,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
-  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x) * SPB + wave);
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave);
 #if defined(HSM_EXP_TIMESTAMPS)
   const unsigned long long ts_entry = wall_clock64();
 #endif

@@ -161,6 +161,7 @@ struct hsm_ctx {
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
+  int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
@@ -687,6 +688,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
+  if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
@@ -863,6 +865,9 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   P.shared_n = shared_n;
   P.out_pose = d_out_pose;
   P.out_cov = d_out_cov;
+  // workgroup -> XCD mapping (gn_match.h, xcd_block): chunks dealt to the XCDs in turn balance the data-dependent
+  // per-scan time; maps whose touched region outgrows the L2s keep one contiguous eighth of the batch per XCD
+  P.xcd_chunk = h->levels[0].cells() <= ((size_t)1 << 23) ? h->xcd_chunk : 0;
   // per-scan length is only known on the device for CSR input; shared_n doubles as the sizing HINT there
   // (callers pass the typical beams per scan, 0 = unknown).  It only picks the kernel form: every form handles
   // scans longer than the hint (the beams beyond the register/LDS-resident ones stream from memory).
