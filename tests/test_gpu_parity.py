@@ -938,6 +938,36 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
     assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
 
 
+def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, monkeypatch):
+    """xcd_block(): whichever mapping a launch uses -- chunks of 16 workgroups dealt to the XCDs (default), odd chunk
+    sizes, one contiguous eighth per XCD -- every scan is matched exactly once: a 1003-scan batch (251 workgroups: one
+    full round of 8 x 16 chunks + a ragged remainder) gives the same bits under all of them, and no row is left unwritten"""
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    rng = np.random.default_rng(77)
+    nq = len(sc.query_scans)
+    B = 1003
+    scans = [sc.query_scans[j % nq] for j in range(B)]
+    init = np.stack([sc.query_init[j % nq] + (rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]).astype(np.float32) for j in range(B)])
+    pts, offs = synth.pack_scans(scans)
+    results = []
+    for chunk in ("16", "0", "5", "64"):
+        monkeypatch.setenv("HSM_XCD_CHUNK", chunk)
+        m = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1, layout=capi.LAYOUT_QUAD)
+        for lvl in range(sc.levels):
+            m.upload_level(lvl, *o.download_level(lvl))
+        p, c = m.match_batch(init, pts, offs)
+        assert m.last_launch_config()["texel_cache"]
+        results.append((p, c))
+        m.close()
+    for p, c in results[1:]:
+        assert np.array_equal(bits(p), bits(results[0][0])) and np.array_equal(bits(c), bits(results[0][1]))
+    assert not np.any(np.all(results[0][0] == 0.0, axis=1))  # every scan was written
+    for j in (0, 511, 512, 1002):
+        assert_pose_close(results[0][0][j:j + 1], np.stack([o.match(init[j], scans[j])[0]]), f"scan {j} vs oracle")
+
+
 def test_queued_updates_are_ordered_against_caller_streams(capi, pyramid_scene, monkeypatch):
     """hsm_match_batch_device runs on a CALLER-owned stream while map updates are queued on the context's own:
     a batch match must see every update queued before it, and an update must not rewrite the map under a batch
