@@ -100,6 +100,7 @@ struct MatchParams {
                              // waiting for the end-of-kernel signal
   int xcd_chunk;             // workgroup -> scan mapping (xcd_block): 0 = one contiguous eighth of the batch per XCD,
                              // c > 0 = chunks of c workgroups dealt to the XCDs in turn
+  int wg_sync;               // texel-cache form: the waves of a workgroup meet at a barrier before every beam (L1 sharing)
 };
 
 __device__ __forceinline__ void publish_done(const MatchParams& P) {
@@ -1035,6 +1036,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
     asm volatile("" : "+v"(zero_off));
 #endif
     // one GN step; FIRST = the peeled step (compile-time)
+    const bool wg_sync = __builtin_amdgcn_readfirstlane(P.wg_sync) != 0;
     auto gn_step = [&](auto FIRST, int it) {
       constexpr bool kFirst = decltype(FIRST)::value;
       // peeled step: the endpoint registers live only here.  The byte offset is made opaque so that its computation
@@ -1198,6 +1200,11 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
             if (HSM_LDS_AHEAD && k + 2 < BPL) p_next = mine[k + 2][lane];
             if (k + 1 < BPL) next_moved = locate(k + 1, HSM_LDS_AHEAD ? p_cur : mine[k + 1][lane], rn, fxn, fyn);
           }
+          // large maps (MatchParams::wg_sync): the four waves of a workgroup -- consecutive scans, whose beam k ends in
+          // the same or neighbouring cells -- locate beam k together, so the texel lines one of them pulls in are still
+          // in the CU's L1 when the others ask (4096^2 pyramid: 137 -> 133 us; nothing on maps whose touched region the
+          // L2s hold).  Waves that have left the kernel (empty scan, batch tail) do not count at s_barrier.
+          if (wg_sync) asm volatile("s_barrier" ::: "memory");
           texel_ready(k, next_moved, k + 1 < BPL);
           consume(k, rc, fxc, fyc);
           asm volatile(""

@@ -162,6 +162,7 @@ struct hsm_ctx {
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
+  int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
@@ -688,6 +689,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
+  if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
   if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
 
 #define CREATE_TRY(expr)                                   \
@@ -868,6 +870,7 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   // workgroup -> XCD mapping (gn_match.h, xcd_block): chunks dealt to the XCDs in turn balance the data-dependent
   // per-scan time; maps whose touched region outgrows the L2s keep one contiguous eighth of the batch per XCD
   P.xcd_chunk = h->levels[0].cells() <= ((size_t)1 << 23) ? h->xcd_chunk : 0;
+  P.wg_sync = h->wg_sync >= 0 ? h->wg_sync : (h->levels[0].cells() > ((size_t)1 << 23) ? 1 : 0);
   // per-scan length is only known on the device for CSR input; shared_n doubles as the sizing HINT there
   // (callers pass the typical beams per scan, 0 = unknown).  It only picks the kernel form: every form handles
   // scans longer than the hint (the beams beyond the register/LDS-resident ones stream from memory).
