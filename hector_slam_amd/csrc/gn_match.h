@@ -1008,6 +1008,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   }
 #if defined(HSM_EXP_TIMESTAMPS)  // experiment (tools/exp_wave_timeline.py): per-wave start / end stamps of the 100 MHz clock
   const unsigned long long ts_begin = wall_clock64();
+  const unsigned long long sc_begin = __builtin_readcyclecounter();  // shader clock (s_memtime)
 #endif
   f4v tq[BPL];
   unsigned toff[BPL];
@@ -1247,12 +1248,13 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       float* c = P.out_cov + 9 * scan;
 #if defined(HSM_EXP_TIMESTAMPS)  // the stamps and the wave's placement overwrite the covariance
       const unsigned long long ts_end = wall_clock64();
+      const unsigned long long sc_end = __builtin_readcyclecounter();
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       unsigned* u = reinterpret_cast<unsigned*>(c);
       u[0] = (unsigned)ts_begin; u[1] = (unsigned)(ts_begin >> 32); u[2] = (unsigned)ts_end; u[3] = (unsigned)(ts_end >> 32);
-      u[4] = hwid; u[5] = xcc; u[6] = blockIdx.x; u[7] = (unsigned)(ts_begin - ts_entry); u[8] = 0;
+      u[4] = hwid; u[5] = xcc; u[6] = blockIdx.x; u[7] = (unsigned)(ts_begin - ts_entry); u[8] = (unsigned)(sc_end - sc_begin);
 #else
       c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;

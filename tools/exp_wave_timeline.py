@@ -29,6 +29,8 @@ def analyse(u, B, prev):
     print(f"kernel entry -> first GN step: min/median/p90/max {stage.min():.2f}/{np.median(stage):.2f}/"
           f"{np.percentile(stage, 90):.2f}/{stage.max():.2f} us; first entry {entry.min():.2f} us, last entry {entry.max():.2f} us "
           f"(relative to the first wave's first step)")
+    sclk = u[:, 8].astype(np.float64) / np.maximum(e - b, 1e-3)  # shader-clock cycles per us of the 100 MHz wall clock = MHz
+    print(f"shader clock over the waves' lifetimes (s_memtime / wall clock): min/median/max {sclk.min():.0f}/{np.median(sclk):.0f}/{sclk.max():.0f} MHz")
     cu = (hwid >> 8) & 0xF
     se = (hwid >> 13) & 0x7
     print(f"waves {B}: start min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f} us; end min/median/p90/max "
