@@ -579,7 +579,7 @@ def pmc_leg(kernel_name: str, steps: int = 20, warmup: int = 3):
     return (vals or None), ("; ".join(errors) or None)
 
 
-def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pmc, pmc_err, clock_hz):
+def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pmc, pmc_err, clock_hz, sclk_hz=None):
     """see the module docstring: VALU-issue utilisation + in-run HBM traffic + the labelled SURVEY 8(d) contract figure"""
     t = kern_ms * 1e-3
     # algorithmic fp32 operations: 51 per beam and GN iteration (25 mul + 26 add/sub, unfused by construction) +
@@ -633,6 +633,13 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
             rf["counter_source"] = "none" + (": " + pmc_err if pmc_err else "")
     elif pmc_err:
         rf["pmc_errors"] = pmc_err
+    if sclk_hz and 0.5e9 < sclk_hz < 3.5e9 and rf.get("achieved"):
+        # what the kernel actually got (DVFS): shader-clock ticks / 100 MHz wall-clock ticks over the lifetime of one wave of
+        # the last timed launch, read inside the kernel.  `frac` above stays priced at the nominal peak clock.
+        rf["clock_measured"] = {"sclk_hz": sclk_hz, "peak_at_measured_clock": 1024 * sclk_hz / 2 / 1e9,
+                                "frac_at_measured_clock": rf["achieved"] / (1024 * sclk_hz / 2 / 1e9),
+                                "source": "s_memtime vs the 100 MHz wall clock over the lifetime of the wave of scan 0 in the last "
+                                          "timed launch (hsm_set_clock_probe)"}
     return rf
 
 
@@ -729,6 +736,10 @@ def main():
             if gatherer:
                 gatherer.launch()
 
+        # clock probe (hsm_set_clock_probe): the wave of scan 0 stamps {shader-clock counter, 100 MHz wall clock} at its
+        # first GN step and at its end; read after the timed loop = the clock the LAST timed launch ran at
+        probe = torch.zeros(4, dtype=torch.int64, device=dev)
+        matcher.set_clock_probe(probe.data_ptr())
         for _ in range(warmup):
             step()
         if world > 1:
@@ -753,6 +764,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kern_ms = ev0.elapsed_time(ev1) / steps
+        st = probe.cpu().numpy().astype(np.uint64)
+        matcher.set_clock_probe(0)
+        run.sclk_hz = None
+        if st[1] and st[3] > st[1]:  # (only the quad-layout texel-cache form carries the probe)
+            run.sclk_hz = float(st[2] - st[0]) / float(st[3] - st[1]) * 100e6
         return dt, kern_ms, its
 
     def kernel_of(cfg):
@@ -825,6 +841,7 @@ def main():
     # ---------------- the headline ---------------------------------------------------------------------------------
     matcher = build_matcher(args.levels)
     dt, kern_ms, its = run(matcher, d_init_l0 if args.levels == 1 else d_init_pyr, args.steps, args.warmup)
+    headline_sclk = getattr(run, "sclk_hz", None)
     gpu_pose = d_pose.cpu().numpy()
     cfg = matcher.last_launch_config()
     value = total * its * args.steps / dt
@@ -851,7 +868,8 @@ def main():
                                   "the `pyramid` leg uses SURVEY.md 8(d)'s +-0.15 m / +-0.05 rad)",
                    "kernel": cfg},
         "matchdata_per_s": total * args.steps / dt,
-        "roofline": roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz),
+        "roofline": roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
+                                   sclk_hz=headline_sclk),
     }
     conv = np.abs(gpu_pose.astype(np.float64) - truth.astype(np.float64))
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),

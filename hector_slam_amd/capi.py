@@ -101,6 +101,7 @@ SIGNATURES = {
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_device_info": (_i, [_vp, _i32p]),
+    "hsm_set_clock_probe": (_i, [_vp, _vp]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
     "hsm_last_error": (C.c_char_p, []),
@@ -405,6 +406,10 @@ class MapRepMultiMap:
         a = np.empty(4, np.int32)
         _check(self._lib.hsm_device_info(self._h, a), "hsm_device_info")
         return {"device": int(a[0]), "compute_units": int(a[1]), "clock_khz": int(a[2]), "memory_clock_khz": int(a[3])}
+
+    def set_clock_probe(self, d_stamps4: int):
+        """device pointer (int) to four uint64 words, or 0: see hsm_set_clock_probe"""
+        _check(self._lib.hsm_set_clock_probe(self._h, d_stamps4 or None), "hsm_set_clock_probe")
 
     def gn_iterations_per_match(self) -> int:
         return self._lib.hsm_gn_iterations_per_match(self._h)

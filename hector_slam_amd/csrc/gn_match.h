@@ -101,6 +101,8 @@ struct MatchParams {
   int xcd_chunk;             // workgroup -> scan mapping (xcd_block): 0 = one contiguous eighth of the batch per XCD,
                              // c > 0 = chunks of c workgroups dealt to the XCDs in turn
   int wg_sync;               // texel-cache form: the waves of a workgroup meet at a barrier before every beam (L1 sharing)
+  unsigned long long* clock_probe;  // nullptr, or four words the wave of scan 0 fills: shader-clock counter (s_memtime)
+                                    // and 100 MHz wall clock at its first GN step [0,1] and at its end [2,3]
 };
 
 __device__ __forceinline__ void publish_done(const MatchParams& P) {
@@ -968,6 +970,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   const unsigned long long ts_entry = wall_clock64();
 #endif
   if (scan >= P.batch) return;
+
   int beg = 0, n = P.shared_n;
   if (P.offsets) {
     beg = P.offsets[scan];
@@ -1050,6 +1053,12 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pq[kFirst ? k : 0]) : "v"(byte_off), "s"(pts) : "memory");
       };
       if (kFirst) {
+        // clock probe, begin stamps (see the end of the kernel): here, at the top of the peeled step, no texel is live
+        // yet -- the same block at the kernel's entry made the register allocator spill
+        if (P.clock_probe != nullptr && scan == 0 && lane_id_now() == 0) {
+          P.clock_probe[0] = __builtin_readcyclecounter();
+          P.clock_probe[1] = wall_clock64();
+        }
 #pragma unroll
         for (int k = 0; k <= kEpAhead; ++k) endpoint_issue(k);
       }
@@ -1261,6 +1270,14 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
 #endif
     }
+  }
+  // clock probe (bench.py: what clock does the kernel actually get?): the wave of scan 0 stamps the shader-clock counter
+  // (s_memtime) and the 100 MHz wall clock at the top of its first GN step and here, as its last act; the ratio of the
+  // two differences is the clock it ran at.  (Stamps of different launches cannot be compared: the wave lands on
+  // different CUs, whose shader-clock counters are not aligned.)
+  if (P.clock_probe != nullptr && scan == 0 && lane_id_now() == 0) {
+    P.clock_probe[2] = __builtin_readcyclecounter();
+    P.clock_probe[3] = wall_clock64();
   }
 }
 

@@ -162,6 +162,7 @@ struct hsm_ctx {
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
+  unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
@@ -829,6 +830,13 @@ int hsm_set_parity(hsm_ctx* h, int mode) {
 }
 int hsm_parity(const hsm_ctx* h) { return (h && h->exact) ? HSM_PARITY_EXACT : HSM_PARITY_FAST; }
 
+int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->clock_probe = d_stamps4;
+  return HSM_OK;
+}
+
 int hsm_device_info(const hsm_ctx* h, int info[4]) {
   if (!h || !info) return fail(HSM_ERR_INVALID, "null argument");
   hipDeviceProp_t p;
@@ -871,6 +879,7 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   // per-scan time; maps whose touched region outgrows the L2s keep one contiguous eighth of the batch per XCD
   P.xcd_chunk = h->levels[0].cells() <= ((size_t)1 << 23) ? h->xcd_chunk : 0;
   P.wg_sync = h->wg_sync >= 0 ? h->wg_sync : (h->levels[0].cells() > ((size_t)1 << 23) ? 1 : 0);
+  P.clock_probe = h->clock_probe;
   // per-scan length is only known on the device for CSR input; shared_n doubles as the sizing HINT there
   // (callers pass the typical beams per scan, 0 = unknown).  It only picks the kernel form: every form handles
   // scans longer than the hint (the beams beyond the register/LDS-resident ones stream from memory).

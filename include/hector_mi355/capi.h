@@ -302,6 +302,13 @@ int hsm_debug_expf(hsm_ctx* h, int n, const float* x, float* out_exp, float* out
 
 /* the context's device: {HIP ordinal, compute units, shader clock kHz, memory clock kHz} (roofline arithmetic of bench.py) */
 int hsm_device_info(const hsm_ctx* h, int info[4]);
+
+/* Measurement aid (no reference counterpart): d_stamps4 = device pointer to four 64-bit words, or NULL to switch it
+ * off.  While set, every batched match (texel-cache form, quad layout) lets the wavefront of scan 0 store {shader-clock
+ * counter (s_memtime), 100 MHz wall clock} at the top of its first GN step [0,1] and as its last act [2,3]:
+ * (s[2]-s[0]) / (s[3]-s[1]) * 100 MHz = the clock the kernel actually ran at (bench.py prices the VALU roof at it next
+ * to the nominal 2.4 GHz).  The caller owns the memory. */
+int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4);
 /* GN steps one full hsm_match performs per scan (4 per coarse level + 6) */
 int hsm_gn_iterations_per_match(const hsm_ctx* h);
 /* effective kernel configuration of the last match launch:
