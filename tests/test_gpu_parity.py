@@ -968,6 +968,36 @@ def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, mon
         assert_pose_close(results[0][0][j:j + 1], np.stack([o.match(init[j], scans[j])[0]]), f"scan {j} vs oracle")
 
 
+def test_clock_probe_reports_a_plausible_shader_clock(capi, pyr, pyramid_scene):
+    """hsm_set_clock_probe: the wave of scan 0 stamps {s_memtime, 100 MHz wall clock} at its first GN step and at its end;
+    the probe changes no result and the ratio is a clock an MI355X can run at"""
+    import torch
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    nq = len(sc.query_scans)
+    B = 256
+    scans = [sc.query_scans[j % nq] for j in range(B)]
+    init = np.stack([sc.query_init[j % nq] for j in range(B)])
+    pts, offs = synth.pack_scans(scans)
+    m = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1, layout=capi.LAYOUT_QUAD)
+    for lvl in range(sc.levels):
+        m.upload_level(lvl, *o.download_level(lvl))
+    p0, c0 = m.match_batch(init, pts, offs)
+    assert m.last_launch_config()["texel_cache"]
+    stamps = torch.zeros(4, dtype=torch.int64, device="cuda")
+    m.set_clock_probe(stamps.data_ptr())
+    p1, c1 = m.match_batch(init, pts, offs)
+    torch.cuda.synchronize()
+    m.set_clock_probe(0)
+    st = stamps.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(bits(p0), bits(p1)) and np.array_equal(bits(c0), bits(c1))
+    assert st[3] > st[1] and st[2] > st[0], st
+    ghz = float(st[2] - st[0]) / float(st[3] - st[1]) * 0.1
+    assert 0.8 < ghz < 3.0, ghz
+    m.close()
+
+
 def test_queued_updates_are_ordered_against_caller_streams(capi, pyramid_scene, monkeypatch):
     """hsm_match_batch_device runs on a CALLER-owned stream while map updates are queued on the context's own:
     a batch match must see every update queued before it, and an update must not rewrite the map under a batch
