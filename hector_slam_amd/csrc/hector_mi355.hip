@@ -163,6 +163,7 @@ struct hsm_ctx {
   bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
   unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
+  int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
@@ -401,7 +402,16 @@ int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stre
 
 int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   switch (choose_wps(h, P.batch, max_n)) {
-    case 1: return launch_match_w<1, 4>(h, P, max_n, stream);
+    case 1: {
+      // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
+      // per-beam workgroup barrier (MatchParams::wg_sync) eight waves share the texel lines in the CU's L1 (4096^2
+      // pyramid: 132.8 -> 129.1 us; 16 per workgroup: 133 us; no effect on the 2048^2 workloads, which keep four)
+      const int per_lane = (max_n + 63) / 64;
+      if (h->spb_large == 8 && h->levels[0].cells() > ((size_t)1 << 23) && !h->exact && h->texel_cache && P.begin_world &&
+          !P.trace && h->bpl_override != 0 && per_lane > 5 && per_lane <= 17)
+        return per_lane <= 9 ? launch_match_t<1, 8, 9>(h, P, stream) : launch_match_t<1, 8, 17>(h, P, stream);
+      return launch_match_w<1, 4>(h, P, max_n, stream);
+    }
     case 2: return launch_match_w<2, 1>(h, P, max_n, stream);
     case 4: return launch_match_w<4, 1>(h, P, max_n, stream);
     case 8: return launch_match_w<8, 1>(h, P, max_n, stream);
@@ -691,6 +701,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
+  if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
   if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
 
 #define CREATE_TRY(expr)                                   \

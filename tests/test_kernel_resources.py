@@ -48,7 +48,8 @@ def test_texel_cache_matcher_fits_four_waves_per_simd(device_asm):
     assert ks
     for k, v in ks.items():
         assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)   # 512 VGPRs per SIMD lane / 4 waves
-        assert 4 * v["lds"] <= 160 * 1024, (k, v)               # four workgroups (16 waves) per CU
+        spb = int(re.search(r"gn_match_cached_kernelILi(\d+)E", k).group(1))   # scans (= waves) per workgroup
+        assert (16 // spb) * v["lds"] <= 160 * 1024, (k, v)     # 16 waves per CU: 16 / spb workgroups share its LDS
 
 
 def test_counted_waits_are_static_in_the_peeled_step(device_asm):
