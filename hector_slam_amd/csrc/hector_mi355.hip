@@ -160,7 +160,7 @@ struct hsm_ctx {
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
-  bool exact_batch_form = true;  // env HSM_EXACT_BATCH=0: the one-wavefront-per-scan exact form for batches, too
+  int exact_batch_form = 2;      // env HSM_EXACT_BATCH: 0 = the one-wavefront-per-scan exact form for batches, too; 1 = producer / chain workgroups on maps <= 2^23 cells only (the rule until the <8,2> shape); 2 = on every map
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
   unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
   int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
@@ -341,11 +341,12 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
 template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
-  // throughput launches: seven producer wavefronts + one consumer wavefront per workgroup (gn_match.h).  Measured
-  // (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch, 235 vs 275 us through its 3-level pyramid,
-  // but 334 vs 317 us on the 4096^2 pyramid, whose gathers miss the L2 and want more wavefronts in flight per CU than
-  // eight-wave workgroups with 34 KB of LDS leave -- so maps beyond 2^23 cells keep the one-wavefront-per-scan form.
-  if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form && h->levels[0].cells() <= ((size_t)1 << 23)) {
+  // throughput launches: producer wavefronts + chain wavefronts per workgroup (gn_match.h).  Measured
+  // (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2> and two
+  // gathers in flight; on the 4096^2 pyramid, whose gathers miss the L2, <7,1> lost to the one-wavefront-per-scan form
+  // (334 vs 317 us) but <8,2> wins there too (293 us), so every map takes it
+  if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form &&
+      (h->exact_batch_form == 2 || h->levels[0].cells() <= ((size_t)1 << 23))) {
     // workgroup shape: 7 producers + 1 consumer, or 8 + 2.  All workgroups of a launch are resident at once, so the
     // launch lasts as long as the CU with the most producer wavefronts: pick the shape whose fullest of the 256 CUs
     // carries fewer (4096 scans: 586 workgroups of 7 = three on 74 CUs = 21 producers, against 512 workgroups of 8 =
@@ -698,7 +699,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
-  if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
