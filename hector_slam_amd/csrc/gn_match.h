@@ -999,7 +999,9 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   // and the counts are static) and are replaced by the padding value.
   constexpr bool kPeel = LAYOUT == kLayoutQuad && HSM_ASM_GATHER && HSM_PEEL_FIRST;
   constexpr int kEpAhead = HSM_EP_AHEAD < BPL ? HSM_EP_AHEAD : BPL - 1;
+  static_assert(BPL <= 31, "PeelSchedule holds 32 positions per load kind");
   constexpr PeelSchedule kSched = peel_schedule(BPL, kEpAhead);
+  static_assert(kSched.total <= 2 * BPL, "one endpoint load and one gather per beam");
   const bool peel = kPeel && P.lv[P.first_level].gn_steps > 0;  // wave-uniform
   if (!peel) {
 #pragma unroll
