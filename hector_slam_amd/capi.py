@@ -129,6 +129,12 @@ def load_library(build_if_missing: bool = True):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = header/library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
+    # the node's two per-scan calls a second time with raw-address prototypes: numpy's ndpointer argument check costs
+    # ~2 us per array argument, which is a third of a 40 us call (lib["name"] creates a separate function object)
+    lib._hsm_match_raw = lib["hsm_match"]
+    lib._hsm_match_raw.restype, lib._hsm_match_raw.argtypes = _i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]
+    lib._hsm_update_raw = lib["hsm_update_by_scan"]
+    lib._hsm_update_raw.restype, lib._hsm_update_raw.argtypes = _i, [_vp, _vp, _vp, _i, _vp]
     _lib = lib
     return lib
 
@@ -138,16 +144,52 @@ def _check(rc: int, what: str):
         raise HsmError(f"{what} failed ({rc}): {load_library().hsm_last_error().decode()}")
 
 
+def _addr(a) -> int:
+    """address of a numpy array's first element (cheaper than a.ctypes.data)"""
+    return a.__array_interface__["data"][0]
+
+
+def _is_f32c(x) -> bool:
+    return type(x) is np.ndarray and x.dtype == np.float32 and x.flags.c_contiguous
+
+
 def _pts(pts):
-    a = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
-    return a, (a.ctypes.data if a.size else None), a.shape[0]
+    if _is_f32c(pts) and pts.ndim == 2 and pts.shape[1] == 2:
+        a = pts
+    else:
+        a = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    return a, (_addr(a) if a.size else None), a.shape[0]
 
 
 def _v(x, n):
-    a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    if _is_f32c(x) and x.ndim == 1:
+        a = x
+    else:
+        a = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
     if a.size != n:
         raise ValueError(f"expected {n} floats")
     return a
+
+
+def _fill(dst, x, n):
+    """dst[:] = the n floats of x (ValueError on any other size, as _v)"""
+    if type(x) is not np.ndarray:
+        x = np.asarray(x, dtype=np.float32)
+    if x.size != n:
+        raise ValueError(f"expected {n} floats")
+    dst[:] = x.reshape(-1)
+
+
+class _SmallArgs:
+    __slots__ = ("buf", "pose", "origo", "out", "cov", "a_pose", "a_origo", "a_out", "a_cov", "lock")
+
+    def __init__(self):
+        import threading
+        self.buf = np.zeros(3 + 2 + 3 + 9 + 3, np.float32)
+        self.pose, self.origo, self.out, self.cov = self.buf[0:3], self.buf[3:5], self.buf[5:8], self.buf[8:17]
+        base = _addr(self.buf)
+        self.a_pose, self.a_origo, self.a_out, self.a_cov = base, base + 12, base + 20, base + 32
+        self.lock = threading.Lock()
 
 
 _ZERO2 = np.zeros(2, np.float32)
@@ -166,6 +208,15 @@ class MapRepMultiMap:
                                     startCoords[1], C.byref(opts), C.byref(self._h)), "hsm_create")
         if parity is not None:
             self.set_parity(parity)
+
+    def _io(self):
+        """small-argument block of the two per-scan calls: one persistent float32 array whose addresses are taken ONCE
+        (extracting an array's address costs ~1 us, a 3-float copy 0.3 us); the lock keeps concurrent Python callers
+        of one map apart (ctypes releases the GIL during the call)"""
+        io = getattr(self, "_iobuf", None)
+        if io is None:
+            io = self._iobuf = _SmallArgs()
+        return io
 
     def set_parity(self, mode: int):
         """PARITY_FAST (tree summation) / PARITY_EXACT (the reference's beam-order fp32 chains: bit-identical poses)"""
@@ -200,15 +251,29 @@ class MapRepMultiMap:
     def matchData(self, beginEstimateWorld, dataContainer, covMatrix=None, origo=_ZERO2):
         """-> (newEstimateWorld[3], covMatrix[9] column-major); cov is in/out like the reference."""
         a, p, n = _pts(dataContainer)
-        out = np.empty(3, np.float32)
-        cov = np.zeros(9, np.float32) if covMatrix is None else _v(covMatrix, 9).copy()
-        _check(self._lib.hsm_match(self._h, _v(beginEstimateWorld, 3), p, n, _v(origo, 2), out, cov), "hsm_match")
+        io = self._io()
+        with io.lock:
+            _fill(io.pose, beginEstimateWorld, 3)
+            _fill(io.origo, origo, 2)
+            if covMatrix is None:
+                io.cov[:] = 0.0
+            else:
+                _fill(io.cov, covMatrix, 9)
+            rc = self._lib._hsm_match_raw(self._h, io.a_pose, p, n, io.a_origo, io.a_out, io.a_cov)
+            out, cov = io.out.copy(), io.cov.copy()
+        if rc != HSM_OK:
+            _check(rc, "hsm_match")
         return out, cov
 
     def updateByScan(self, dataContainer, robotPoseWorld, origo=_ZERO2):
         a, p, n = _pts(dataContainer)
-        _check(self._lib.hsm_update_by_scan(self._h, _v(robotPoseWorld, 3), p, n, _v(origo, 2)),
-               "hsm_update_by_scan")
+        io = self._io()
+        with io.lock:
+            _fill(io.pose, robotPoseWorld, 3)
+            _fill(io.origo, origo, 2)
+            rc = self._lib._hsm_update_raw(self._h, io.a_pose, p, n, io.a_origo)
+        if rc != HSM_OK:
+            _check(rc, "hsm_update_by_scan")
 
     def synchronize(self):
         """wait for queued device work (updateByScan returns once its kernels are queued)"""
