@@ -1064,7 +1064,9 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
 #pragma unroll
         for (int k = 0; k <= kEpAhead; ++k) endpoint_issue(k);
       }
+#if !defined(HSM_EXP_NO_PRIO_ROTATION)
       rotate_wave_priority(it + l);
+#endif
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
