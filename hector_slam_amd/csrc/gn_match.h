@@ -959,13 +959,21 @@ struct __attribute__((packed, aligned(4))) CellPair {
   float a, b;
 };
 
-template <int SPB, int BPL, int LAYOUT = kLayoutQuad>
-__global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const MatchParams P) {
-  __shared__ f2 lds_pts[SPB][BPL][64];
+// WPS = 2 (experimental, HSM_CACHED_WPS2): TWO waves per scan, beam i in thread i mod 128 of the pair like
+// gn_match_kernel<2,1> (identical bits), nine beams per lane = 92 VGPRs = five waves per SIMD: a 4096-scan launch is
+// 8192 waves on 5120 slots, so late workgroups start as early ones finish.
+template <int SPB, int BPL, int LAYOUT = kLayoutQuad, int WPS = 1>
+__global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cached_kernel(const MatchParams P) {
+  static_assert(WPS == 1 || SPB == 1, "a pair of waves owns its workgroup (one barrier per GN step)");
+  constexpr int T = 64 * WPS;  // lanes per scan
+  __shared__ f2 lds_pts[SPB * WPS][BPL][64];
+  __shared__ float red[2][WPS][9];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int wit = __builtin_amdgcn_readfirstlane(wave % WPS);  // wave in team
+  int red_buf = 0;
   // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
-  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave);
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave / WPS);
 #if defined(HSM_EXP_TIMESTAMPS)
   const unsigned long long ts_entry = wall_clock64();
 #endif
@@ -978,7 +986,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   }
   float pw0 = P.begin_world[3 * scan + 0], pw1 = P.begin_world[3 * scan + 1], pw2 = P.begin_world[3 * scan + 2];
   if (n == 0) {
-    if (lane == 0) {
+    if (lane == 0 && wit == 0) {
       P.out_pose[3 * scan + 0] = pw0;
       P.out_pose[3 * scan + 1] = pw1;
       P.out_pose[3 * scan + 2] = pw2;
@@ -1006,7 +1014,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   if (!peel) {
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
-      const int i = lane + k * 64;
+      const int i = lane + 64 * wit + k * T;
       const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: see gn_match_kernel
       mine[k][lane] = f2{q.x, q.y};
     }
@@ -1049,7 +1057,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       // stays at the load (hoisted out of the level loop, 17 offsets would sit in VGPRs for the whole kernel).
       f2 pq[kFirst ? BPL : 1];
       auto endpoint_issue = [&](int k) {
-        int i = min((int)lane_id_now() + 64 * k, n - 1);
+        int i = min((int)lane_id_now() + 64 * wit + T * k, n - 1);
         asm volatile("" : "+v"(i));
         const unsigned byte_off = (unsigned)i << 3;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pq[kFirst ? k : 0]) : "v"(byte_off), "s"(pts) : "memory");
@@ -1057,7 +1065,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       if (kFirst) {
         // clock probe, begin stamps (see the end of the kernel): here, at the top of the peeled step, no texel is live
         // yet -- the same block at the kernel's entry made the register allocator spill
-        if (P.clock_probe != nullptr && scan == 0 && lane_id_now() == 0) {
+        if (P.clock_probe != nullptr && scan == 0 && wit == 0 && lane_id_now() == 0) {
           P.clock_probe[0] = __builtin_readcyclecounter();
           P.clock_probe[1] = wall_clock64();
         }
@@ -1175,7 +1183,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       // peeled step: endpoint k from its load register (padding lanes replaced), scaled for this level, into LDS
       auto endpoint_take = [&](int k) -> f2 {
         wait_vmcnt(kSched.posG[k] - kSched.posE[k] - 1, pq[k]);  // beam k's gather is the next load in issue order
-        const bool pad = (int)lane_id_now() + 64 * k >= n;
+        const bool pad = (int)lane_id_now() + 64 * wit + T * k >= n;
         const f2 p = f2{(pad ? 1.0e30f : pq[k].x) * ps, (pad ? 1.0e30f : pq[k].y) * ps};
         mine[k][lane] = p;
         return p;
@@ -1233,14 +1241,19 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
       // a scan longer than the 64 * BPL cached beams (BPL comes from a host-side length HINT): the rest streams
       // from memory like gn_match_kernel's loop, in the same per-lane order (wave-uniform trip count)
 #if !defined(HSM_EXP_NO_TAIL)
-      for (int i = 64 * BPL + (n > 64 * BPL ? lane_id_now() : 0); i < n; i += 64) {
+      for (int i = T * BPL + (n > T * BPL ? lane_id_now() + 64 * wit : 0); i < n; i += T) {
         const float2 p = pts[i];
         BeamRot r;
         const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
         beam_finish(b, r, acc);
       }
 #endif
-      wave_allreduce9(acc);
+      if (WPS > 1) {
+        team_allreduce9<WPS>(acc, red, red_buf, wit, lane_id_now());
+        red_buf ^= 1;
+      } else {
+        wave_allreduce9(acc);
+      }
       gn_solve_and_step(acc, ex, ey, eth);
     };
     int it = 0;
@@ -1253,7 +1266,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw2 = eth;
   }
-  if (lane_id_now() == 0) {
+  if (lane_id_now() == 0 && wit == 0) {
     P.out_pose[3 * scan + 0] = pw0;
     P.out_pose[3 * scan + 1] = pw1;
     P.out_pose[3 * scan + 2] = pw2;
@@ -1279,7 +1292,7 @@ __global__ void __launch_bounds__(64 * SPB, 4) gn_match_cached_kernel(const Matc
   // (s_memtime) and the 100 MHz wall clock at the top of its first GN step and here, as its last act; the ratio of the
   // two differences is the clock it ran at.  (Stamps of different launches cannot be compared: the wave lands on
   // different CUs, whose shader-clock counters are not aligned.)
-  if (P.clock_probe != nullptr && scan == 0 && lane_id_now() == 0) {
+  if (P.clock_probe != nullptr && scan == 0 && wit == 0 && lane_id_now() == 0) {
     P.clock_probe[2] = __builtin_readcyclecounter();
     P.clock_probe[3] = wall_clock64();
   }

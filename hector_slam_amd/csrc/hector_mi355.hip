@@ -163,6 +163,7 @@ struct hsm_ctx {
   int exact_batch_form = 2;      // env HSM_EXACT_BATCH: 0 = the one-wavefront-per-scan exact form for batches, too; 1 = producer / chain workgroups on maps <= 2^23 cells only (the rule until the <8,2> shape); 2 = on every map
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
   unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
+  bool cached_wps2 = false;      // env HSM_CACHED_WPS2=1: with waves_per_scan = 2, batches use the two-wave texel-cache form (experimental)
   int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
@@ -413,7 +414,24 @@ int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream
         return per_lane <= 9 ? launch_match_t<1, 8, 9>(h, P, stream) : launch_match_t<1, 8, 17>(h, P, stream);
       return launch_match_w<1, 4>(h, P, max_n, stream);
     }
-    case 2: return launch_match_w<2, 1>(h, P, max_n, stream);
+    case 2: {
+      // experimental (HSM_CACHED_WPS2=1, explicit waves_per_scan = 2): the texel-cache form on a PAIR of waves per scan
+      // -- nine beams per lane, five waves per SIMD, 1.6 generations of waves for a 4096-scan launch (gn_match.h)
+      const int per_lane = (max_n + 127) / 128;
+      if (h->cached_wps2 && !h->exact && h->texel_cache && P.begin_world && !P.trace && h->bpl_override != 0 &&
+          h->layout == kLayoutQuad && per_lane > 0 && per_lane <= 9) {
+        hipLaunchKernelGGL((gn_match_cached_kernel<1, 9, kLayoutQuad, 2>), dim3(P.batch), dim3(128), 0, stream, P);
+        HIP_TRY(hipGetLastError());
+        h->last_cfg[0] = h->layout;
+        h->last_cfg[1] = 2;
+        h->last_cfg[2] = 128;
+        h->last_cfg[3] = P.batch;
+        h->last_cfg[4] = 9;
+        h->last_cfg[5] = 1;
+        return HSM_OK;
+      }
+      return launch_match_w<2, 1>(h, P, max_n, stream);
+    }
     case 4: return launch_match_w<4, 1>(h, P, max_n, stream);
     case 8: return launch_match_w<8, 1>(h, P, max_n, stream);
     default: return launch_match_w<16, 1>(h, P, max_n, stream);
@@ -702,6 +720,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
+  if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
   if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
 

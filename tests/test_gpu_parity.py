@@ -938,6 +938,42 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
     assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
 
 
+def test_two_wave_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch):
+    """the experimental two-waves-per-scan texel-cache form (HSM_CACHED_WPS2=1, waves_per_scan=2: nine beams per lane, five
+    waves per SIMD) == gn_match_kernel<2,1> bit for bit -- same beam -> thread mapping, same team reduction"""
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    monkeypatch.setenv("HSM_CACHED_WPS2", "1")
+    cached = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=2, layout=capi.LAYOUT_QUAD)
+    monkeypatch.setenv("HSM_CACHED_WPS2", "0")
+    plain = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=2, layout=capi.LAYOUT_QUAD)
+    for lvl in range(sc.levels):
+        lv = o.download_level(lvl)
+        cached.upload_level(lvl, *lv)
+        plain.upload_level(lvl, *lv)
+    rng = np.random.default_rng(32)
+    nq = len(sc.query_scans)
+    for sizes in ([1081] * 70, list(rng.integers(200, 1081, 40)) + [0, 1, 127, 128, 129, 1081, 0], [600] * 9):
+        scans, init = [], []
+        for j, n in enumerate(sizes):
+            full = sc.query_scans[j % nq]
+            n = min(int(n), full.shape[0])
+            scans.append(full[np.sort(rng.choice(full.shape[0], n, replace=False))] if n else np.zeros((0, 2), np.float32))
+            init.append(sc.query_init[j % nq] + (rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]).astype(np.float32))
+        init = np.asarray(init, np.float32)
+        pts, offs = synth.pack_scans(scans)
+        pc, cc = cached.match_batch(init, pts, offs)
+        cfg = cached.last_launch_config()
+        pp, cp = plain.match_batch(init, pts, offs)
+        assert cfg["texel_cache"] and cfg["waves_per_scan"] == 2 and not plain.last_launch_config()["texel_cache"], cfg
+        assert np.array_equal(bits(pc), bits(pp)) and np.array_equal(bits(cc), bits(cp)), sizes[:3]
+    po = np.stack([o.match(init[j], scans[j])[0] for j in range(6)])
+    assert_pose_close(pc[:6], po, "two-wave texel-cache form vs oracle")
+    cached.close()
+    plain.close()
+
+
 def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, monkeypatch):
     """xcd_block(): whichever mapping a launch uses -- chunks of 16 workgroups dealt to the XCDs (default), odd chunk
     sizes, one contiguous eighth per XCD -- every scan is matched exactly once: a 1003-scan batch (251 workgroups: one

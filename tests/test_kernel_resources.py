@@ -48,15 +48,19 @@ def test_texel_cache_matcher_fits_four_waves_per_simd(device_asm):
     assert ks
     for k, v in ks.items():
         assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)   # 512 VGPRs per SIMD lane / 4 waves
-        spb = int(re.search(r"gn_match_cached_kernelILi(\d+)E", k).group(1))   # scans (= waves) per workgroup
-        assert (16 // spb) * v["lds"] <= 160 * 1024, (k, v)     # 16 waves per CU: 16 / spb workgroups share its LDS
+        m = re.search(r"gn_match_cached_kernelILi(\d+)ELi\d+ELi\d+ELi(\d+)E", k)
+        waves = int(m.group(1)) * int(m.group(2))                # scans per workgroup x waves per scan
+        per_cu = 20 if int(m.group(2)) == 2 else 16              # five / four waves per SIMD
+        if int(m.group(2)) == 2:
+            assert v["vgpr"] <= 96, (k, v)                        # the two-wave form is built for five waves per SIMD
+        assert (per_cu // waves) * v["lds"] <= 160 * 1024, (k, v)  # the workgroups of one CU share its LDS
 
 
 def test_counted_waits_are_static_in_the_peeled_step(device_asm):
     """the waits of the peeled first step must have folded to immediates (s_waitcnt vmcnt(n) in straight-line code): the
     quad-layout 17-beam kernel then contains the schedule's values (endpoints 4 ahead: 4..8 while they stream in, 2 / 1
     for a texel with the next endpoint + gather or only the next gather behind it)"""
-    m = re.search(r"^_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1EEEvNS_11MatchParamsE:(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
+    m = re.search(r"^_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1EEEvNS_11MatchParamsE:(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
     assert m
     body = m.group(1)
     seen = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)}
