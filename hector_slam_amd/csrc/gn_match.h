@@ -20,15 +20,20 @@
 //     the probability plane directly and keeps no texel plane: less memory, one pass
 //     less per map update);
 //   * the 6 unique H terms + 3 dTr terms are lane-local fp32 partial sums, reduced
-//     with a wavefront all-reduce (4 DPP row steps + v_permlane16/32_swap, no LDS),
+//     with ONE folded wavefront reduction (v_permlane32/16_swap on pairs of values,
+//     DPP bank masks on the row levels, 9 v_readlane: 34 instructions, no LDS),
 //     then -- when WPS > 1 -- staged through LDS (double buffered, one barrier per
 //     GN step);
 //   * every lane ends up with bit-identical totals and solves the 3x3 system
 //     redundantly: no broadcast, no divergence;
+//   * batches of long scans run the texel-cache form (gn_match_cached_kernel): the
+//     last texel of every beam stays in VGPRs, endpoints in LDS, gathers only in the
+//     lanes whose cell changed, issued one beam ahead with counted s_waitcnt (inline
+//     asm), first GN step peeled so that it runs while the endpoints stream in;
 //   * a single DENSE scan (>= 4096 beams) is spread over up to 64 workgroups of one
 //     cooperative launch instead (gn_match_coop_kernel, one grid sync per GN step).
 //   No MFMA: this is a bilinear gather plus a 9-term reduction, not a contraction.
-//   Measured limits (profiles/r01/README.md): VALU issue (62 instructions per beam) and
+//   Measured limits (profiles/r02/README.md): VALU issue (61 instructions per beam) and
 //   the texture path of the divergent 16-byte gathers -- not HBM.
 //
 // Numerics: built with -ffp-contract=off.  Every per-beam value (M, dM/dx, dM/dy,
