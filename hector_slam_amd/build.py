@@ -15,7 +15,8 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SRC = os.path.join(_PKG, "csrc", "hector_mi355.hip")
-DEPS = [SRC, os.path.join(_PKG, "csrc", "gn_match.h"), os.path.join(_PKG, "csrc", "map_update.h"),
+DEPS = [SRC, os.path.join(_PKG, "csrc", "gn_match.h"), os.path.join(_PKG, "csrc", "gn_match_exact.h"),
+        os.path.join(_PKG, "csrc", "map_update.h"),
         os.path.join(_PKG, "csrc", "libm_exact.h"),
         os.path.join(_ROOT, "include", "hector_mi355", "capi.h")]
 LIB = os.path.join(_PKG, "lib", "libhector_mi355.so")

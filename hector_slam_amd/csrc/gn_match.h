@@ -196,9 +196,9 @@ __device__ __forceinline__ void sincos_f32(float th, float& s, float& c) { libm:
 
 // util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
 __device__ __forceinline__ float normalize_angle(float angle) {
-  const double two_pi = 2.0 * 3.14159265358979323846;
+  const double two_pi = libm::at_use(2.0 * 3.14159265358979323846);  // materialised here, not hoisted over the GN loops
   float a = (float)fmod(fmod((double)angle, two_pi) + two_pi, two_pi);
-  if ((double)a > 3.14159265358979323846) {
+  if ((double)a > libm::at_use(3.14159265358979323846)) {
     a = (float)((double)a - two_pi);
   }
   return a;

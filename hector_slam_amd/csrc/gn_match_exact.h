@@ -1,0 +1,487 @@
+// gn_match_exact.h -- HSM_PARITY_EXACT for batches, texel-cache form (round 3).
+//
+// What it computes: the same coarse-to-fine Gauss-Newton match as gn_match.h, with the nine sums of
+// OccGridMapUtil::getCompleteHessianDerivs (HSL/map/OccGridMapUtil.h:76-98) accumulated in the REFERENCE's order --
+// one fp32 chain per term, beam 0 .. n-1 -- so H, dTr, every GN step (ScanMatcher.h:194-221), the pose and the
+// covariance are bit-identical to the reference CPU matcher, at close to the throughput of the fast form.
+//
+// How:
+//   * one wavefront per scan, NS scans per workgroup; every wavefront is a PRODUCER with gn_match_cached_kernel's
+//     machinery: the last texel + byte offset of each of its BPL beams per lane stay in VGPRs, exec-masked inline-asm
+//     gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the first kXRegRows rows in VGPRs: the
+//     LDS budget of 16 scans per CU does not hold all 17 rows next to the stage);
+//   * per ROUND k (beam k of every lane = beams 64k .. 64k+63 of the scan) a producer stages FOUR values per beam --
+//     gx, gy (the source's dM/dx, dM/dy), rotDeriv, funVal -- not the nine products: every product of :83-97 is a
+//     product of two of those four, so the chain lane multiplies (unfused, one rounding, like the reference) and adds;
+//     4 instead of 9 LDS rows per scan is what lets a triple-buffered stage and the endpoints of 16 scans share 160 KB;
+//   * the chains: 9 NS sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
+//     lane l runs chain-round unit u = 64 j + l, u = k * (9 NS) + (9 scan + term): jobs are PACKED across round
+//     boundaries, so all 64 lanes work (NS = 8: 72 chains per round = 1.125 jobs instead of two 36-lane jobs); a
+//     chain's running sum travels from job to job through LDS.  The jobs that complete with round k run right after
+//     round k's barrier on ONE wavefront (they depend on each other through the carried sums), the owner rotating
+//     from round to round, while the other wavefronts already produce round k+1.  A job may still read round k-1's
+//     rows, hence three stage buffers; one workgroup barrier per round.
+//   Same arithmetic on the same texels in the same order as gn_match_kernel<.., EXACT>: identical bits.
+#pragma once
+#include "gn_match.h"
+
+namespace hsm {
+
+constexpr int kXRow = 64 + kExactPad;  // floats per staged row: 16-byte aligned rows, chain lanes on distinct banks
+// term t of OccGridMapUtil.h:83-97 = row A_t * row B_t of {0: gx, 1: gy, 2: rotDeriv, 3: funVal}
+//   t:      dTr0     dTr1     dTr2     H00      H11      H22      H01      H02      H12
+constexpr unsigned kTermRowA = 0u | 1u << 2 | 2u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 0u << 12 | 0u << 14 | 1u << 16;
+constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
+
+#ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
+#define HSM_XBPC 13
+#endif
+#ifndef HSM_XBPC4  // the same for 4 scans per workgroup (more endpoint rows in VGPRs: four stage buffers)
+#define HSM_XBPC4 14
+#endif
+#ifndef HSM_XLDS_AHEAD
+#define HSM_XLDS_AHEAD 1
+#endif
+#ifndef HSM_XJOB_SLOTS  // 16-byte LDS slots per row a chain job keeps in flight (8 VGPRs each)
+#define HSM_XJOB_SLOTS 3
+#endif
+#ifndef HSM_XWS_SPIN_LIMIT  // polls before a wait gives up (sets Smem::err -> NaN poses; nothing hangs)
+#define HSM_XWS_SPIN_LIMIT (1 << 22)
+#endif
+#ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
+#define HSM_XJOB_PRIO 3
+#endif
+
+// BPL rows of beams per lane, the first BPC of them with a cached texel (5 VGPRs per row: the chain jobs need ~28
+// VGPRs of their own for the LDS rows they keep in flight, which 17 cached rows + 4 endpoint rows do not leave at 128);
+// rows BPC .. BPL-1 gather in every step.
+//
+// SYNC = 0: one workgroup barrier per round; the jobs that complete with round k run behind barrier k on the wavefront
+//   (k + step) mod NS.  Measured: every round then lasts as long as its slowest member -- the owner's job (a 64-deep
+//   dependent chain) PLUS its own next round -- about twice the fast form's round (profiles/r03/README.md).
+// SYNC = 1 (default): no barriers.  Two monotonic LDS words couple the wavefronts:
+//   prog[w]    rounds wavefront w has staged (written behind its four rows: the LDS operations of a wavefront execute
+//              in order);
+//   jobs_done  chain jobs completed (a job publishes it behind its sums).
+//   Job G (global index, in order: it inherits running sums from job G - 1) belongs to wavefront G mod NS, which runs it
+//   as soon as it has itself staged the last round the job reads: it waits until jobs_done == G and every prog[] covers
+//   that round, runs the job, publishes.  A wavefront overwrites stage buffer k mod NB only once the jobs that read round
+//   k - NB are done, and reads its nine totals once the step's last job is.  Nobody waits for a wavefront that is merely
+//   slower: the producers drift like the fast form's wavefronts, up to NB - 1 rounds ahead of the chain.
+template <int NS, int BPL, int BPC = BPL, int SYNC = 1>
+__global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const MatchParams P) {
+  static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
+  constexpr int NC = 9 * NS;  // chains per workgroup
+  // unit stride of a round.  A chain must not appear twice in one job (its rounds are sequential), so workgroups with
+  // fewer than 64 chains pad the round to 64 units: one job per round, the lanes beyond NC idle.
+  constexpr int NCP = NC >= 64 ? NC : 64;
+  // stage buffers: a job of 64 units spans one round (NCP a multiple of 64) or two, and the next round is being
+  // produced meanwhile
+  constexpr int NB = NCP % 64 == 0 ? 2 : 3;
+  // endpoint rows in VGPRs: what the LDS share of a workgroup (16 wavefronts per CU) does not hold next to the stage
+  constexpr int kLdsShare = 160 * 1024 / (16 / NS);
+  constexpr int kRowsFit = (kLdsShare - NB * NS * 4 * kXRow * 4 - NC * 4 - NS * 4 - 64) / (NS * 512);
+  constexpr int RV = BPL <= kRowsFit ? 0 : BPL - kRowsFit;
+  static_assert(RV < BPL && RV <= 8, "endpoint rows kept in VGPRs");
+  static_assert(64 * NS <= 1024, "one workgroup");
+  // ONE shared object with the stage first: its LDS address must fit M0[15:0] (ds_write_addtid_b32 below)
+  struct alignas(16) Smem {
+    float stage[NB][NS][4][kXRow];
+    float runs[NC];
+    unsigned prog[NS];
+    unsigned jobs_done;
+    unsigned err;
+    int nmax;
+    f2 pts[NS][BPL - RV][64];
+  };
+  static_assert(sizeof(Smem) <= kLdsShare, "16 wavefronts per CU");
+  __shared__ Smem sm;
+  auto& stage = sm.stage;
+  auto& runs = sm.runs;
+  int& nmax_s = sm.nmax;
+  auto& lds_pts = sm.pts;
+  static_assert(sizeof(sm.stage) < 65536, "stage rows are addressed through M0[15:0]");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * NS + wave);
+  const bool active = scan < P.batch;  // inactive wavefronts (batch tail) run along with an empty scan: barriers, jobs
+  int beg = 0, n = 0;
+  float pw0 = 0.0f, pw1 = 0.0f, pw2 = 0.0f;
+  if (active) {
+    n = P.shared_n;
+    if (P.offsets) {
+      beg = P.offsets[scan];
+      n = P.offsets[scan + 1] - beg;
+    }
+    pw0 = P.begin_world[3 * scan + 0];
+    pw1 = P.begin_world[3 * scan + 1];
+    pw2 = P.begin_world[3 * scan + 2];
+  }
+  // wave-uniform values live in SGPRs: this kernel has no VGPR to spare
+  pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(pw2);
+  const float b0 = pw0, b1 = pw1, b2 = pw2;  // an empty scan passes its start estimate through (ScanMatcher.h:68,189)
+  if (threadIdx.x == 0) {
+    nmax_s = 0;
+    sm.jobs_done = 0;
+    sm.err = 0;
+  }
+  if (threadIdx.x < NS) sm.prog[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0 && n > 0) atomicMax(&nmax_s, n);
+  __syncthreads();
+  const int nmax = nmax_s;  // workgroup-uniform
+  if (nmax == 0) {          // nothing but empty scans
+    if (active && lane == 0) {
+      P.out_pose[3 * scan + 0] = b0;
+      P.out_pose[3 * scan + 1] = b1;
+      P.out_pose[3 * scan + 2] = b2;
+    }
+    return;
+  }
+  // rounds per GN step: the BPL cached rows (all of them: shorter scans pad with +-0 contributions), plus streamed
+  // rounds for scans longer than the host's length hint
+  const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
+  const int units = rounds * NCP;
+  const int jobs_per_step = (units + 63) >> 6;
+  const float2* __restrict__ pts = P.pts + beg;
+  f2(*mine)[64] = lds_pts[wave];
+#if defined(HSM_EXP_XTIMING)  // experiment: per-wavefront cycle accounting, written over the covariance
+  unsigned long long xt_job = 0, xt_ready = 0, xt_wait = 0, xt_njobs = 0, xt_nwait = 0;
+  const unsigned long long xt_begin = __builtin_readcyclecounter();
+#define XT(x) x
+#else
+#define XT(x)
+#endif
+  unsigned my_job = (unsigned)wave;  // SYNC = 1: global index of the next chain job this wavefront owns
+  unsigned jobs_seen = 0;            // last value read from jobs_done (monotonic: a stale value can only under-report)
+  auto wait_jobs = [&](unsigned need) {
+    if ((int)(jobs_seen - need) >= 0) return;
+    XT(const unsigned long long t0 = __builtin_readcyclecounter();)
+    for (int spin = 0;; ++spin) {
+      jobs_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.jobs_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if ((int)(jobs_seen - need) >= 0) break;
+      if (spin > HSM_XWS_SPIN_LIMIT) {
+        sm.err = 2;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    XT(xt_wait += __builtin_readcyclecounter() - t0; ++xt_nwait;)
+    asm volatile("" ::: "memory");  // what the jobs wrote is read after this point
+  };
+  f2 pv[RV > 0 ? RV : 1];
+#pragma unroll
+  for (int k = 0; k < BPL; ++k) {
+    const int i = lane + 64 * k;
+    const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 contributions (gn_match_kernel)
+    if (k < RV)
+      pv[k] = f2{q.x, q.y};
+    else
+      mine[k - RV][lane] = f2{q.x, q.y};
+  }
+  f4v tq[BPC];
+  unsigned toff[BPC];
+  Acc9 acc;
+  acc.zero();
+  float reg_scale = 1.0f;
+  int step_no = 0;
+  // LDS byte address of this wavefront's stage rows in buffer 0 (wave-uniform; a generic LDS pointer's low half)
+  const unsigned st_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&stage[0][wave][0][0]);
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    ex = uniform_f32(ex), ey = uniform_f32(ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<kLayoutQuad>(L);
+    const float ratio = ps / reg_scale;  // powers of two: exact
+    reg_scale = ps;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+      if (ratio != 1.0f) {
+        if (k < RV)
+          pv[k] *= f2{ratio, ratio};
+        else
+          mine[k - RV][lane] *= f2{ratio, ratio};
+      }
+      if (k < BPC) toff[k] = 0xffffffffu;  // never a texel offset: every beam gathers in the level's first step
+    }
+    unsigned zero_off = (unsigned)R.zero_index << 4;
+    asm volatile("" : "+v"(zero_off));
+    for (int it = 0; it < gn_steps; ++it, ++step_no) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      const f2 o2 = step_origin(ex, ey);
+      const f2 e2 = f2{uniform_f32(o2.x), uniform_f32(o2.y)};
+      const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
+      const unsigned job0 = (unsigned)(step_no * jobs_per_step);  // global index of the step's first job
+      const unsigned round0 = (unsigned)(step_no * rounds);       // rounds staged before this step
+      auto endpoint = [&](int k) -> f2 { return k < RV ? pv[k < RV ? k : 0] : mine[k < RV ? 0 : k - RV][lane]; };
+      // rotate, bounds test, cell offset, fractions; gather only in the lanes whose cell changed (gn_match_cached_kernel)
+      f4v tu[2];  // texels of the uncached rows (k >= BPC), alternating
+      auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) -> unsigned long long {
+        r.r.x = cs.x * p.x - sc.x * p.y;
+        r.r.y = cs.y * p.x + sc.y * p.y;
+        const CellCoord q = cell_coord(R, f2{e2.x + r.r.x, e2.y + r.r.y});
+        fx = q.fx;
+        fy = q.fy;
+        unsigned idx = quad_index(q.ix, q.iy, R.tiles_x, R.sx);
+        asm volatile("" : "+v"(idx));
+        const unsigned off = q.oob ? zero_off : idx << 4;
+        if (k >= BPC) {  // uncached row: every lane gathers
+          asm volatile("global_load_dwordx4 %[t], %[o], %[b]" : [t] "=v"(tu[k & 1]) : [o] "v"(off), [b] "s"(R.quad) : "memory");
+          return ~0ull;
+        }
+        const int kc = k < BPC ? k : 0;
+        unsigned long long moved, saved;
+        asm volatile(
+            "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
+            "s_mov_b64 %[mv], vcc\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "s_cbranch_execz 1f\n\t"
+            "global_load_dwordx4 %[t], %[o], %[b]\n\t"
+            "v_mov_b32 %[to], %[o]\n\t"
+            "1:\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [t] "+v"(tq[kc]), [to] "+v"(toff[kc]), [sv] "=&s"(saved), [mv] "=&s"(moved)
+            : [o] "v"(off), [b] "s"(R.quad)
+            : "vcc", "scc", "memory");
+        return moved;
+      };
+      auto texel_ready = [&](int k, unsigned long long next_moved, bool has_next) {
+        f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
+        if (has_next && k + 1 >= BPC) {  // the next row's gather is unconditional
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(tx) : : "memory");
+        } else if (has_next) {
+          asm volatile(
+              "s_cmp_eq_u64 %[m], 0\n\t"
+              "s_cbranch_scc1 1f\n\t"
+              "s_waitcnt vmcnt(1)\n\t"
+              "s_branch 2f\n\t"
+              "1:\n\t"
+              "s_waitcnt vmcnt(0)\n\t"
+              "2:"
+              : "+v"(tx)
+              : [m] "s"(next_moved)
+              : "scc", "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(tx) : : "memory");
+        }
+      };
+      // the four staged values of one beam (OccGridMapUtil.h:332-346 and :80-87), with the source's signs:
+      //   gx = -((P00-P10)*xFacInv + (P01-P11)*fx) == (P10-P00)*xFacInv + (P11-P01)*fx   (negation commutes with rounding)
+      //   rotDeriv = (-ry)*gx + rx*gy == rx*gy - ry*gx,  (rx, ry) = R(theta) p shared with the transform (gn_match.h)
+      auto produce = [&](int k, float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy) {
+        const int buf = k % NB;
+        // SYNC = 1: buffer k mod NB held round k - NB: the jobs that read it (the last one: the job of that round's
+        // last unit) must be done -- none for k < NB, the step's start waited for every job of the step before
+        if (SYNC == 1 && k >= NB) wait_jobs(job0 + (unsigned)(((k - NB + 1) * NCP - 1) >> 6) + 1u);
+        const float xFacInv = 1.0f - fx, yFacInv = 1.0f - fy;
+        const float M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
+        const float gx = ((i1 - i0) * xFacInv) + ((i3 - i2) * fx);
+        const float gy = ((i2 - i0) * yFacInv) + ((i3 - i1) * fy);
+        const float funVal = 1.0f - M;
+        const float rotDeriv = r.r.x * gy - r.r.y * gx;
+        // four rows, lane l at row + 4 l: ds_write_addtid_b32 (address = M0 + offset + 4 * lane) needs no address VGPR and
+        // half the LDS cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS)
+        asm volatile(
+            "s_mov_b32 m0, %[m]\n\t"
+            "s_nop 0\n\t"
+            "ds_write_addtid_b32 %[a] offset:%[o0]\n\t"
+            "ds_write_addtid_b32 %[b] offset:%[o1]\n\t"
+            "ds_write_addtid_b32 %[c] offset:%[o2]\n\t"
+            "ds_write_addtid_b32 %[d] offset:%[o3]"
+            :
+            : [m] "s"(st_wave + (unsigned)buf * (NS * 4 * kXRow * 4)), [a] "v"(gx), [b] "v"(gy), [c] "v"(rotDeriv), [d] "v"(funVal),
+              [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4), [o3] "n"(3 * kXRow * 4)
+            : "memory");  // M0 is reserved, not allocatable: nothing else in this kernel uses it (gfx9+ DS operations do not)
+        // relaxed workgroup-scope atomics on LDS = plain ds_write / ds_read.  (A volatile access through a generic
+        // pointer would be a system-scope FLAT access: slow, and it counts in vmcnt, which the inline-asm gathers own.)
+        if (SYNC == 1) __hip_atomic_store(&sm.prog[wave], round0 + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
+      // running sum.  The two rows stream through kSlots 16-byte slots each; the four products of slot q + 1 are computed
+      // BETWEEN the four additions of slot q (inline asm: the order is the point), so that the dependent chain is the
+      // additions alone -- v_add_f32 back to back costs ~4 cycles, a v_mul_f32 feeding the next v_add_f32 another 4.
+      auto chain_job = [&](int j) {
+        // the lane index is re-read here (volatile asm): everything below depends on it, so the per-lane unit / address
+        // arithmetic of the ~20 jobs of a step is not hoisted out of the GN loop into VGPRs that are not there
+        const int u = 64 * j + lane_id_now();
+        const int ku = u / NCP, c = u - ku * NCP;  // round, chain
+        if (u < units && c < NC) {
+          const int sj = c / 9, t = c - 9 * sj;  // scan of the workgroup, term
+          const unsigned ra = (kTermRowA >> (2 * t)) & 3u, rb = (kTermRowB >> (2 * t)) & 3u;
+          const float* base = &stage[0][0][0][0] + ((ku % NB) * NS + sj) * (4 * kXRow);
+          const float4* pa = reinterpret_cast<const float4*>(base + ra * kXRow);
+          const float4* pb = reinterpret_cast<const float4*>(base + rb * kXRow);
+          float run = ku == 0 ? 0.0f : runs[c];
+          constexpr int S = HSM_XJOB_SLOTS;
+          float4 a[S], b[S];
+#pragma unroll
+          for (int q = 0; q < S; ++q) a[q] = pa[q], b[q] = pb[q];
+          float p0 = a[0].x * b[0].x, p1 = a[0].y * b[0].y, p2 = a[0].z * b[0].z, p3 = a[0].w * b[0].w;
+          asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : : "memory");
+          if (S < 16) a[0] = pa[S], b[0] = pb[S];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (q + 1 < 16) {
+              const float4 x = a[(q + 1) % S], y = b[(q + 1) % S];
+              float n0, n1, n2, n3;
+              asm volatile(
+                  "v_add_f32 %[r], %[r], %[p0]\n\t"
+                  "v_mul_f32 %[n0], %[x0], %[y0]\n\t"
+                  "v_add_f32 %[r], %[r], %[p1]\n\t"
+                  "v_mul_f32 %[n1], %[x1], %[y1]\n\t"
+                  "v_add_f32 %[r], %[r], %[p2]\n\t"
+                  "v_mul_f32 %[n2], %[x2], %[y2]\n\t"
+                  "v_add_f32 %[r], %[r], %[p3]\n\t"
+                  "v_mul_f32 %[n3], %[x3], %[y3]"
+                  : [r] "+v"(run), [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3)
+                  : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [x0] "v"(x.x), [x1] "v"(x.y), [x2] "v"(x.z),
+                    [x3] "v"(x.w), [y0] "v"(y.x), [y1] "v"(y.y), [y2] "v"(y.z), [y3] "v"(y.w)
+                  : "memory");
+              p0 = n0, p1 = n1, p2 = n2, p3 = n3;
+              if (q + 1 + S < 16) a[(q + 1) % S] = pa[q + 1 + S], b[(q + 1) % S] = pb[q + 1 + S];  // the slot just consumed
+              asm volatile("" ::: "memory");
+            } else {
+              run += p0;
+              run += p1;
+              run += p2;
+              run += p3;
+            }
+          }
+          runs[c] = run;
+        }
+      };
+      // round k is staged.  SYNC = 0: meet, then (one wavefront) run the chain jobs that are complete with it.
+      // SYNC = 1: run the jobs this wavefront owns whose last round it has now staged itself.
+      auto round_done = [&](int k, bool last_round) {
+#if defined(HSM_EXP_XNOBAR)  // experiment: production alone (results are garbage)
+        return;
+#endif
+        if (SYNC == 1) {
+          for (;;) {
+            const int j = (int)(my_job - job0);  // >= 0: every job of the steps before has been run
+            if (j >= jobs_per_step) break;
+            const int last_unit = 64 * j + 63 < units ? 64 * j + 63 : units - 1;
+            const int r = last_unit / NCP;
+            if (r > k) break;  // reads a round this wavefront has yet to stage
+            const unsigned need = round0 + (unsigned)r + 1u;
+            XT(const unsigned long long t0 = __builtin_readcyclecounter();)
+            for (int spin = 0;; ++spin) {
+              const unsigned jd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.jobs_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              const unsigned pr = __hip_atomic_load(&sm.prog[lane_id_now() & (NS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (jd == my_job && __builtin_amdgcn_ballot_w64((int)(pr - need) < 0) == 0ull) break;
+              if (spin > HSM_XWS_SPIN_LIMIT) {
+                sm.err = 1;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            XT(const unsigned long long t1 = __builtin_readcyclecounter(); xt_ready += t1 - t0;)
+            __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+            chain_job(j);
+            __builtin_amdgcn_s_setprio(0);
+            XT(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); xt_job += __builtin_readcyclecounter() - t1; ++xt_njobs;)
+            // published behind the sums: the LDS operations of a wavefront execute in program order
+            asm volatile("" ::: "memory");
+            jobs_seen = my_job + 1u;
+            __hip_atomic_store(&sm.jobs_done, jobs_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            my_job += NS;
+          }
+          return;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if defined(HSM_EXP_XNOJOB)  // experiment: production + barriers, no chain jobs (results are garbage)
+        return;
+#endif
+        const int j_lo = (k * NCP) >> 6;
+        const int j_hi = last_round ? (units + 63) >> 6 : ((k + 1) * NCP) >> 6;
+        if (j_lo >= j_hi) return;
+        if (wave != (int)((unsigned)(k + step_no) % (unsigned)NS)) return;  // wave-uniform
+        __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+        for (int j = j_lo; j < j_hi; ++j) chain_job(j);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      {
+        BeamRot rc, rn;
+        float fxc, fyc, fxn = 0.0f, fyn = 0.0f;
+        unsigned long long next_moved = 0ull;
+#if HSM_XLDS_AHEAD
+        f2 p_next = endpoint(BPL > 1 ? 1 : 0);
+#endif
+        locate(0, endpoint(0), rc, fxc, fyc);
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+#if HSM_XLDS_AHEAD  // endpoint of beam k+2 read from LDS before beam k+1 is located (two more VGPRs)
+          const f2 p_cur = p_next;
+          if (k + 2 < BPL) p_next = endpoint(k + 2);
+          if (k + 1 < BPL) next_moved = locate(k + 1, p_cur, rn, fxn, fyn);
+#else
+          if (k + 1 < BPL) next_moved = locate(k + 1, endpoint(k + 1), rn, fxn, fyn);
+#endif
+          texel_ready(k, next_moved, k + 1 < BPL);
+          {
+            const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
+            produce(k, tx.x, tx.y, tx.z, tx.w, rc, fxc, fyc);
+          }
+          round_done(k, k == BPL - 1 && rounds == BPL);
+          rc = rn;
+          fxc = fxn;
+          fyc = fyn;
+        }
+      }
+      // scans longer than the 64 * BPL cached beams: the rest streams from memory, uncached
+      for (int k = BPL; k < rounds; ++k) {
+        const int i = 64 * k + lane;
+        const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);
+        BeamRot r;
+        const BeamSample b = beam_fetch<kLayoutQuad>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
+        produce(k, b.lo.x, b.lo.y, b.hi.x, b.hi.y, r, b.X.y, b.Y.y);
+        round_done(k, k == rounds - 1);
+      }
+      if (SYNC == 1)
+        wait_jobs(job0 + (unsigned)jobs_per_step);  // the step's last job has published the totals
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      {
+        const float* tt = &runs[9 * wave];
+        acc.d01 = f2{uniform_f32(tt[0]), uniform_f32(tt[1])};
+        acc.d2 = uniform_f32(tt[2]);
+        acc.hd = f2{uniform_f32(tt[3]), uniform_f32(tt[4])};
+        acc.h22 = uniform_f32(tt[5]);
+        acc.h01 = uniform_f32(tt[6]);
+        acc.hr = f2{uniform_f32(tt[7]), uniform_f32(tt[8])};
+      }
+      gn_solve_and_step(acc, ex, ey, eth);
+      ex = uniform_f32(ex), ey = uniform_f32(ey), eth = uniform_f32(eth);
+    }
+    eth = normalize_angle(eth);
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+    pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
+  }
+  if (active && lane == 0) {
+    const bool empty = n == 0;
+    if (SYNC == 1 && sm.err != 0) pw0 = pw1 = pw2 = __int_as_float(0x7fc00000);  // a wait gave up: fail loudly, not plausibly
+    P.out_pose[3 * scan + 0] = empty ? b0 : pw0;
+    P.out_pose[3 * scan + 1] = empty ? b1 : pw1;
+    P.out_pose[3 * scan + 2] = empty ? b2 : pw2;
+    if (P.out_cov && !empty) {
+      float* c = P.out_cov + 9 * scan;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
+#if defined(HSM_EXP_XTIMING)
+      unsigned* uu = reinterpret_cast<unsigned*>(c);
+      uu[0] = (unsigned)(__builtin_readcyclecounter() - xt_begin);
+      uu[1] = (unsigned)xt_job; uu[2] = (unsigned)xt_njobs; uu[3] = (unsigned)xt_ready; uu[4] = (unsigned)xt_wait; uu[5] = (unsigned)xt_nwait;
+#endif
+    }
+  }
+#undef XT
+}
+
+}  // namespace hsm

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "gn_match.h"
+#include "gn_match_exact.h"
 #include "hector_mi355/capi.h"
 #include "map_update.h"
 
@@ -167,6 +168,8 @@ struct hsm_ctx {
   int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
+  int exact_sync = 1;            // env HSM_EXACT_SYNC=0|1: 0 = one workgroup barrier per round, 1 = LDS progress words, no barriers
+  int exact_cached = 8;          // env HSM_EXACT_CACHED=0|4|8|16: scans per workgroup of the texel-cache exact form (gn_match_exact.h); 0 = round 2's producer / chain workgroups
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -340,8 +343,52 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
+template <int NS, int BPL, int BPC, int SYNC>
+int launch_match_exact_cached_s(hsm_ctx* h, MatchParams P, hipStream_t stream);
+
+template <int NS, int BPL, int BPC = BPL>
+int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
+  if (h->exact_sync == 0) return launch_match_exact_cached_s<NS, BPL, BPC, 0>(h, P, stream);
+  return launch_match_exact_cached_s<NS, BPL, BPC, 1>(h, P, stream);
+}
+
+template <int NS, int BPL, int BPC, int SYNC>
+int launch_match_exact_cached_s(hsm_ctx* h, MatchParams P, hipStream_t stream) {
+  const int grid = (P.batch + NS - 1) / NS, block = 64 * NS;
+  if (P.xcd_chunk > 0) P.xcd_chunk = P.xcd_chunk * 4 / NS > 0 ? P.xcd_chunk * 4 / NS : 1;  // chunks of the same number of scans
+  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, SYNC>), dim3(grid), dim3(block), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = 1;
+  h->last_cfg[2] = block;
+  h->last_cfg[3] = grid;
+  h->last_cfg[4] = BPL;
+  h->last_cfg[5] = 1;
+  return HSM_OK;
+}
+
 template <int WPS, int SPB>
-int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  // throughput launches of the quad layout: every wavefront a producer with the texel cache, packed chain jobs
+  // (gn_match_exact.h); scans of up to 17 beams per lane (longer ones stream their tail)
+  if (WPS == 1 && P.begin_world && !P.trace && h->exact_cached && h->layout == kLayoutQuad && h->bpl_override != 0) {
+    const int per_lane = (max_n + 63) / 64;
+    if (per_lane <= 17 + 4) {
+      if (h->exact_cached == 16) {
+        if (per_lane <= 5) return launch_match_exact_cached<16, 5>(h, P, stream);
+        if (per_lane <= 9) return launch_match_exact_cached<16, 9>(h, P, stream);
+        return launch_match_exact_cached<16, 17, HSM_XBPC>(h, P, stream);
+      }
+      if (h->exact_cached == 4) {
+        if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
+        if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
+        return launch_match_exact_cached<4, 17, HSM_XBPC4>(h, P, stream);
+      }
+      if (per_lane <= 5) return launch_match_exact_cached<8, 5>(h, P, stream);
+      if (per_lane <= 9) return launch_match_exact_cached<8, 9>(h, P, stream);
+      return launch_match_exact_cached<8, 17, HSM_XBPC>(h, P, stream);
+    }
+  }
   // throughput launches: producer wavefronts + chain wavefronts per workgroup (gn_match.h).  Measured
   // (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2> and two
   // gathers in flight; on the 4096^2 pyramid, whose gathers miss the L2, <7,1> lost to the one-wavefront-per-scan form
@@ -393,7 +440,7 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
 
 template <int WPS, int SPB>
 int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  if (h->exact) return launch_match_exact<WPS, SPB>(h, P, stream);
+  if (h->exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
   const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
   if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
   if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
@@ -471,6 +518,7 @@ struct LevelPrep {
   int slot = -1;          // index in batch.lv, -1 = nothing to launch for this level (empty scan)
   const float* h_pts = nullptr;
   int n = 0;
+  bool derivable = false;  // set by level_bbox(): coarser levels of the same container may derive their box from this one
 };
 
 int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, const float pose_world[3],
@@ -533,7 +581,14 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
 // finer level's value times 2^-k (products and sums of exactly scaled operands), so cell = (int)(e * 2^-k + 0.5)
 // with the finer cell (int)(e + 0.5) in [x0, x1] lies in [(x0 >> k) - 1, (x1 >> k) + 1]: a conservative box without
 // touching the endpoints again (a superset only costs the dense passes a few rows of untouched cells).
-void level_bbox(hsm_ctx* h, UpdateBatch& batch, const LevelPrep& prep, const UpdateParams* finer, int shift) {
+//   The derivation needs the finer level to have SEEN every beam the coarser one accepts.  The low map edge breaks that:
+//   (int) truncates towards zero, so level 0 keeps an end point e (cell units, before the + 0.5) with e > -1.5 while
+//   level k keeps e * 2^-k > -1.5, i.e. e > -1.5 * 2^k -- a beam (or the begin cell) just outside the low x / y edge of
+//   level 0 is dropped there and valid on the coarser levels (the high edge only gets stricter with k).  level 0's own
+//   pass therefore records whether it rejected anything on the low side (prep.derivable); if so the coarser levels walk
+//   the end points themselves.
+void level_bbox(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, const UpdateParams* finer, int shift) {
+  prep.derivable = false;
   if (prep.slot < 0) return;
   Level& L = h->levels[prep.level];
   UpdateParams& P = batch.lv[prep.slot];
@@ -558,11 +613,13 @@ void level_bbox(hsm_ctx* h, UpdateBatch& batch, const LevelPrep& prep, const Upd
     const float fsx = (float)L.sx + 2.0f, fsy = (float)L.sy + 2.0f;
     const float* h_pts = prep.h_pts;
     const float pt_scale = P.pt_scale;
+    bool low_reject = false;  // a beam this level drops at its low x / y edge (a coarser level may keep it)
     for (int i = 0; i < prep.n; ++i) {
       float ex, ey;
       affine_apply_host(P.pose, h_pts[2 * i] * pt_scale, h_pts[2 * i + 1] * pt_scale, ex, ey);
       ex += 0.5f;
       ey += 0.5f;
+      low_reject |= (ex <= -1.0f) | (ey <= -1.0f);
       if (!(ex > -2.0f && ex < fsx && ey > -2.0f && ey < fsy)) continue;
       const int exi = (int)ex, eyi = (int)ey;
       if (exi < 0 || exi >= L.sx || eyi < 0 || eyi >= L.sy) continue;
@@ -571,6 +628,7 @@ void level_bbox(hsm_ctx* h, UpdateBatch& batch, const LevelPrep& prep, const Upd
       if (eyi < y0) y0 = eyi;
       if (eyi > y1) y1 = eyi;
     }
+    prep.derivable = !low_reject;
   }
   if (x1 >= 0) {  // at least one beam ends inside the map
     L.bbox[0] = P.x0 = x0 < bxi ? x0 : bxi;
@@ -719,6 +777,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
+  if (const char* env = getenv("HSM_EXACT_SYNC")) h->exact_sync = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) == 16 ? 16 : (atoi(env) == 4 ? 4 : (atoi(env) ? 8 : 0));
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
   if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
@@ -1273,7 +1333,7 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   if (int rc = launch_update_mark(h, batch)) return rc;
   level_bbox(h, batch, prep[0], nullptr, 0);
   for (size_t l = 1; l < h->levels.size(); ++l) {
-    const bool derive = coarse_same_container && prep[0].slot >= 0 && h->levels[l].sx == (h->levels[0].sx >> l) &&
+    const bool derive = coarse_same_container && prep[0].slot >= 0 && prep[0].derivable && h->levels[l].sx == (h->levels[0].sx >> l) &&
                         h->levels[l].sy == (h->levels[0].sy >> l);
     level_bbox(h, batch, prep[l], derive ? &batch.lv[prep[0].slot] : nullptr, (int)l);
   }

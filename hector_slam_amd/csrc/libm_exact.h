@@ -50,6 +50,19 @@ HSM_HD double bits_f64(uint64_t u) {
   return f;
 }
 
+// A binary64 constant whose materialisation stays next to its use.  On the device the optimiser otherwise hoists the
+// ~10 constants of sincosf out of the matcher's Gauss-Newton loop into registers (SGPR pairs, VGPR pairs for second operands) that stay live across the whole beam
+// loop -- in kernels that keep a per-beam texel cache in all 128 (gn_match_exact.h: spills, which the asynchronous
+// inline-asm gathers cannot tolerate).  The volatile asm is not loop invariant; the value is unchanged.
+#if defined(__HIP_DEVICE_COMPILE__)
+HSM_HD double at_use(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+#else
+HSM_HD double at_use(double c) { return c; }
+#endif
+
 // ---- sincosf ----------------------------------------------------------------------------------
 // Polynomial stage shared by all argument ranges.  xs = reduced argument times the quadrant sign,
 // x2 = (reduced argument)^2, n = quadrant.  Returns the double-precision sine/cosine of the
@@ -58,9 +71,9 @@ HSM_HD double bits_f64(uint64_t u) {
 // Quadrants 2,3 use the table with negated cosine coefficients: every operation of that chain is
 // odd in the coefficients, so its result is the exact negation of the first table's.
 HSM_HD void sincosf_poly(double xs, double x2, int n, float& sinp, float& cosp) {
-  const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
-               C4 = 0x1.99343027bf8c3p-16;
-  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  const double C0 = 0x1p0, C1 = at_use(-0x1.ffffffd0c621cp-2), C2 = at_use(0x1.55553e1068f19p-5),
+               C3 = at_use(-0x1.6c087e89a359dp-10), C4 = at_use(0x1.99343027bf8c3p-16);
+  const double S1 = at_use(-0x1.555545995a603p-3), S2 = at_use(0x1.1107605230bc4p-7), S3 = at_use(-0x1.994eb3774cf24p-13);
   const double x3 = x2 * xs;
   const double x4 = x2 * x2;
   const double s1 = __builtin_fma(x2, S3, S2);
@@ -112,9 +125,9 @@ HSM_HD void sincosf_glibc(float y, float& sinp, float& cosp) {
     }
     sincosf_poly(x, x * x, 0, sinp, cosp);
   } else if (top < 0x42f) {  // |y| < 120
-    const double r = x * 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+    const double r = x * at_use(0x1.45F306DC9C883p+23);  // 2/pi * 2^24
     const int n = ((int32_t)r + 0x800000) >> 24;
-    const double xr = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+    const double xr = __builtin_fma(-(double)n, at_use(0x1.921FB54442D18p0), x);
     const double sign = ((n ^ (n >> 1)) & 1) ? -1.0 : 1.0;  // +,-,-,+ for quadrants 0..3
     sincosf_poly(xr * sign, xr * xr, n, sinp, cosp);
   } else if (top < 0x7f8) {

@@ -121,17 +121,21 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
         assert same(pg, po) and same(cg, co), it
 
 
-@pytest.mark.parametrize("form", ["auto", "throughput", "throughput-8+2", "throughput-plane", "one-wave-per-scan"])
+@pytest.mark.parametrize("form", ["auto", "cached", "cached-4", "cached-16", "cached-tail", "cached-barrier", "throughput", "throughput-8+2",
+                                  "throughput-plane", "one-wave-per-scan"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
-    a small batch picks by itself ("auto"), the wave-specialised throughput form (seven producer wavefronts + one
-    chain wavefront per workgroup; 17 scans = 3 workgroups, the last one partial -- or eight producers + two chain
-    wavefronts, the shape full-size batches pick), and the one-wavefront-per-scan form"""
+    a small batch picks by itself ("auto"), the texel-cache exact form (gn_match_exact.h: every wavefront a producer,
+    packed chain jobs; 8 or 16 scans per workgroup, 17 scans = a partial last workgroup; "cached-tail": scans up to four
+    rows longer than the 17 cached ones stream their tail), round 2's wave-specialised forms (seven producer wavefronts +
+    one chain wavefront per workgroup, or eight + two), and the one-wavefront-per-scan form"""
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
     if form == "one-wave-per-scan":
         monkeypatch.setenv("HSM_EXACT_BATCH", "0")
+    monkeypatch.setenv("HSM_EXACT_CACHED", {"cached": "8", "cached-4": "4", "cached-16": "16", "cached-tail": "8", "cached-barrier": "8", "auto": "8"}.get(form, "0"))
+    monkeypatch.setenv("HSM_EXACT_SYNC", "0" if form == "cached-barrier" else "1")
     monkeypatch.setenv("HSM_EXACT_SHAPE", "8" if form == "throughput-8+2" else "7")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
     if form == "throughput-plane":
@@ -146,6 +150,10 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         scans.append(full[np.linspace(0, full.shape[0] - 1, min(n, full.shape[0])).astype(int)] if n else full[:0])
         init.append(sc.query_init[q])
     long_scan = np.concatenate([sc.query_scans[3], sc.query_scans[3][::2] + np.float32(0.01)])  # 1622 beams > 64 * 17
+    if form.endswith("-tail"):
+        long_scan = long_scan[:1300]  # 21 rows: the texel-cache form takes it and streams rows 17..20
+    elif form.startswith("cached"):
+        long_scan = long_scan[:1081]
     scans.append(long_scan)
     init.append(sc.query_init[3])
     init = np.stack(init)
@@ -153,6 +161,9 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     pb, cb = g.match_batch(init, pts, offs)
     if form.startswith("throughput"):
         assert g.last_launch_config()["block"] == (640 if form == "throughput-8+2" else 512), g.last_launch_config()
+    if form.startswith("cached"):
+        cfg = g.last_launch_config()
+        assert cfg["texel_cache"] and cfg["block"] == {"cached-16": 1024, "cached-4": 256}.get(form, 512), cfg
     for q, sq in enumerate(scans):
         po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
         assert same(pb[q], po), (q, sq.shape[0])

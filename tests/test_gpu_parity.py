@@ -430,6 +430,41 @@ def test_update_edge_cases_bit_exact(capi, oracle_mod, small_scene, kind):
     assert not lo_g.any() and (ui_g == -1).all() and (g.download_prob(0) == 0.5).all()
 
 
+def test_multi_level_update_at_the_low_map_edge_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
+    """Beams (and the begin cell) just outside the LOW x / y edge of level 0 are dropped there but valid on the coarser
+    levels: (int) truncates towards zero, so level k keeps an end point e (level-0 cell units) with e > -1.5 * 2^k.  The
+    multi-level updateByScan must not derive the coarse levels' apply boxes from level 0's box then (round-2 advisor
+    finding): every level bit-exact against the oracle, through the usual match -> update flow."""
+    sc = pyramid_scene
+    g = make_gpu(capi, sc, build=False)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
+    res, half = sc.resolution, sc.map_size // 2
+    rng = np.random.default_rng(5)
+    cases = []
+    for cx, cy, th in [(6.0, 9.0, 0.0), (5.2, 30.0, 0.3), (40.0, 4.4, -0.2), (-1.2, 7.0, 0.0), (7.0, -2.4, 0.1), (-2.0, -2.0, 0.0)]:
+        # robot at level-0 cell (cx, cy): the last three begin OFF the map at level 0 (cell -1 / -2) but inside at level 1 / 2
+        pose = np.array([(cx - half) * res, (cy - half) * res, th], np.float32)
+        ex = np.concatenate([np.linspace(-7.0, 4.0, 45), rng.uniform(-7.0, 60.0, 60)])
+        ey = np.concatenate([rng.uniform(-7.0, 60.0, 45), np.linspace(-7.0, 4.0, 60)])
+        c, s_ = np.cos(-th), np.sin(-th)
+        dx, dy = ex - cx, ey - cy
+        pts = np.stack([c * dx - s_ * dy, s_ * dx + c * dy], 1).astype(np.float32)  # robot frame, level-0 cell units
+        cases.append((pose, pts))
+    origo = np.zeros(2, np.float32)
+    for pose, pts in cases:
+        o.match(pose, pts, origo)  # retains the coarse containers (MapRepMultiMap.h:143)
+        g.matchData(pose, pts, None, origo)
+        o.update_by_scan(pose, pts, origo)
+        g.updateByScan(pts, pose, origo)
+    for lvl in range(sc.levels):
+        a, b = g.download_level(lvl), o.download_level(lvl)
+        assert (b[1] >= 0).sum() > 50, lvl
+        assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])), lvl
+        # the probability plane (and with it the texels) was rewritten wherever a cell changed
+        _, prob = oracle_mod.libm_expf(b[0].reshape(-1), o.kind)
+        assert np.array_equal(bits(g.download_prob(lvl)).reshape(-1), bits(prob)), lvl
+
+
 # ---------------------------------------------------------------- golden vectors
 def test_golden_config1(capi):
     g1 = np.load(os.path.join(GOLD, "config1_181beam_256map.npz"))
