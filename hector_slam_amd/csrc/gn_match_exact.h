@@ -1,27 +1,31 @@
-// gn_match_exact.h -- HSM_PARITY_EXACT for batches, texel-cache form (round 3).
+// gn_match_exact.h -- HSM_PARITY_EXACT for batches on LARGE maps: the exact-order matcher with the texel cache (round 3).
 //
 // What it computes: the same coarse-to-fine Gauss-Newton match as gn_match.h, with the nine sums of
 // OccGridMapUtil::getCompleteHessianDerivs (HSL/map/OccGridMapUtil.h:76-98) accumulated in the REFERENCE's order --
 // one fp32 chain per term, beam 0 .. n-1 -- so H, dTr, every GN step (ScanMatcher.h:194-221), the pose and the
-// covariance are bit-identical to the reference CPU matcher, at close to the throughput of the fast form.
+// covariance are bit-identical to the reference CPU matcher.
 //
-// How:
-//   * one wavefront per scan, NS scans per workgroup; every wavefront is a PRODUCER with gn_match_cached_kernel's
-//     machinery: the last texel + byte offset of each of its BPL beams per lane stay in VGPRs, exec-masked inline-asm
-//     gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the first kXRegRows rows in VGPRs: the
-//     LDS budget of 16 scans per CU does not hold all 17 rows next to the stage);
+// How (measurements and the variants that lost: profiles/r03/README.md):
+//   * one wavefront per scan, 8 scans per workgroup; every wavefront is a PRODUCER with gn_match_cached_kernel's
+//     machinery: the last texel + byte offset of its first BPC beams per lane stay in VGPRs (the other rows gather in
+//     every step), exec-masked inline-asm gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the
+//     first rows in VGPRs: the LDS share of 16 scans per CU does not hold all 17 rows next to the stage);
 //   * per ROUND k (beam k of every lane = beams 64k .. 64k+63 of the scan) a producer stages FOUR values per beam --
 //     gx, gy (the source's dM/dx, dM/dy), rotDeriv, funVal -- not the nine products: every product of :83-97 is a
 //     product of two of those four, so the chain lane multiplies (unfused, one rounding, like the reference) and adds;
 //     4 instead of 9 LDS rows per scan is what lets a triple-buffered stage and the endpoints of 16 scans share 160 KB;
-//   * the chains: 9 NS sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
-//     lane l runs chain-round unit u = 64 j + l, u = k * (9 NS) + (9 scan + term): jobs are PACKED across round
-//     boundaries, so all 64 lanes work (NS = 8: 72 chains per round = 1.125 jobs instead of two 36-lane jobs); a
-//     chain's running sum travels from job to job through LDS.  The jobs that complete with round k run right after
-//     round k's barrier on ONE wavefront (they depend on each other through the carried sums), the owner rotating
-//     from round to round, while the other wavefronts already produce round k+1.  A job may still read round k-1's
-//     rows, hence three stage buffers; one workgroup barrier per round.
+//   * the chains: 72 sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
+//     lane l runs chain-round unit u = 64 j + l, u = k * 72 + (9 scan + term): jobs are PACKED across round boundaries,
+//     so all 64 lanes work (1.125 jobs per round instead of two 36-lane jobs); a chain's running sum travels from job to
+//     job through LDS.  The jobs that complete with round k run right behind round k's barrier on ONE wavefront (they
+//     depend on each other through the carried sums), the owner rotating from round to round, while the other
+//     wavefronts already produce round k+1.  A job may still read round k-1's rows, hence three stage buffers; one
+//     workgroup barrier per round.
 //   Same arithmetic on the same texels in the same order as gn_match_kernel<.., EXACT>: identical bits.
+//   Against round 2's producer / chain-wavefront form (gn_match_exact_batch_kernel: endpoints streamed, no texel cache,
+//   nine staged products): 26 % fewer VALU instructions; 295 -> 217 us on the 4096^2 pyramid, whose gathers miss the L2,
+//   but 93 -> 100 us on the 2048^2 headline batch (the job sits on every round's critical path) -- so the host takes this
+//   form for maps above 2^23 cells only.
 #pragma once
 #include "gn_match.h"
 
@@ -34,19 +38,10 @@ constexpr unsigned kTermRowA = 0u | 1u << 2 | 2u << 4 | 0u << 6 | 1u << 8 | 2u <
 constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
 
 #ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
-#define HSM_XBPC 13
-#endif
-#ifndef HSM_XBPC4  // the same for 4 scans per workgroup (more endpoint rows in VGPRs: four stage buffers)
-#define HSM_XBPC4 14
+#define HSM_XBPC 14
 #endif
 #ifndef HSM_XLDS_AHEAD
 #define HSM_XLDS_AHEAD 1
-#endif
-#ifndef HSM_XJOB_SLOTS  // 16-byte LDS slots per row a chain job keeps in flight (8 VGPRs each)
-#define HSM_XJOB_SLOTS 3
-#endif
-#ifndef HSM_XWS_SPIN_LIMIT  // polls before a wait gives up (sets Smem::err -> NaN poses; nothing hangs)
-#define HSM_XWS_SPIN_LIMIT (1 << 22)
 #endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
@@ -55,20 +50,7 @@ constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u <
 // BPL rows of beams per lane, the first BPC of them with a cached texel (5 VGPRs per row: the chain jobs need ~28
 // VGPRs of their own for the LDS rows they keep in flight, which 17 cached rows + 4 endpoint rows do not leave at 128);
 // rows BPC .. BPL-1 gather in every step.
-//
-// SYNC = 0: one workgroup barrier per round; the jobs that complete with round k run behind barrier k on the wavefront
-//   (k + step) mod NS.  Measured: every round then lasts as long as its slowest member -- the owner's job (a 64-deep
-//   dependent chain) PLUS its own next round -- about twice the fast form's round (profiles/r03/README.md).
-// SYNC = 1 (default): no barriers.  Two monotonic LDS words couple the wavefronts:
-//   prog[w]    rounds wavefront w has staged (written behind its four rows: the LDS operations of a wavefront execute
-//              in order);
-//   jobs_done  chain jobs completed (a job publishes it behind its sums).
-//   Job G (global index, in order: it inherits running sums from job G - 1) belongs to wavefront G mod NS, which runs it
-//   as soon as it has itself staged the last round the job reads: it waits until jobs_done == G and every prog[] covers
-//   that round, runs the job, publishes.  A wavefront overwrites stage buffer k mod NB only once the jobs that read round
-//   k - NB are done, and reads its nine totals once the step's last job is.  Nobody waits for a wavefront that is merely
-//   slower: the producers drift like the fast form's wavefronts, up to NB - 1 rounds ahead of the chain.
-template <int NS, int BPL, int BPC = BPL, int SYNC = 1>
+template <int NS, int BPL, int BPC = BPL>
 __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
   constexpr int NC = 9 * NS;  // chains per workgroup
@@ -80,7 +62,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   constexpr int NB = NCP % 64 == 0 ? 2 : 3;
   // endpoint rows in VGPRs: what the LDS share of a workgroup (16 wavefronts per CU) does not hold next to the stage
   constexpr int kLdsShare = 160 * 1024 / (16 / NS);
-  constexpr int kRowsFit = (kLdsShare - NB * NS * 4 * kXRow * 4 - NC * 4 - NS * 4 - 64) / (NS * 512);
+  constexpr int kRowsFit = (kLdsShare - NB * NS * 4 * kXRow * 4 - NC * 4 - 64) / (NS * 512);
   constexpr int RV = BPL <= kRowsFit ? 0 : BPL - kRowsFit;
   static_assert(RV < BPL && RV <= 8, "endpoint rows kept in VGPRs");
   static_assert(64 * NS <= 1024, "one workgroup");
@@ -88,9 +70,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   struct alignas(16) Smem {
     float stage[NB][NS][4][kXRow];
     float runs[NC];
-    unsigned prog[NS];
-    unsigned jobs_done;
-    unsigned err;
     int nmax;
     f2 pts[NS][BPL - RV][64];
   };
@@ -120,12 +99,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   // wave-uniform values live in SGPRs: this kernel has no VGPR to spare
   pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(pw2);
   const float b0 = pw0, b1 = pw1, b2 = pw2;  // an empty scan passes its start estimate through (ScanMatcher.h:68,189)
-  if (threadIdx.x == 0) {
-    nmax_s = 0;
-    sm.jobs_done = 0;
-    sm.err = 0;
-  }
-  if (threadIdx.x < NS) sm.prog[threadIdx.x] = 0;
+  if (threadIdx.x == 0) nmax_s = 0;
   __syncthreads();
   if (lane == 0 && n > 0) atomicMax(&nmax_s, n);
   __syncthreads();
@@ -142,33 +116,8 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   // rounds for scans longer than the host's length hint
   const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
   const int units = rounds * NCP;
-  const int jobs_per_step = (units + 63) >> 6;
   const float2* __restrict__ pts = P.pts + beg;
   f2(*mine)[64] = lds_pts[wave];
-#if defined(HSM_EXP_XTIMING)  // experiment: per-wavefront cycle accounting, written over the covariance
-  unsigned long long xt_job = 0, xt_ready = 0, xt_wait = 0, xt_njobs = 0, xt_nwait = 0;
-  const unsigned long long xt_begin = __builtin_readcyclecounter();
-#define XT(x) x
-#else
-#define XT(x)
-#endif
-  unsigned my_job = (unsigned)wave;  // SYNC = 1: global index of the next chain job this wavefront owns
-  unsigned jobs_seen = 0;            // last value read from jobs_done (monotonic: a stale value can only under-report)
-  auto wait_jobs = [&](unsigned need) {
-    if ((int)(jobs_seen - need) >= 0) return;
-    XT(const unsigned long long t0 = __builtin_readcyclecounter();)
-    for (int spin = 0;; ++spin) {
-      jobs_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.jobs_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      if ((int)(jobs_seen - need) >= 0) break;
-      if (spin > HSM_XWS_SPIN_LIMIT) {
-        sm.err = 2;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    XT(xt_wait += __builtin_readcyclecounter() - t0; ++xt_nwait;)
-    asm volatile("" ::: "memory");  // what the jobs wrote is read after this point
-  };
   f2 pv[RV > 0 ? RV : 1];
 #pragma unroll
   for (int k = 0; k < BPL; ++k) {
@@ -216,8 +165,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       const f2 o2 = step_origin(ex, ey);
       const f2 e2 = f2{uniform_f32(o2.x), uniform_f32(o2.y)};
       const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
-      const unsigned job0 = (unsigned)(step_no * jobs_per_step);  // global index of the step's first job
-      const unsigned round0 = (unsigned)(step_no * rounds);       // rounds staged before this step
       auto endpoint = [&](int k) -> f2 { return k < RV ? pv[k < RV ? k : 0] : mine[k < RV ? 0 : k - RV][lane]; };
       // rotate, bounds test, cell offset, fractions; gather only in the lanes whose cell changed (gn_match_cached_kernel)
       f4v tu[2];  // texels of the uncached rows (k >= BPC), alternating
@@ -275,9 +222,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       //   rotDeriv = (-ry)*gx + rx*gy == rx*gy - ry*gx,  (rx, ry) = R(theta) p shared with the transform (gn_match.h)
       auto produce = [&](int k, float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy) {
         const int buf = k % NB;
-        // SYNC = 1: buffer k mod NB held round k - NB: the jobs that read it (the last one: the job of that round's
-        // last unit) must be done -- none for k < NB, the step's start waited for every job of the step before
-        if (SYNC == 1 && k >= NB) wait_jobs(job0 + (unsigned)(((k - NB + 1) * NCP - 1) >> 6) + 1u);
         const float xFacInv = 1.0f - fx, yFacInv = 1.0f - fy;
         const float M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
         const float gx = ((i1 - i0) * xFacInv) + ((i3 - i2) * fx);
@@ -297,14 +241,12 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
             : [m] "s"(st_wave + (unsigned)buf * (NS * 4 * kXRow * 4)), [a] "v"(gx), [b] "v"(gy), [c] "v"(rotDeriv), [d] "v"(funVal),
               [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4), [o3] "n"(3 * kXRow * 4)
             : "memory");  // M0 is reserved, not allocatable: nothing else in this kernel uses it (gfx9+ DS operations do not)
-        // relaxed workgroup-scope atomics on LDS = plain ds_write / ds_read.  (A volatile access through a generic
-        // pointer would be a system-scope FLAT access: slow, and it counts in vmcnt, which the inline-asm gathers own.)
-        if (SYNC == 1) __hip_atomic_store(&sm.prog[wave], round0 + (unsigned)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
       // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
-      // running sum.  The two rows stream through kSlots 16-byte slots each; the four products of slot q + 1 are computed
-      // BETWEEN the four additions of slot q (inline asm: the order is the point), so that the dependent chain is the
-      // additions alone -- v_add_f32 back to back costs ~4 cycles, a v_mul_f32 feeding the next v_add_f32 another 4.
+      // running sum.  The two rows stream through three 16-byte slots each (24 VGPRs): a slot is refilled right after its
+      // values are consumed, so a read has two compute periods to land in.  (Measured, profiles/r03/README.md: ~1 240
+      // cycles per job, loaded or not -- a single wavefront issues an instruction every 4-5 cycles -- and a hand-scheduled
+      // body with the multiplications one slot ahead of the additions is no faster.)
       auto chain_job = [&](int j) {
         // the lane index is re-read here (volatile asm): everything below depends on it, so the per-lane unit / address
         // arithmetic of the ~20 jobs of a step is not hoisted out of the GN loop into VGPRs that are not there
@@ -317,87 +259,27 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
           const float4* pa = reinterpret_cast<const float4*>(base + ra * kXRow);
           const float4* pb = reinterpret_cast<const float4*>(base + rb * kXRow);
           float run = ku == 0 ? 0.0f : runs[c];
-          constexpr int S = HSM_XJOB_SLOTS;
-          float4 a[S], b[S];
+          float4 a[3], b[3];
 #pragma unroll
-          for (int q = 0; q < S; ++q) a[q] = pa[q], b[q] = pb[q];
-          float p0 = a[0].x * b[0].x, p1 = a[0].y * b[0].y, p2 = a[0].z * b[0].z, p3 = a[0].w * b[0].w;
-          asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : : "memory");
-          if (S < 16) a[0] = pa[S], b[0] = pb[S];
+          for (int q = 0; q < 3; ++q) a[q] = pa[q], b[q] = pb[q];
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            if (q + 1 < 16) {
-              const float4 x = a[(q + 1) % S], y = b[(q + 1) % S];
-              float n0, n1, n2, n3;
-              asm volatile(
-                  "v_add_f32 %[r], %[r], %[p0]\n\t"
-                  "v_mul_f32 %[n0], %[x0], %[y0]\n\t"
-                  "v_add_f32 %[r], %[r], %[p1]\n\t"
-                  "v_mul_f32 %[n1], %[x1], %[y1]\n\t"
-                  "v_add_f32 %[r], %[r], %[p2]\n\t"
-                  "v_mul_f32 %[n2], %[x2], %[y2]\n\t"
-                  "v_add_f32 %[r], %[r], %[p3]\n\t"
-                  "v_mul_f32 %[n3], %[x3], %[y3]"
-                  : [r] "+v"(run), [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3)
-                  : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [x0] "v"(x.x), [x1] "v"(x.y), [x2] "v"(x.z),
-                    [x3] "v"(x.w), [y0] "v"(y.x), [y1] "v"(y.y), [y2] "v"(y.z), [y3] "v"(y.w)
-                  : "memory");
-              p0 = n0, p1 = n1, p2 = n2, p3 = n3;
-              if (q + 1 + S < 16) a[(q + 1) % S] = pa[q + 1 + S], b[(q + 1) % S] = pb[q + 1 + S];  // the slot just consumed
-              asm volatile("" ::: "memory");
-            } else {
-              run += p0;
-              run += p1;
-              run += p2;
-              run += p3;
-            }
+            const float4 x = a[q % 3], y = b[q % 3];
+            run += x.x * y.x;
+            run += x.y * y.y;
+            run += x.z * y.z;
+            run += x.w * y.w;
+            // fences: a refill stays behind the use of its slot and in its own period (the scheduler would hoist all 32 reads)
+            asm volatile("" : "+v"(run) : : "memory");
+            if (q + 3 < 16) a[q % 3] = pa[q + 3], b[q % 3] = pb[q + 3];
+            asm volatile("" ::: "memory");
           }
           runs[c] = run;
         }
       };
-      // round k is staged.  SYNC = 0: meet, then (one wavefront) run the chain jobs that are complete with it.
-      // SYNC = 1: run the jobs this wavefront owns whose last round it has now staged itself.
+      // round k is staged: meet, then (one wavefront) run the chain jobs that are complete with it
       auto round_done = [&](int k, bool last_round) {
-#if defined(HSM_EXP_XNOBAR)  // experiment: production alone (results are garbage)
-        return;
-#endif
-        if (SYNC == 1) {
-          for (;;) {
-            const int j = (int)(my_job - job0);  // >= 0: every job of the steps before has been run
-            if (j >= jobs_per_step) break;
-            const int last_unit = 64 * j + 63 < units ? 64 * j + 63 : units - 1;
-            const int r = last_unit / NCP;
-            if (r > k) break;  // reads a round this wavefront has yet to stage
-            const unsigned need = round0 + (unsigned)r + 1u;
-            XT(const unsigned long long t0 = __builtin_readcyclecounter();)
-            for (int spin = 0;; ++spin) {
-              const unsigned jd = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.jobs_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-              const unsigned pr = __hip_atomic_load(&sm.prog[lane_id_now() & (NS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (jd == my_job && __builtin_amdgcn_ballot_w64((int)(pr - need) < 0) == 0ull) break;
-              if (spin > HSM_XWS_SPIN_LIMIT) {
-                sm.err = 1;
-                break;
-              }
-              __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-            XT(const unsigned long long t1 = __builtin_readcyclecounter(); xt_ready += t1 - t0;)
-            __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
-            chain_job(j);
-            __builtin_amdgcn_s_setprio(0);
-            XT(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); xt_job += __builtin_readcyclecounter() - t1; ++xt_njobs;)
-            // published behind the sums: the LDS operations of a wavefront execute in program order
-            asm volatile("" ::: "memory");
-            jobs_seen = my_job + 1u;
-            __hip_atomic_store(&sm.jobs_done, jobs_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            my_job += NS;
-          }
-          return;
-        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#if defined(HSM_EXP_XNOJOB)  // experiment: production + barriers, no chain jobs (results are garbage)
-        return;
-#endif
         const int j_lo = (k * NCP) >> 6;
         const int j_hi = last_round ? (units + 63) >> 6 : ((k + 1) * NCP) >> 6;
         if (j_lo >= j_hi) return;
@@ -443,10 +325,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         produce(k, b.lo.x, b.lo.y, b.hi.x, b.hi.y, r, b.X.y, b.Y.y);
         round_done(k, k == rounds - 1);
       }
-      if (SYNC == 1)
-        wait_jobs(job0 + (unsigned)jobs_per_step);  // the step's last job has published the totals
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last jobs have published the totals
       {
         const float* tt = &runs[9 * wave];
         acc.d01 = f2{uniform_f32(tt[0]), uniform_f32(tt[1])};
@@ -465,7 +344,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   }
   if (active && lane == 0) {
     const bool empty = n == 0;
-    if (SYNC == 1 && sm.err != 0) pw0 = pw1 = pw2 = __int_as_float(0x7fc00000);  // a wait gave up: fail loudly, not plausibly
     P.out_pose[3 * scan + 0] = empty ? b0 : pw0;
     P.out_pose[3 * scan + 1] = empty ? b1 : pw1;
     P.out_pose[3 * scan + 2] = empty ? b2 : pw2;
@@ -474,14 +352,8 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
-#if defined(HSM_EXP_XTIMING)
-      unsigned* uu = reinterpret_cast<unsigned*>(c);
-      uu[0] = (unsigned)(__builtin_readcyclecounter() - xt_begin);
-      uu[1] = (unsigned)xt_job; uu[2] = (unsigned)xt_njobs; uu[3] = (unsigned)xt_ready; uu[4] = (unsigned)xt_wait; uu[5] = (unsigned)xt_nwait;
-#endif
     }
   }
-#undef XT
 }
 
 }  // namespace hsm

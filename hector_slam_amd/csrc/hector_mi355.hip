@@ -168,8 +168,7 @@ struct hsm_ctx {
   int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
-  int exact_sync = 1;            // env HSM_EXACT_SYNC=0|1: 0 = one workgroup barrier per round, 1 = LDS progress words, no barriers
-  int exact_cached = 8;          // env HSM_EXACT_CACHED=0|4|8|16: scans per workgroup of the texel-cache exact form (gn_match_exact.h); 0 = round 2's producer / chain workgroups
+  int exact_cached = -1;         // env HSM_EXACT_CACHED=0|1: the texel-cache exact form (gn_match_exact.h) never / always; -1 = on maps above 2^23 cells
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -343,20 +342,11 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
-template <int NS, int BPL, int BPC, int SYNC>
-int launch_match_exact_cached_s(hsm_ctx* h, MatchParams P, hipStream_t stream);
-
 template <int NS, int BPL, int BPC = BPL>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
-  if (h->exact_sync == 0) return launch_match_exact_cached_s<NS, BPL, BPC, 0>(h, P, stream);
-  return launch_match_exact_cached_s<NS, BPL, BPC, 1>(h, P, stream);
-}
-
-template <int NS, int BPL, int BPC, int SYNC>
-int launch_match_exact_cached_s(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   const int grid = (P.batch + NS - 1) / NS, block = 64 * NS;
   if (P.xcd_chunk > 0) P.xcd_chunk = P.xcd_chunk * 4 / NS > 0 ? P.xcd_chunk * 4 / NS : 1;  // chunks of the same number of scans
-  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, SYNC>), dim3(grid), dim3(block), 0, stream, P);
+  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
   h->last_cfg[0] = h->layout;
   h->last_cfg[1] = 1;
@@ -369,21 +359,13 @@ int launch_match_exact_cached_s(hsm_ctx* h, MatchParams P, hipStream_t stream) {
 
 template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  // throughput launches of the quad layout: every wavefront a producer with the texel cache, packed chain jobs
-  // (gn_match_exact.h); scans of up to 17 beams per lane (longer ones stream their tail)
-  if (WPS == 1 && P.begin_world && !P.trace && h->exact_cached && h->layout == kLayoutQuad && h->bpl_override != 0) {
+  // throughput launches of the quad layout on maps whose gathers miss the L2: every wavefront a producer with the texel
+  // cache, packed rotating chain jobs (gn_match_exact.h; 4096^2 pyramid 295 -> 217 us).  On smaller maps round 2's form
+  // below is the faster one (2048^2 headline 93 vs 100 us).  env HSM_EXACT_CACHED=0|1 pins the choice.
+  if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 &&
+      (h->exact_cached == 1 || (h->exact_cached < 0 && h->levels[0].cells() > ((size_t)1 << 23)))) {
     const int per_lane = (max_n + 63) / 64;
-    if (per_lane <= 17 + 4) {
-      if (h->exact_cached == 16) {
-        if (per_lane <= 5) return launch_match_exact_cached<16, 5>(h, P, stream);
-        if (per_lane <= 9) return launch_match_exact_cached<16, 9>(h, P, stream);
-        return launch_match_exact_cached<16, 17, HSM_XBPC>(h, P, stream);
-      }
-      if (h->exact_cached == 4) {
-        if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
-        if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
-        return launch_match_exact_cached<4, 17, HSM_XBPC4>(h, P, stream);
-      }
+    if (per_lane <= 17 + 4) {  // scans of up to 17 beams per lane (up to four rows more stream their tail)
       if (per_lane <= 5) return launch_match_exact_cached<8, 5>(h, P, stream);
       if (per_lane <= 9) return launch_match_exact_cached<8, 9>(h, P, stream);
       return launch_match_exact_cached<8, 17, HSM_XBPC>(h, P, stream);
@@ -777,8 +759,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
-  if (const char* env = getenv("HSM_EXACT_SYNC")) h->exact_sync = atoi(env) != 0;
-  if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) == 16 ? 16 : (atoi(env) == 4 ? 4 : (atoi(env) ? 8 : 0));
+  if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
   if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;

@@ -121,12 +121,12 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
         assert same(pg, po) and same(cg, co), it
 
 
-@pytest.mark.parametrize("form", ["auto", "cached", "cached-4", "cached-16", "cached-tail", "cached-barrier", "throughput", "throughput-8+2",
+@pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "throughput", "throughput-8+2",
                                   "throughput-plane", "one-wave-per-scan"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
-    a small batch picks by itself ("auto"), the texel-cache exact form (gn_match_exact.h: every wavefront a producer,
-    packed chain jobs; 8 or 16 scans per workgroup, 17 scans = a partial last workgroup; "cached-tail": scans up to four
+    a small batch picks by itself ("auto"), the texel-cache exact form large maps take (gn_match_exact.h: every wavefront a
+    producer, packed rotating chain jobs; 17 scans = two full workgroups and a partial one; "cached-tail": scans up to four
     rows longer than the 17 cached ones stream their tail), round 2's wave-specialised forms (seven producer wavefronts +
     one chain wavefront per workgroup, or eight + two), and the one-wavefront-per-scan form"""
     from hector_slam_amd import synth
@@ -134,8 +134,7 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     o = make_oracle(oracle_mod, kind, sc)
     if form == "one-wave-per-scan":
         monkeypatch.setenv("HSM_EXACT_BATCH", "0")
-    monkeypatch.setenv("HSM_EXACT_CACHED", {"cached": "8", "cached-4": "4", "cached-16": "16", "cached-tail": "8", "cached-barrier": "8", "auto": "8"}.get(form, "0"))
-    monkeypatch.setenv("HSM_EXACT_SYNC", "0" if form == "cached-barrier" else "1")
+    monkeypatch.setenv("HSM_EXACT_CACHED", "1" if form in ("cached", "cached-tail", "auto") else "0")
     monkeypatch.setenv("HSM_EXACT_SHAPE", "8" if form == "throughput-8+2" else "7")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
     if form == "throughput-plane":
@@ -163,7 +162,7 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         assert g.last_launch_config()["block"] == (640 if form == "throughput-8+2" else 512), g.last_launch_config()
     if form.startswith("cached"):
         cfg = g.last_launch_config()
-        assert cfg["texel_cache"] and cfg["block"] == {"cached-16": 1024, "cached-4": 256}.get(form, 512), cfg
+        assert cfg["texel_cache"] and cfg["block"] == 512, cfg
     for q, sq in enumerate(scans):
         po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
         assert same(pb[q], po), (q, sq.shape[0])

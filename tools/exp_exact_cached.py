@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of the exact-order batch kernels on the bench workloads (GPU box):
-    python tools/exp_exact_cached.py [config3 config3pyr config4] [--variants "HSM_EXACT_CACHED=0;HSM_EXACT_CACHED=8;..."]
+    python tools/exp_exact_cached.py [config3 config3pyr config4] [--variants "HSM_EXACT_CACHED=0;HSM_EXACT_CACHED=1"]
 For every workload: the fast mode, then every variant (env settings applied before the context is created) in
 HSM_PARITY_EXACT -- kernel time (HIP events, back-to-back launches) and whether all poses / covariances equal the first
 variant's bit for bit (the first variant should be the round-2 form, which the full-size tests pin to the reference).
@@ -61,7 +61,7 @@ def context(w, env):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("workloads", nargs="*", default=["config3", "config3pyr", "config4"])
-    ap.add_argument("--variants", default="HSM_EXACT_CACHED=0;HSM_EXACT_CACHED=8;HSM_EXACT_CACHED=16")
+    ap.add_argument("--variants", default="HSM_EXACT_CACHED=0;HSM_EXACT_CACHED=1")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=0, help="scans per launch (default: the workload's)")
     args = ap.parse_args()
@@ -117,10 +117,6 @@ def main():
             if env is not None and vi == 1:
                 dd = np.abs(fast_pose.astype(np.float64) - pose)
                 rec["fast_within_1e-4"] = float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean())
-            if os.environ.get("HSM_EXP_XTIMING") and env is not None:
-                u = cov.view(np.uint32)[:, :6].astype(np.float64)
-                rec["xtiming_mean"] = {k: float(u[:, i].mean()) for i, k in enumerate(["total_cyc", "job_cyc", "njobs", "ready_wait_cyc", "jobs_wait_cyc", "nwaits"])}
-                rec["xtiming_max"] = {k: float(u[:, i].max()) for i, k in enumerate(["total_cyc", "job_cyc", "njobs", "ready_wait_cyc", "jobs_wait_cyc", "nwaits"])}
             print(json.dumps(rec), flush=True)
             del m
 
