@@ -268,6 +268,10 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         if nranks > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if args.leg == "pmc":  # counter pass of the parent: the launches above are all it wants
+            m.close()
+            torch.cuda.synchronize()
+            return
         if nranks > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -290,6 +294,19 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         t_match = float(np.median(tm)) * args.steps
         t_upd = dt - t_match
         nb = float(np.mean([s_.shape[0] for s_ in scans[1:]]))
+        # what one updateByScan touches (16 B per distinct touched cell + 8 B per beam): one more update,
+        # then count the cells that carry its two stamps (OccGridMapBase.h:167: currUpdateIndex + 1 / + 2), per level
+        m.matchData(gpu_poses[-1], scans[T])
+        m.updateByScan(scans[T], gpu_poses[-1])
+        m.synchronize()
+        touched, boxes = [], []
+        for lvl in range(levels):
+            _, ui = m.download_level(lvl)
+            touched.append(int((ui >= int(ui.max()) - 1).sum()))
+            bb = m.last_update_bbox(lvl)
+            boxes.append(int(max(0, bb[2] - bb[0] + 1) * max(0, bb[3] - bb[1] + 1)))
+            del ui
+        upd_alg_bytes = 16 * sum(touched) + 8 * int(nb) * levels
         out.update({"value": args.steps * its / dt, "ms_per_step": dt / args.steps * 1e3,
                     "config": {"workload": f"configs[4] (one replica): dense {beams}-beam scans (mean {nb:.0f} valid), "
                                            f"{size}^2 map, {levels} levels, matchData + updateByScan interleaved",
@@ -299,7 +316,39 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                     "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9, "traffic": None,
                                  "achieved": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / 1e9,
                                  "frac": algorithmic_bytes_per_iteration(int(nb)) * its / (t_match / args.steps) / HBM_PEAK,
-                                 "note": "host-call latency of ONE scan (H2D + launch + D2H), not a throughput kernel"}})
+                                 "note": "matchData: host-call latency of ONE scan (cooperative launch), not a throughput kernel"}})
+        # the update is 3/4 of a step: its own roofline -- algorithmic bytes of one updateByScan (all levels) against the
+        # summed duration and the summed HBM traffic of its kernels, from counter passes around `--workload config5 --leg pmc`
+        upd = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+               "algorithmic_bytes_per_update": upd_alg_bytes, "touched_cells_per_level": touched, "dense_box_cells_per_level": boxes,
+               "dense_box_over_touched": sum(boxes) / max(sum(touched), 1), "beams": int(nb),
+               "achieved": upd_alg_bytes / (t_upd / args.steps) / 1e9, "frac": upd_alg_bytes / (t_upd / args.steps) / HBM_PEAK,
+               "time_basis": "update_ms of the step (host timed: step - matchData)", "traffic": None, "kernels": None}
+        if not args.no_pmc and nranks == 1 and not under_profiler():
+            names = ["update_mark_occ_kernel", "update_mark_free_kernel", "update_mark_kernel", "update_apply_kernel",
+                     "update_texels_kernel", "gn_match_coop_kernel"]
+            pv, perr = pmc_collect(["--workload", "config5", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=2)
+            if pv:
+                ks, tot_ns, tot_hbm = {}, 0.0, 0.0
+                for k, v in pv.items():
+                    h = hbm_block(v, None, max(v.get("avg_ns", 0.0), 1.0) * 1e-9)
+                    ks[k] = {"avg_us": v.get("avg_ns", 0.0) / 1e3, "launches": v.get("avg_ns_launches"),
+                             "hbm_bytes_per_launch": h["bytes_per_launch"] if h else None,
+                             "hbm_GBps": h["achieved_GBps"] if h else None,
+                             "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"), "SQ_WAVES": v.get("SQ_WAVES")}
+                    if k.startswith("update_") and h:
+                        tot_ns += v.get("avg_ns", 0.0)
+                        tot_hbm += h["bytes_per_launch"]
+                upd["kernels"] = ks
+                if tot_ns > 0:
+                    upd.update({"traffic": tot_hbm, "traffic_over_algorithmic": tot_hbm / upd_alg_bytes,
+                                "kernel_time_us": tot_ns / 1e3, "achieved": upd_alg_bytes / (tot_ns * 1e-9) / 1e9,
+                                "frac": upd_alg_bytes / (tot_ns * 1e-9) / HBM_PEAK,
+                                "hbm_frac_measured": tot_hbm / (tot_ns * 1e-9) / HBM_PEAK,
+                                "time_basis": "summed average duration of the update kernels (rocprofv3 kernel trace of the counter passes)"})
+            if perr:
+                upd["pmc_errors"] = perr
+        out["update_roofline"] = upd
         if not args.no_cpu and nranks == 1:
             o, kind = cpu_oracle()
             o.proc_set_thresholds(0.0, 0.0)
@@ -308,7 +357,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                 o.update_by_scan(allp[k], alls[k])
                 o.on_map_updated()  # HectorSlamProcessor.h:93 -- the reference's probability cache must be dropped
             pose = poses[0]
-            n_cpu = min(T, 12)
+            n_cpu = min(T, 3 if args.compact else 12)
             dmax = 0.0
             t0 = time.perf_counter()
             for t in range(1, n_cpu + 1):
@@ -344,6 +393,14 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                                0.05 if levels > 1 else 0.01)
     pts, offs = synth.pack_scans(scans)
 
+    if name == "config2" and args.leg == "pmc":  # counter pass of the parent: the match + update cycle, nothing else
+        for k in range(60):
+            q = k % len(build_scans)
+            m.matchData(build_poses[q], build_scans[q])
+            m.updateByScan(build_scans[q], build_poses[q])
+            m.onMapUpdated()
+        m.synchronize()
+        return
     if name == "config2":
         # one scan at a time through the host entry (what the ROS node calls): latency
         lat = []
@@ -389,7 +446,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         # the reference's CPU map representation and once on the drop-in facade (no Python in the timed calls)
         try:
             import subprocess
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "node_cycle_bench.py"), "400"],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "node_cycle_bench.py"), "200" if args.compact else "400"],
                                capture_output=True, text=True, timeout=240)
             out["node_loop_cpp"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         except Exception as e:  # the two drivers are prebuilt where /root/reference exists
@@ -405,13 +462,31 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                                  "achieved": algorithmic_bytes_per_iteration(beams) * its / float(np.median(lat)) / 1e9,
                                  "frac": algorithmic_bytes_per_iteration(beams) * its / float(np.median(lat)) / HBM_PEAK,
                                  "note": "single-scan latency is launch/PCIe bound by construction"}})
+        if not args.no_pmc and not under_profiler():
+            # the node's cycle kernel by kernel: duration, instructions, HBM bytes (counter passes around `--leg pmc`)
+            names = ["gn_match_kernel", "update_mark_kernel", "update_apply_kernel", "update_texels_kernel"]
+            pv, perr = pmc_collect(["--workload", "config2", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=5)
+            if pv:
+                out["roofline"]["kernels"] = {
+                    k: {"avg_us": v.get("avg_ns", 0.0) / 1e3, "launches": v.get("avg_ns_launches"),
+                        "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"), "SQ_WAVES": v.get("SQ_WAVES"),
+                        "hbm_bytes_per_launch": (hbm_block(v, None, 1.0) or {}).get("bytes_per_launch")} for k, v in pv.items()}
+                mk = pv.get("gn_match_kernel")
+                if mk and mk.get("avg_ns"):
+                    alg = algorithmic_bytes_per_iteration(beams) * its
+                    h = hbm_block(mk, alg, mk["avg_ns"] * 1e-9)
+                    out["roofline"].update({"kernel": "gn_match_kernel (4 waves, one CU: 14 dependent GN steps)", "kernel_us": mk["avg_ns"] / 1e3,
+                                            "achieved": alg / (mk["avg_ns"] * 1e-9) / 1e9, "frac": alg / (mk["avg_ns"] * 1e-9) / HBM_PEAK,
+                                            "traffic": h["bytes_per_launch"] if h else None})
+            if perr:
+                out["roofline"]["pmc_errors"] = perr
         if not args.no_cpu:
             o, kind = cpu_oracle()
             o.build_map(build_poses, build_scans)
             for q in range(8):
                 o.match(init[q], scans[q])
             t0 = time.perf_counter()
-            n_cpu = 2000
+            n_cpu = 500 if args.compact else 2000
             for k in range(n_cpu):
                 o.match(init[k % nq], scans[k % nq])
             dtc = time.perf_counter() - t0
@@ -467,6 +542,11 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             dt = float(tt.item())
         return dt, ev0.elapsed_time(ev1) / steps  # back-to-back launches: average duration per launch
 
+    if args.leg == "pmc":  # counter pass of the parent: fast-mode launches, then exact-mode launches
+        timed(args.steps, 3)
+        m.set_parity(capi.PARITY_EXACT)
+        timed(max(3, args.steps // 2), 2)
+        return
     dt, kern_ms = timed(args.steps, args.warmup)
     bytes_per_launch = algorithmic_bytes_per_iteration(beams) * its * B
     gpu_pose = d_pose.cpu().numpy()
@@ -479,13 +559,14 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                                        + (" = BASELINE configs[3] at 8 GPUs" if name == "config4" else ""),
                            "batch_per_gpu": B, "global_batch": total, "beams": beams, "map": size, "levels": levels,
                            "gn_iterations_per_scan": its, "parallelism": f"dp{nranks}", "kernel": cfg},
-                "roofline": {"bound": "valu" if size <= 2048 else "l2/hbm gather latency", "kernel_ms": kern_ms,
-                             "kernel": "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel",
-                             "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                             "note": "counters for this workload: tools/pmc_config4.sh -> profiles/r02 (DESIGN.md 5)",
-                             "contract": {"bound": "hbm", "algorithmic_bytes_per_launch": bytes_per_launch,
-                                          "achieved": bytes_per_launch / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                                          "unit": "GB/s", "frac": bytes_per_launch / (kern_ms * 1e-3) / HBM_PEAK}}})
+                })
+    fast_kernel = "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
+    pv = perr = None
+    if rank == 0 and nranks == 1 and not args.no_pmc and not under_profiler():
+        pv, perr = pmc_collect(["--workload", name, "--leg", "pmc", "--no-cpu", "--no-pmc", "--steps", str(min(args.steps, 10))],
+                               ["gn_match_exact_cached_kernel", "gn_match_exact_batch_kernel", "gn_match_cached_kernel", "gn_match_kernel"])
+    clock_hz = m.device_info()["clock_khz"] * 1e3
+    out["roofline"] = roofline_block(fast_kernel, kern_ms, bytes_per_launch, beams, its, B, (pv or {}).get(fast_kernel), perr, clock_hz)
     if rank == 0 and not args.no_exact:
         m.set_parity(capi.PARITY_EXACT)
         steps_x = max(5, args.steps // 3)
@@ -493,7 +574,12 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         if nranks == 1:
             exact_pose = d_pose.cpu().numpy().copy()
             dd = np.abs(gpu_pose.astype(np.float64) - exact_pose)
-            out["exact_parity"] = {"value": B * its * steps_x / dtx, "unit": "GN it/s", "kernel_ms": kx,
+            xk = m.last_launch_config()
+            xname = "gn_match_exact_cached_kernel" if xk.get("texel_cache") else "gn_match_exact_batch_kernel"
+            out["exact_parity"] = {"value": B * its * steps_x / dtx, "unit": "GN it/s", "kernel_ms": kx, "kernel": xname,
+                                   "roofline": {k: v for k, v in roofline_block(xname, kx, bytes_per_launch, beams, its, B, (pv or {}).get(xname),
+                                                                                  None, clock_hz).items()
+                                                if k in ("kernel", "kernel_ms", "bound", "unit", "achieved", "peak", "frac", "traffic", "hbm", "valu", "counter_source")},
                                    "fast_vs_exact_all_scans": {
                                        "scans": B, "bit_identical": float((gpu_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
                                        "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
@@ -502,7 +588,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
     if not args.no_cpu and nranks == 1:
         o, kind = cpu_oracle()
         o.build_map(build_poses, build_scans)
-        n_cpu = min(B, 1024)
+        n_cpu = min(B, 256 if args.compact else 1024)
         o.match_many(init[:64], pts, offs[:65])
         t0 = time.perf_counter()
         cpu_pose = o.match_many(init[:n_cpu], pts, offs[:n_cpu + 1])
@@ -541,8 +627,11 @@ def run_child(extra_args, timeout_s=300, env=None):
     return json.loads(lines[-1])
 
 
-def pmc_leg(kernel_name: str, steps: int = 20, warmup: int = 3):
-    """mean counter values per launch of `kernel_name`, collected by rocprofv3 around `bench.py --leg pmc`"""
+def pmc_collect(child_args, kernels, warmup: int = 3, timeout_s: int = 300):
+    """Counter passes around a child of this script: `rocprofv3 --kernel-trace --pmc <group> -- python bench.py <child_args>`,
+    one pass per group of PMC_GROUPS (FETCH_SIZE and WRITE_SIZE do not fit one pass).  `kernels` = substrings of kernel
+    names, most specific first; a dispatch is attributed to the first one it contains.  Returns ({key: {counter: mean per
+    launch, counter_launches: n, "avg_ns": mean duration from the same passes' kernel trace}}, errors)."""
     import csv
     import glob
     import shutil
@@ -551,35 +640,76 @@ def pmc_leg(kernel_name: str, steps: int = 20, warmup: int = 3):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
-    vals, errors = {}, []
-    for group in PMC_GROUPS:
+
+    def key_of(name):
+        for k in kernels:
+            if k in name:
+                return k
+        return None
+
+    vals, errors = {k: {} for k in kernels}, []
+    # durations come from a pass WITHOUT counters (group None): under --pmc the dense update kernels run up to 6x longer
+    for group in (None,) + tuple(PMC_GROUPS):
         with tempfile.TemporaryDirectory(prefix="hsm_pmc_", dir="/tmp") as d:
-            cmd = [rocprof, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "--",
-                   sys.executable, os.path.abspath(__file__), "--leg", "pmc", "--steps", str(steps), "--warmup", str(warmup)]
+            cmd = [rocprof, "--kernel-trace"] + (["--pmc", *group] if group else []) + ["--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__)] + list(child_args)
             env = dict(os.environ, TMPDIR="/tmp")
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd="/tmp", env=env)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
             except subprocess.TimeoutExpired:
-                errors.append(f"{group[0]}: timeout")
+                errors.append(f"{group[0] if group else 'kernel-trace'}: timeout")
                 continue
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                errors.append(f"{group[0]}: rc={r.returncode} {r.stderr.strip()[-200:]}")
+            gname = group[0] if group else "kernel-trace"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv" if group else "*kernel_trace.csv"), recursive=True)
+            if not files:
+                errors.append(f"{gname}: rc={r.returncode} {r.stderr.strip()[-200:]}")
                 continue
-            acc = {}
-            for f in files:
+            if r.returncode != 0:  # (a child that dies in its exit handlers has delivered its output already)
+                errors.append(f"{gname}: child rc={r.returncode}, output was written")
+            acc = {k: {} for k in kernels}
+            for f in (files if group else []):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if kernel_name in row.get("Kernel_Name", ""):
-                            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            for c, v in acc.items():
-                v = v[warmup:] if len(v) > warmup else v  # first launches touch cold L2 / page tables
-                vals[c] = sum(v) / len(v)
-                vals[c + "_launches"] = len(v)
-    return (vals or None), ("; ".join(errors) or None)
+                        k = key_of(row.get("Kernel_Name", ""))
+                        if k is not None:
+                            acc[k].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            dur = {k: [] for k in kernels}
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = key_of(row.get("Kernel_Name", ""))
+                        if k is not None:
+                            dur[k].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+            for k in kernels:
+                for c, v in acc[k].items():
+                    v = v[warmup:] if len(v) > warmup else v  # first launches touch cold L2 / page tables
+                    vals[k][c] = sum(v) / len(v)
+                    vals[k][c + "_launches"] = len(v)
+                if dur[k] and group is None:
+                    v = dur[k][warmup:] if len(dur[k]) > warmup else dur[k]
+                    vals[k]["avg_ns"] = sum(v) / len(v)
+                    vals[k]["avg_ns_launches"] = len(v)
+    return ({k: v for k, v in vals.items() if v} or None), ("; ".join(errors) or None)
 
 
-def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pmc, pmc_err, clock_hz, sclk_hz=None):
+def pmc_leg(kernel_name: str, steps: int = 20, warmup: int = 3):
+    """mean counter values per launch of `kernel_name`, collected by rocprofv3 around `bench.py --leg pmc`"""
+    vals, err = pmc_collect(["--leg", "pmc", "--steps", str(steps), "--warmup", str(warmup)], [kernel_name], warmup)
+    return (vals or {}).get(kernel_name), err
+
+
+def hbm_block(pmc, algorithmic_bytes, seconds):
+    """HBM traffic of one kernel from its FETCH_SIZE / WRITE_SIZE passes (KB; gfx950: reads tallied at half their size)"""
+    if not pmc or "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
+        return None
+    hbm = 2.0 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024
+    return {"bytes_per_launch": hbm, "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"], "fetch_correction": 2.0,
+            "achieved_GBps": hbm / seconds / 1e9, "peak_GBps": HBM_PEAK / 1e9, "frac": hbm / seconds / HBM_PEAK,
+            "traffic_over_algorithmic": hbm / algorithmic_bytes if algorithmic_bytes else None}
+
+
+def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pmc, pmc_err, clock_hz, sclk_hz=None,
+                   committed_profile=None):
     """see the module docstring: VALU-issue utilisation + in-run HBM traffic + the labelled SURVEY 8(d) contract figure"""
     t = kern_ms * 1e-3
     # algorithmic fp32 operations: 51 per beam and GN iteration (25 mul + 26 add/sub, unfused by construction) +
@@ -620,14 +750,16 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
                           "cycles_per_wave64_instr": (pmc["SQ_ACTIVE_INST_VALU"] * 4 / pmc["SQ_INSTS_VALU"]
                                                       if pmc.get("SQ_ACTIVE_INST_VALU") else None),
                           "full_rate_cycles_per_wave64_instr": 2, "source": src}
-    if rf["frac"] is None:
+    if rf["frac"] is None and committed_profile is None:
+        rf["counter_source"] = "none" + (": " + pmc_err if pmc_err else "")
+    elif rf["frac"] is None:
         # no counters in this run (nested profiler, rocprofv3 missing, ...): the committed profile of this workload
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic.json")))[kernel_name]
+            tj = json.load(open(os.path.join(ROOT, "profiles", committed_profile, "traffic.json")))[kernel_name]
             rf["traffic"] = tj["hbm_bytes_per_launch"]
             rf["achieved"] = tj["SQ_INSTS_VALU_per_launch"] / t / 1e9
             rf["frac"] = tj["SQ_INSTS_VALU_per_launch"] * 2 / (1024 * clock_hz * t)
-            rf["counter_source"] = "profiles/r02/traffic.json (committed PMC profile of this workload; no counters in this run" + \
+            rf["counter_source"] = f"profiles/{committed_profile}/traffic.json (committed PMC profile of this workload; no counters in this run" + \
                 (": " + pmc_err if pmc_err else "") + ")"
         except (OSError, KeyError, ValueError):
             rf["counter_source"] = "none" + (": " + pmc_err if pmc_err else "")
@@ -659,6 +791,10 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the HSM_PARITY_EXACT leg")
     ap.add_argument("--streams", type=int, default=4, help="caller-owned streams of the `pipelined` leg")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream leg")
+    ap.add_argument("--compact", action="store_true",
+                    help="extra workloads: the short form the default run embeds (fewer steps, smaller CPU samples)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs for the other BASELINE configs")
+    ap.add_argument("--no-relaxed", action="store_true", help="skip the HSM_PARITY_RELAXED leg")
     ap.add_argument("--leg", default=None, choices=["pmc", "pyramid", "pipelined"],
                     help="internal: a leg of the default run executed in a child process")
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS),
@@ -666,8 +802,12 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.workload == "config3" and args.leg != "pyramid" else 30
+        if args.workload != "config3" and (args.compact or args.leg == "pmc"):
+            args.steps = {"config2": 150, "config5": 6}.get(args.workload, 10)
     if args.warmup is None:
         args.warmup = 10 if args.workload == "config3" else 5
+        if args.workload == "config5" and (args.compact or args.leg == "pmc"):
+            args.warmup = 2
 
     import torch
     import torch.distributed as dist
@@ -869,7 +1009,7 @@ def main():
                    "kernel": cfg},
         "matchdata_per_s": total * args.steps / dt,
         "roofline": roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
-                                   sclk_hz=headline_sclk),
+                                   sclk_hz=headline_sclk, committed_profile="r03"),
     }
     conv = np.abs(gpu_pose.astype(np.float64) - truth.astype(np.float64))
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
@@ -894,6 +1034,24 @@ def main():
         if not args.no_cpu:
             out["exact_parity"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init if args.levels == 1 else init_pyr,
                                                                 pts, offs, exact_pose, args.levels, budget_s=0.0, n_par=512)
+    if single and not args.no_relaxed and args.levels == 1:
+        # HSM_PARITY_RELAXED (opt-in): multiply-add pairs of the per-beam arithmetic contracted; bar = 1e-4 m / 1e-4 rad
+        matcher.set_parity(capi.PARITY_RELAXED)
+        steps_r = max(10, args.steps // 4)
+        dtr, kr, _ = run(matcher, d_init_l0, steps_r, 3)
+        relaxed_pose = d_pose.cpu().numpy().copy()
+        matcher.set_parity(capi.PARITY_FAST)
+        out["relaxed"] = {"mode": "HSM_PARITY_RELAXED: v_fma_f32 for the rotation, blends, rotDeriv and the nine accumulations (32 "
+                                  "instead of 51 fp32 operations per beam); opt-in, the headline `value` stays the default mode",
+                          "value": B * its * steps_r / dtr, "unit": "GN it/s", "kernel_ms": kr, "steps": steps_r,
+                          "speedup_vs_default": kern_ms / kr}
+        if "exact_parity" in out:
+            dd = np.abs(relaxed_pose.astype(np.float64) - exact_pose)
+            out["relaxed"]["vs_exact_all_scans"] = {"scans": B, "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
+                                                    "bit_identical": float((relaxed_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
+                                                    "max_abs_dxy_m": float(dd[:, :2].max())}
+        if not args.no_cpu:
+            out["relaxed"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init, pts, offs, relaxed_pose, 1, budget_s=0.0, n_par=512)
     if single and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(build_poses, build_scans, init if args.levels == 1 else init_pyr, pts,
                                            offs, gpu_pose, args.levels)
@@ -906,11 +1064,59 @@ def main():
     if single and not args.no_pipelined and args.levels == 1:
         out["pipelined"] = run_child(["--leg", "pipelined", "--steps", str(max(40, args.steps)), "--batch", str(B),
                                       "--streams", str(args.streams)])
+    if single and not args.no_configs and args.levels == 1 and B == BATCH_PER_GPU:
+        # the other BASELINE configs in the same line: compact child runs, each with its own counter passes
+        matcher.close()
+        del matcher
+        torch.cuda.empty_cache()
+        extra = ["--compact"] + (["--no-cpu"] if args.no_cpu else []) + (["--no-pmc"] if args.no_pmc else [])
+        cf = {"configs[0]": config1_plumbing(capi) if not args.no_cpu else None}
+        for key, wl in (("configs[1]", "config2"), ("configs[3] (one GPU's share)", "config4"), ("configs[4] (one replica)", "config5")):
+            cf[key] = run_child(["--workload", wl] + extra, timeout_s=400)
+        out["configs"] = cf
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def config1_plumbing(capi):
+    """BASELINE configs[0]: single 181-beam synthetic scan, 256x256 single-resolution map, 5 GN iterations on the reference CPU
+    path (plumbing) -- timed on the host, and the same call through the C ABI in HSM_PARITY_EXACT compared bit for bit."""
+    from hector_slam_amd import synth
+    from oracle import pyoracle
+    pyoracle.build()
+    kind = "hr" if pyoracle.available("hr") else "ho"
+    sc = synth.make_scene(n_beams=181, map_size=256, levels=1, resolution=0.1, n_build=40, n_query=8, room=(20.0, 15.0), seed=4321)
+    o = pyoracle.Oracle(kind, sc.resolution, sc.map_size, sc.map_size, 1)
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, 1, parity=capi.PARITY_EXACT)
+    for x in (o.set_update_factor_free, g.setUpdateFactorFree):
+        x(0.4)
+    for x in (o.set_update_factor_occupied, g.setUpdateFactorOccupied):
+        x(0.9)
+    o.build_map(sc.build_poses, sc.build_scans)
+    g.build_map(sc.build_poses, sc.build_scans)
+    same = True
+    for q in range(8):
+        po, co = o.match_level(0, sc.query_init[q], sc.query_scans[q], 5)
+        pg, cg = g.match_level(0, sc.query_init[q], sc.query_scans[q], 5)
+        same &= bool((po.view(np.uint32) == pg.view(np.uint32)).all() and (co.view(np.uint32) == cg.view(np.uint32)).all())
+    n = 2000
+    t0 = time.perf_counter()
+    for k in range(n):
+        o.match_level(0, sc.query_init[k % 8], sc.query_scans[k % 8], 5)
+    dt = time.perf_counter() - t0
+    lat = []
+    for k in range(200):
+        a = time.perf_counter()
+        g.match_level(0, sc.query_init[k % 8], sc.query_scans[k % 8], 5)
+        lat.append(time.perf_counter() - a)
+    g.close()
+    return {"workload": "configs[0]: single 181-beam scan, 256^2 single-resolution map, 5 GN iterations (+ the unconditional first step)",
+            "cpu_reference": {"kind": "reference" if kind == "hr" else "port", "us_per_match": dt / n * 1e6, "gn_it_per_s": 6 * n / dt, "cores": 1},
+            "mi355x_host_call_us": float(np.median(lat[20:])) * 1e6,
+            "exact_mode_pose_and_cov_bit_identical": same}
 
 
 if __name__ == "__main__":

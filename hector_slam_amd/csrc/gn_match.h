@@ -967,8 +967,16 @@ struct __attribute__((packed, aligned(4))) CellPair {
 // WPS = 2 (experimental, HSM_CACHED_WPS2): TWO waves per scan, beam i in thread i mod 128 of the pair like
 // gn_match_kernel<2,1> (identical bits), nine beams per lane = 92 VGPRs = five waves per SIMD: a 4096-scan launch is
 // 8192 waves on 5120 slots, so late workgroups start as early ones finish.
-template <int SPB, int BPL, int LAYOUT = kLayoutQuad, int WPS = 1>
+//
+// RELAXED (HSM_PARITY_RELAXED, opt-in): the same expressions with their multiply-add pairs CONTRACTED -- the rotation, the
+// bilinear blend written as two lerps on the differences the gradient needs anyway, the blends of the differences, rotDeriv
+// and the nine accumulations become v_fma_f32: 32 instead of 51 fp32 operations per beam (42 instead of 61 VALU
+// instructions).  Per-beam values then differ from the reference's in the last bit or two (one rounding instead of two
+// per pair); the mode's bar is north_star's tolerance (1e-4 m / 1e-4 rad on the pose), measured at full size against the
+// reference (tests/test_gpu_full_size.py, bench.py), not bit-exactness of the terms.
+template <int SPB, int BPL, int LAYOUT = kLayoutQuad, int WPS = 1, bool RELAXED = false>
 __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cached_kernel(const MatchParams P) {
+  static_assert(!RELAXED || (LAYOUT == kLayoutQuad && WPS == 1), "the tolerance mode exists for the throughput form only");
   static_assert(WPS == 1 || SPB == 1, "a pair of waves owns its workgroup (one barrier per GN step)");
   constexpr int T = 64 * WPS;  // lanes per scan
   __shared__ f2 lds_pts[SPB * WPS][BPL][64];
@@ -1090,8 +1098,13 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       // "locate" a beam: rotate, bounds test, cell offset, fractions, and -- only in the lanes whose cell changed since
       // the previous step -- the gather of its texel straight into the beam's cache registers
       auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) -> unsigned long long {
-        r.r.x = cs.x * p.x - sc.x * p.y;
-        r.r.y = cs.y * p.x + sc.y * p.y;
+        if (RELAXED) {
+          r.r.x = __builtin_fmaf(cs.x, p.x, -(sc.x * p.y));
+          r.r.y = __builtin_fmaf(cs.y, p.x, sc.y * p.y);
+        } else {
+          r.r.x = cs.x * p.x - sc.x * p.y;
+          r.r.y = cs.y * p.x + sc.y * p.y;
+        }
         const CellCoord q = cell_coord(R, f2{e2.x + r.r.x, e2.y + r.r.y});
         fx = q.fx;
         fy = q.fy;
@@ -1194,6 +1207,29 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
         return p;
       };
       auto consume = [&](int k, const BeamRot& r, float fx, float fy) {
+        if (RELAXED) {
+          // OccGridMapUtil.h:332-346 and :80-97 with contracted multiply-adds: the blend as two lerps on the x differences
+          // (i0*(1-fx) + i1*fx == i0 - fx*(i0-i1)), then one on the rows; accumulations as v_fma_f32
+          const float i0 = tq[k].x, i1 = tq[k].y, i2 = tq[k].z, i3 = tq[k].w;
+          const float xFacInv = 1.0f - fx, yFacInv = 1.0f - fy;
+          const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;
+          const float t0 = __builtin_fmaf(-fx, dx1, i0), t1 = __builtin_fmaf(-fx, dx2, i2);
+          const float M = __builtin_fmaf(fy, t1 - t0, t0);
+          const float Gx = __builtin_fmaf(dx2, fx, dx1 * xFacInv);  // -gx
+          const float Gy = __builtin_fmaf(dy2, fy, dy1 * yFacInv);  // -gy
+          const float funVal = 1.0f - M;
+          const float rotDeriv = __builtin_fmaf(r.r.y, Gx, -(r.r.x * Gy));
+          acc.d01.x = __builtin_fmaf(-Gx, funVal, acc.d01.x);
+          acc.d01.y = __builtin_fmaf(-Gy, funVal, acc.d01.y);
+          acc.d2 = __builtin_fmaf(rotDeriv, funVal, acc.d2);
+          acc.hd.x = __builtin_fmaf(Gx, Gx, acc.hd.x);
+          acc.hd.y = __builtin_fmaf(Gy, Gy, acc.hd.y);
+          acc.h22 = __builtin_fmaf(rotDeriv, rotDeriv, acc.h22);
+          acc.h01 = __builtin_fmaf(Gx, Gy, acc.h01);
+          acc.hr.x = __builtin_fmaf(-Gx, rotDeriv, acc.hr.x);
+          acc.hr.y = __builtin_fmaf(-Gy, rotDeriv, acc.hr.y);
+          return;
+        }
         BeamSample b;
         b.X = f2{1.0f - fx, fx};
         b.Y = f2{1.0f - fy, fy};

@@ -170,6 +170,7 @@ struct hsm_ctx {
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   int exact_cached = -1;         // env HSM_EXACT_CACHED=0|1: the texel-cache exact form (gn_match_exact.h) never / always; -1 = on maps above 2^23 cells
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
+  bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -296,7 +297,9 @@ int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
   if constexpr (WPS == 1 && (BPL == 9 || BPL == 17)) {
     // throughput launches of long scans: the texel-cache form (gn_match.h)
     if (h->texel_cache && P.begin_world && !P.trace) {
-      if (h->layout == kLayoutQuad)
+      if (h->layout == kLayoutQuad && h->relaxed)
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad, 1, true>), dim3(grid), dim3(block), 0, stream, P);
+      else if (h->layout == kLayoutQuad)
         hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
       else
         hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
@@ -754,7 +757,10 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
   if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
-  if (const char* env = getenv("HSM_PARITY")) h->exact = strcmp(env, "exact") == 0;
+  if (const char* env = getenv("HSM_PARITY")) {
+    h->exact = strcmp(env, "exact") == 0;
+    h->relaxed = strcmp(env, "relaxed") == 0;
+  }
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
@@ -895,12 +901,16 @@ int hsm_on_map_updated(hsm_ctx* h) { return h ? HSM_OK : fail(HSM_ERR_INVALID, "
 
 int hsm_set_parity(hsm_ctx* h, int mode) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
-  if (mode != HSM_PARITY_FAST && mode != HSM_PARITY_EXACT) return fail(HSM_ERR_INVALID, "hsm_set_parity: unknown mode");
+  if (mode != HSM_PARITY_FAST && mode != HSM_PARITY_EXACT && mode != HSM_PARITY_RELAXED)
+    return fail(HSM_ERR_INVALID, "hsm_set_parity: unknown mode");
   std::lock_guard<std::mutex> lk(h->mu);
   h->exact = mode == HSM_PARITY_EXACT;
+  h->relaxed = mode == HSM_PARITY_RELAXED;
   return HSM_OK;
 }
-int hsm_parity(const hsm_ctx* h) { return (h && h->exact) ? HSM_PARITY_EXACT : HSM_PARITY_FAST; }
+int hsm_parity(const hsm_ctx* h) {
+  return !h ? HSM_PARITY_FAST : (h->exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : HSM_PARITY_FAST));
+}
 
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");

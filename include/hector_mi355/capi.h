@@ -60,9 +60,12 @@ typedef struct hsm_opts {
  *          poses within 1e-4 m / 1e-4 rad of the reference wherever its Gauss-Newton iteration has settled
  *   EXACT  the reference's order, beam 0 .. n-1 in nine sequential fp32 chains: H, dTr, every GN step and
  *          the final pose are BIT-IDENTICAL to the reference CPU matcher on every scan (about 2.5x the
- *          instructions per GN iteration).  sinf/cosf/expf are glibc's algorithms in both modes.
- * Default FAST; env HSM_PARITY=exact selects EXACT at hsm_create, hsm_set_parity switches at run time. */
-enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1 };
+ *          instructions per GN iteration).  sinf/cosf/expf are glibc's algorithms in every mode.
+ *   RELAXED  FAST with the multiply-add pairs of the per-beam arithmetic contracted to fused operations (32 instead of
+ *          51 fp32 operations per beam) in the batched throughput kernel; everything else runs as FAST.  Per-beam terms
+ *          are no longer bit-exact; the bar is north_star's 1e-4 m / 1e-4 rad on the pose, measured at full size.
+ * Default FAST; env HSM_PARITY=exact|relaxed selects a mode at hsm_create, hsm_set_parity switches at run time. */
+enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2 };
 
 /* ---- construction ---------------------------------------------------------
  * replaces: MapRepMultiMap::MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, numDepth,
@@ -87,7 +90,7 @@ int hsm_set_update_factor_occupied(hsm_ctx* h, float occupied_factor);
  * The device probability texels are refreshed eagerly by update_by_scan, so this
  * only has to exist; it returns HSM_OK. */
 int hsm_on_map_updated(hsm_ctx* h);
-/* no reference counterpart: selects HSM_PARITY_FAST / HSM_PARITY_EXACT for all later matches of the context */
+/* no reference counterpart: selects HSM_PARITY_FAST / _EXACT / _RELAXED for all later matches of the context */
 int hsm_set_parity(hsm_ctx* h, int mode);
 int hsm_parity(const hsm_ctx* h);
 
