@@ -71,6 +71,7 @@ struct Level {
   unsigned int* d_key_free = nullptr;
   unsigned int* d_key_occ = nullptr;
   unsigned int* d_occ_bits = nullptr;
+  unsigned char* d_free_bytes = nullptr;  // dense scans: crossed-cell byte map in the key_free tiling (map_update.h)
   // GridMapLogOddsFunctions (GridMapLogOdds.h:200-203)
   float log_odds_free = 0.f, log_odds_occ = 0.f;
   // OccGridMapBase counters / GridMapBase::lastUpdateIndex
@@ -168,6 +169,7 @@ struct hsm_ctx {
   int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
+  bool dense_bits = true;        // env HSM_DENSE_BITS=0: dense scans keep the keyed update (map_update.h)
   int exact_cached = -1;         // env HSM_EXACT_CACHED=0|1: the texel-cache exact form (gn_match_exact.h) never / always; -1 = on maps above 2^23 cells
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
@@ -221,6 +223,7 @@ LevelRW level_rw(const Level& L) {
   v.key_free = L.d_key_free;
   v.key_occ = L.d_key_occ;
   v.occ_bits = L.d_occ_bits;
+  v.free_bytes = L.d_free_bytes;
   v.sx = L.sx;
   v.sy = L.sy;
   v.tiles_x = L.tiles_x();
@@ -276,6 +279,7 @@ void free_level(Level& L) {
   (void)hipFree(L.d_key_free);
   (void)hipFree(L.d_key_occ);
   (void)hipFree(L.d_occ_bits);
+  (void)hipFree(L.d_free_bytes);
   L = Level();
 }
 
@@ -631,6 +635,19 @@ void level_bbox(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, const UpdatePar
   }
 }
 
+// dense scans take the bitmap form of the update (map_update.h) when every level of the batch has rows of a multiple of
+// 64 cells (the apply pass owns its bitmap words per 64 x 4-cell block); env HSM_DENSE_BITS=0 keeps the keyed form
+bool use_dense_bits(const hsm_ctx* h, const UpdateBatch& batch, int max_n) {
+#if HSM_KEYFREE_TILE
+  if (!h->dense_bits || max_n < h->merged_mark_max) return false;
+  for (int i = 0; i < batch.nlev; ++i)
+    if ((batch.lv[i].lv.sx & 63) != 0 || batch.lv[i].lv.free_bytes == nullptr) return false;
+  return true;
+#else
+  return false;
+#endif
+}
+
 // pass 1 of map_update.h for all levels of the batch (grid.y = level): needs no box
 int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
   if (batch.nlev == 0) return HSM_OK;
@@ -638,6 +655,12 @@ int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
   for (int i = 0; i < batch.nlev; ++i)
     if (batch.lv[i].n > max_n) max_n = batch.lv[i].n;
   const unsigned ny = (unsigned)batch.nlev;
+  if (use_dense_bits(h, batch, max_n)) {
+    hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
+    hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);
+    HIP_TRY(hipGetLastError());
+    return HSM_OK;
+  }
   if (max_n < h->merged_mark_max) {
     // small scans: end-cell marks and line walks in ONE launch (keyed atomics, map_update.h) -- one dependent launch less
     const unsigned occ_blocks = (unsigned)(max_n + 255) / 256;
@@ -664,6 +687,16 @@ int launch_update_apply(hsm_ctx* h, const UpdateBatch& batch) {
   int max_n = 0;
   for (int i = 0; i < batch.nlev; ++i)
     if (batch.lv[i].n > max_n) max_n = batch.lv[i].n;
+  if (use_dense_bits(h, batch, max_n)) {
+    // one wavefront per 64 x 4-cell block of the widened box
+    const int g = grid_for(max_box / 4 + 4096);
+    if (h->layout == kLayoutQuad)
+      hipLaunchKernelGGL(update_apply_dense_kernel<true>, dim3(g, ny), dim3(256), 0, h->stream, batch);
+    else
+      hipLaunchKernelGGL(update_apply_dense_kernel<false>, dim3(g, ny), dim3(256), 0, h->stream, batch);
+    HIP_TRY(hipGetLastError());
+    return HSM_OK;
+  }
   if (h->layout == kLayoutQuad && max_n < h->scatter_texels_max) {
     // the apply pass writes the texels itself: one dependent launch less for the launch-bound small scans (1081 beams,
     // 3 levels: complete 39 -> 34.5 us) and one dense pass less for the big ones (16 k beams on 8192^2: 0.51 -> 0.45 ms)
@@ -765,6 +798,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
+  if (const char* env = getenv("HSM_DENSE_BITS")) h->dense_bits = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
   if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
@@ -826,6 +860,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     CREATE_TRY(hipMemsetAsync(L.d_key_occ, 0, n * sizeof(unsigned int), h->stream));
     CREATE_TRY(hipMalloc((void**)&L.d_occ_bits, ((n + 31) / 32 + 1) * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((n + 31) / 32 + 1) * sizeof(unsigned int), h->stream));
+    CREATE_TRY(hipMalloc((void**)&L.d_free_bytes, key_free_cells(L.sx, L.sy) + 256));
+    CREATE_TRY(hipMemsetAsync(L.d_free_bytes, 0, key_free_cells(L.sx, L.sy) + 256, h->stream));
     if (fill_level(h, L) != HSM_OK) {
       hsm_destroy(h);
       return HSM_ERR_HIP;

@@ -47,6 +47,9 @@ struct LevelRW {
   unsigned int* key_free; // first free-touching beam of the current scan
   unsigned int* key_occ;  // first end-cell beam of the current scan
   unsigned int* occ_bits; // 1 bit per cell: "some beam of the current scan ends here" (set in pass 1a, cleared in pass 2)
+  unsigned char* free_bytes; // dense scans: 1 byte per cell "some beam of the current scan crosses this cell", in the key_free
+                             // tiling (index = key_free_index: an 8x4-cell tile is 32 contiguous bytes); set by
+                             // update_mark_free_dense_kernel, cleared by update_apply_dense_kernel
   int sx, sy;
   int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
   int kf_tiles_x;            // free-key tiles per row = ceil(sx / 8)   (key_free_index)
@@ -365,6 +368,156 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
       if (lastx && y > 0) put(x, y - 1, 3);
       if (lasty && x > 0) put(x - 1, y, 3);
       if (lastx && lasty) put(x, y, 3);
+    }
+  }
+}
+
+
+// ---- dense scans (>= HSM_MERGED_MARK_MAX beams): one BYTE per crossed cell instead of a key -------------------------------
+// Measured on the 16 k-beam scans of configs[4] (profiles/r03/README.md): the keyed form moves 4.7x the algorithmic bytes
+// -- the line walk writes a 4-byte tag per crossed cell and the dense apply pass reads a 4-byte key for EVERY cell of the
+// bounding box (2x the touched cells).  WHICH beam crossed a cell first only matters where a beam also ends (see
+// mark_free_block); everywhere else "crossed by this scan" is all there is to say.
+//   update_mark_free_dense_kernel: mark_free_block's walk (one wavefront per beam, lane k owns steps k, k+64, ...; duplicate
+//     suppression against the previous beam) storing ONE byte per crossed cell -- a quarter of the bytes, and consecutive
+//     lanes fill consecutive bytes of a tile row.  All writers store the same value: a benign race.  End cells (bit in the
+//     end-cell bitmap) take the keyed atomicMax as before.  (A bitmap with one atomicOr per tile and lane -- lane k walking
+//     8 consecutive steps -- was built first: 354 us against 110, every lane's accesses land in a different line.)
+//   update_apply_dense_kernel: one wavefront per 64 x 4-cell block of the box (8 tiles = 256 contiguous bytes of the byte
+//     map).  It reads the block's bytes and its 8 end-cell words, skips the block when all are zero, applies the reference's
+//     rule to the marked cells row by row (coalesced 256-byte rows), and clears what it read -- the block has ONE owner, so
+//     there is no race on the marks, and the byte map is all zero again between updates (no generation tag to wrap).
+//     Untouched cells cost 1 byte + 1 bit instead of 4 bytes + 1 bit.
+// Same cells, same rule, same order-dependent artefacts: the maps stay bit-identical to the reference.
+__global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (beam >= P.n) return;
+  const BeamLine b = beam_line(P, beam);
+  if (!b.valid) return;
+  const unsigned int key = (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam);
+  if ((unsigned int)lane >= b.abs_da) return;
+  const unsigned int num0 = b.e0 + (unsigned int)lane * b.abs_db;
+  unsigned int q = num0 / b.abs_da, r = num0 - q * b.abs_da;
+  const unsigned int inc = 64u * b.abs_db;
+  const unsigned int q64 = inc / b.abs_da, r64 = inc - q64 * b.abs_da;
+  const BeamLine pb = beam > 0 ? beam_line(P, beam - 1) : b;
+  const bool dedup = beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
+  const unsigned int pnum0 = pb.e0 + (unsigned int)lane * pb.abs_db;
+  unsigned int pq = dedup ? pnum0 / pb.abs_da : 0u, pr = dedup ? pnum0 - pq * pb.abs_da : 0u;
+  const unsigned int pinc = 64u * pb.abs_db;
+  const unsigned int pq64 = dedup ? pinc / pb.abs_da : 0u, pr64 = dedup ? pinc - pq64 * pb.abs_da : 0u;
+  const unsigned int pda = dedup ? pb.abs_da : 0u;  // no step is "also the previous beam's" without dedup
+  // the walk in (x, y): i steps along the major axis, q along the minor one (wave-uniform direction, hoisted out of the loop)
+  const int sgn_a = b.offset_a > 0 ? 1 : -1, sgn_b = b.offset_b > 0 ? 1 : -1;
+  const int ax = b.x_major ? sgn_a : 0, ay = b.x_major ? 0 : sgn_a, mx = b.x_major ? 0 : sgn_b, my = b.x_major ? sgn_b : 0;
+  for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
+    if (!(i < pda && pq == q)) {
+      const unsigned int cx = (unsigned int)(P.bx + ax * (int)i + mx * (int)q), cy = (unsigned int)(P.by + ay * (int)i + my * (int)q);
+      const unsigned int c = cy * (unsigned int)P.lv.sx + cx;  // == line_cell(b, i)
+      const unsigned int kc = key_free_index(P.lv, cx, cy);
+      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {
+        atomicMax(&P.lv.key_free[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
+      } else {
+        P.lv.free_bytes[kc] = 1;
+      }
+    }
+    q += q64;
+    r += r64;
+    if (r >= b.abs_da) {
+      r -= b.abs_da;
+      ++q;
+    }
+    pq += pq64;
+    pr += pr64;
+    if (pr >= pda && dedup) {
+      pr -= pda;
+      ++pq;
+    }
+  }
+}
+
+// requires sx % 64 == 0 and HSM_KEYFREE_TILE (the host checks): the box is widened to 64-column / 4-row boundaries
+template <bool SCATTER_TEXELS>
+__global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  if (P.x1 < P.x0) return;  // this level has nothing to apply
+  const int lane = threadIdx.x & 63;
+  const int bx0 = P.x0 & ~63, by0 = P.y0 & ~3;
+  const int nbx = ((P.x1 | 63) - bx0 + 1) >> 6, nby = (((P.y1 | 3) - by0) >> 2) + 1;
+  const int nblocks = nbx * nby;
+  const int waves = (int)((gridDim.x * blockDim.x) >> 6);
+  for (int blk = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); blk < nblocks; blk += waves) {
+    const int X0 = bx0 + ((blk % nbx) << 6), Y0 = by0 + ((blk / nbx) << 2);
+    const int x = X0 + lane;
+    // the block's 256 mark bytes: lane l reads ONE dword of them (tile l / 8, row (l % 8) / 2, half l % 2) -- and its 8
+    // end-cell words (two per row)
+    const unsigned int tile0 = (((unsigned int)(Y0 >> 2) * (unsigned int)P.lv.kf_tiles_x) + (unsigned int)(X0 >> 3)) << 5;  // byte index
+    unsigned int* const fwp = reinterpret_cast<unsigned int*>(P.lv.free_bytes + tile0) + lane;
+    const unsigned int fw = *fwp;
+    unsigned int ow[4];
+    bool any = fw != 0u;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const int y = Y0 + dy;
+      ow[dy] = y < P.lv.sy ? P.lv.occ_bits[((size_t)y * P.lv.sx + x) >> 5] : 0u;
+      any |= ow[dy] != 0u;
+    }
+    if (__ballot(any) == 0ull) continue;  // nothing of this scan in the block
+    if (fw != 0u) *fwp = 0u;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const int y = Y0 + dy;
+      if (y >= P.lv.sy) break;
+      const size_t c = (size_t)y * P.lv.sx + x;
+      if (ow[dy] != 0u && (lane & 31) == 0) P.lv.occ_bits[c >> 5] = 0u;
+      bool occ = (ow[dy] >> (lane & 31)) & 1u;
+      // the byte of cell (x, Y0 + dy): tile lane / 8, byte dy * 8 + lane % 8 = dword (lane & ~7) + 2 dy + (lane & 7) / 4, byte lane & 3
+      const unsigned int fwd = (unsigned int)__shfl((int)fw, (lane & ~7) + 2 * dy + ((lane & 7) >> 2));
+      bool fre = ((fwd >> ((lane & 3) << 3)) & 0xffu) != 0u;
+      if (!fre && !occ) continue;
+      unsigned int ko = 0u, kf = 0u;
+      if (occ) {
+        ko = P.lv.key_occ[c];
+        occ = (ko >> kBeamBits) == P.serial;  // (a bit without this scan's key cannot occur; cheap to insist)
+        kf = P.lv.key_free[key_free_index(P.lv, (unsigned int)x, (unsigned int)y)];
+        fre = (kf >> kBeamBits) == P.serial;
+      }
+      if (!fre && !occ) continue;
+      float l = P.lv.logodds[c];
+      int stamp;
+      if (occ) {
+        // free-touched by an earlier beam of this scan: applied, then reverted (OccGridMapBase.h:231-233)
+        if (fre && (kBeamMask - (kf & kBeamMask)) < (kBeamMask - (ko & kBeamMask))) {
+          l += P.log_odds_free;
+          l -= P.log_odds_free;
+        }
+        if (l < 50.0f) l += P.log_odds_occ;  // updateSetOccupied
+        stamp = P.mark_occ;
+      } else {
+        l += P.log_odds_free;                // updateSetFree
+        stamp = P.mark_free;
+      }
+      P.lv.logodds[c] = l;
+      P.lv.update_index[c] = stamp;
+      const float p = grid_probability(l);
+      P.lv.prob[c] = p;
+      if (SCATTER_TEXELS) {
+        float* q = reinterpret_cast<float*>(P.lv.quad);
+        const int sx = P.lv.sx, sy = P.lv.sy;
+        const bool lastx = x == sx - 1, lasty = y == sy - 1;
+        auto put = [&](int tx, int ty, int comp) { q[4 * (size_t)quad_index(tx, ty, P.lv.tiles_x, sx) + comp] = p; };
+        put(x, y, 0);
+        if (x > 0) put(x - 1, y, 1);
+        if (lastx) put(x, y, 1);
+        if (y > 0) put(x, y - 1, 2);
+        if (lasty) put(x, y, 2);
+        if (x > 0 && y > 0) put(x - 1, y - 1, 3);
+        if (lastx && y > 0) put(x, y - 1, 3);
+        if (lasty && x > 0) put(x - 1, y, 3);
+        if (lastx && lasty) put(x, y, 3);
+      }
     }
   }
 }
