@@ -543,10 +543,14 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         return dt, ev0.elapsed_time(ev1) / steps  # back-to-back launches: average duration per launch
 
     if args.leg == "pmc":  # counter pass of the parent: fast-mode launches, then exact-mode launches
+        m.set_parity(capi.PARITY_FAST)
         timed(args.steps, 3)
         m.set_parity(capi.PARITY_EXACT)
         timed(max(3, args.steps // 2), 2)
         return
+    # `value` is the DEFAULT mode (HSM_PARITY_AUTO: exact summation for batches on maps above 2^23 cells, else fast); the
+    # fast tree is timed first and reported beside it
+    m.set_parity(capi.PARITY_FAST)
     dt, kern_ms = timed(args.steps, args.warmup)
     bytes_per_launch = algorithmic_bytes_per_iteration(beams) * its * B
     gpu_pose = d_pose.cpu().numpy()
@@ -567,6 +571,21 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                                ["gn_match_exact_cached_kernel", "gn_match_exact_batch_kernel", "gn_match_cached_kernel", "gn_match_kernel"])
     clock_hz = m.device_info()["clock_khz"] * 1e3
     out["roofline"] = roofline_block(fast_kernel, kern_ms, bytes_per_launch, beams, its, B, (pv or {}).get(fast_kernel), perr, clock_hz)
+    default_is_exact = size * size > (1 << 23)
+    out["fast_mode"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": kern_ms,
+                        "note": "HSM_PARITY_FAST (tree summation)" + ("; NOT the default on this map size" if default_is_exact else " = the default on this map size")}
+    if default_is_exact:
+        m.set_parity(capi.PARITY_AUTO)
+        dta, ka = timed(args.steps, 3)
+        auto_pose = d_pose.cpu().numpy().copy()
+        out.update({"value": total * its * args.steps / dta, "ms_per_step": dta / args.steps * 1e3, "matchdata_per_s": total * args.steps / dta})
+        out["config"]["kernel"] = m.last_launch_config()
+        out["fast_mode"]["roofline"] = out["roofline"]  # the line's `roofline` describes the kernel `value` was measured on
+        aname = "gn_match_exact_cached_kernel" if out["config"]["kernel"].get("texel_cache") else "gn_match_exact_batch_kernel"
+        out["roofline"] = roofline_block(aname, ka, bytes_per_launch, beams, its, B, (pv or {}).get(aname), perr, clock_hz)
+        out["roofline"]["what_binds"] = ("VALU instruction issue plus the serial chain jobs of the reference's summation order "
+                                         "(gn_match_exact.h): one workgroup barrier per 64-beam round, a 64-deep dependent fp32 chain behind it")
+        out["config"]["parity_mode"] = "HSM_PARITY_AUTO -> exact summation (batch on a map of more than 2^23 cells)"
     if rank == 0 and not args.no_exact:
         m.set_parity(capi.PARITY_EXACT)
         steps_x = max(5, args.steps // 3)
@@ -584,7 +603,9 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                                        "scans": B, "bit_identical": float((gpu_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
                                        "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
                                        "max_abs_dxy_m": float(dd[:, :2].max())}}
-        m.set_parity(capi.PARITY_FAST)
+        m.set_parity(capi.PARITY_AUTO)
+        if default_is_exact and nranks == 1:
+            out["exact_parity"]["default_mode_bit_identical_to_exact"] = float((auto_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean())
     if not args.no_cpu and nranks == 1:
         o, kind = cpu_oracle()
         o.build_map(build_poses, build_scans)
@@ -601,6 +622,9 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         if "exact_parity" in out:
             out["cpu_baseline"]["exact_mode_bit_identical"] = float(
                 (cpu_pose.view(np.uint32) == exact_pose[:n_cpu].view(np.uint32)).all(1).mean())
+        if default_is_exact:
+            da = np.abs(cpu_pose.astype(np.float64) - auto_pose[:n_cpu])
+            out["cpu_baseline"]["default_mode_frac_within_1e-4"] = float((da[:, :2].max(1) <= 1e-4).mean())
     if rank == 0:
         print(json.dumps(out))
 

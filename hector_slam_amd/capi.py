@@ -27,7 +27,7 @@ from . import build as _build
 
 HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
-PARITY_FAST, PARITY_EXACT, PARITY_RELAXED = 0, 1, 2
+PARITY_FAST, PARITY_EXACT, PARITY_RELAXED, PARITY_AUTO = 0, 1, 2, 3
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -485,7 +485,7 @@ class MapRepMultiMap:
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
                 "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": max(int(cfg[4]), 0),
                 "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4])),
-                "parity": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed"}.get(self.parity(), "fast")}
+                "parity": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed", PARITY_AUTO: "auto"}.get(self.parity(), "fast")}
 
     # ---- parity / debug ---------------------------------------------------------------------
     def hessian_derivs(self, level, pose_map, pts_level):

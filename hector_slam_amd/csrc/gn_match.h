@@ -44,6 +44,8 @@
 // in beam order, i = 0 .. n-1, exactly the reference's fp32 chains.  sinf/cosf/expf are
 // glibc's algorithms operation for operation (libm_exact.h): identical bits.
 #pragma once
+// Measured variants that are not shipped (the two-wave texel-cache form, per-wave time stamps) only compile with
+// -DHSM_EXPERIMENTS; the default library holds the shipped forms alone.
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
@@ -321,20 +323,7 @@ __device__ __forceinline__ BeamSample sample_fetch(const LevelRegs& L, f2 c) {
   if (LAYOUT == kLayoutQuad) {
     const unsigned index = oob ? (unsigned)L.zero_index : quad_index(ix, iy, L.tiles_x, L.sx);
     // 32-bit byte offset on a uniform base: one global_load_dwordx4 with an SGPR base address
-#if defined(HSM_EXP_QUADCONTIG)  // experiment: the 4 lanes of a quad read 4 CONSECUTIVE texels (leader's cell + lane&3)
-    const unsigned lead = (unsigned)__builtin_amdgcn_update_dpp(0, (int)index, 0x00, 0xf, 0xf, true);  // quad_perm [0,0,0,0]
-    const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(((lead & ~3u) + (threadIdx.x & 3u)) << 4));
-#elif defined(HSM_EXP_NOLOAD)  // experiment: the beam body without any texel traffic
-    const float4 q = make_float4(__uint_as_float(index | 0x3f000000u), 0.25f, 0.75f, __uint_as_float((index >> 3) | 0x3f000000u));
-#elif defined(HSM_EXP_MASKLOAD)  // experiment: only a quarter of the lanes gather (1 = one lane of every quad, 2 = four whole quads)
-    float4 q = make_float4(0.3f, 0.25f, 0.75f, 0.6f);
-    if (HSM_EXP_MASKLOAD == 1 ? (threadIdx.x & 3u) == 0u : (threadIdx.x & 63u) < 16u)
-      q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(index << 4));
-#elif defined(HSM_EXP_SAMELINE)  // experiment: every lane reads the same texel
-    const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)((index & 0u) + 4096u));
-#else
     const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(L.quad) + (size_t)(index << 4));
-#endif
     b.lo = f2{q.x, q.y};
     b.hi = f2{q.z, q.w};
   } else {
@@ -987,7 +976,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
   int red_buf = 0;
   // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
   const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave / WPS);
-#if defined(HSM_EXP_TIMESTAMPS)
+#if defined(HSM_EXPERIMENTS) && defined(HSM_EXP_TIMESTAMPS)
   const unsigned long long ts_entry = wall_clock64();
 #endif
   if (scan >= P.batch) return;
@@ -1032,7 +1021,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       mine[k][lane] = f2{q.x, q.y};
     }
   }
-#if defined(HSM_EXP_TIMESTAMPS)  // experiment (tools/exp_wave_timeline.py): per-wave start / end stamps of the 100 MHz clock
+#if defined(HSM_EXPERIMENTS) && defined(HSM_EXP_TIMESTAMPS)  // experiment (tools/exp_wave_timeline.py): per-wave start / end stamps of the 100 MHz clock
   const unsigned long long ts_begin = wall_clock64();
   const unsigned long long sc_begin = __builtin_readcyclecounter();  // shader clock (s_memtime)
 #endif
@@ -1085,9 +1074,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
 #pragma unroll
         for (int k = 0; k <= kEpAhead; ++k) endpoint_issue(k);
       }
-#if !defined(HSM_EXP_NO_PRIO_ROTATION)
       rotate_wave_priority(it + l);
-#endif
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
@@ -1110,11 +1097,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
         fy = q.fy;
         unsigned idx = LAYOUT == kLayoutQuad ? quad_index(q.ix, q.iy, R.tiles_x, R.sx) : __umul24(q.iy, (unsigned)R.sx) + q.ix;
         asm volatile("" : "+v"(idx));  // computed unconditionally: a select below, not a branch
-#if defined(HSM_EXP_CACHE_FLOOR)  // experiment: every lane always hits its cached texel after the first gather
-        const unsigned off = ((q.oob ? zero_off : idx) & 0u) + 4096u;
-#else
         const unsigned off = q.oob ? zero_off : idx << (LAYOUT == kLayoutQuad ? 4 : 2);
-#endif
         if (kFirst) {  // a level's first step: every lane gathers (toff[] holds no offset yet)
           asm volatile("global_load_dwordx4 %[t], %[o], %[b]" : [t] "=v"(tq[k]) : [o] "v"(off), [b] "s"(R.quad) : "memory");
           toff[k] = off;
@@ -1281,14 +1264,12 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       }
       // a scan longer than the 64 * BPL cached beams (BPL comes from a host-side length HINT): the rest streams
       // from memory like gn_match_kernel's loop, in the same per-lane order (wave-uniform trip count)
-#if !defined(HSM_EXP_NO_TAIL)
       for (int i = T * BPL + (n > T * BPL ? lane_id_now() + 64 * wit : 0); i < n; i += T) {
         const float2 p = pts[i];
         BeamRot r;
         const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
         beam_finish(b, r, acc);
       }
-#endif
       if (WPS > 1) {
         team_allreduce9<WPS>(acc, red, red_buf, wit, lane_id_now());
         red_buf ^= 1;
@@ -1313,7 +1294,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
     P.out_pose[3 * scan + 2] = pw2;
     if (P.out_cov) {
       float* c = P.out_cov + 9 * scan;
-#if defined(HSM_EXP_TIMESTAMPS)  // the stamps and the wave's placement overwrite the covariance
+#if defined(HSM_EXPERIMENTS) && defined(HSM_EXP_TIMESTAMPS)  // the stamps and the wave's placement overwrite the covariance
       const unsigned long long ts_end = wall_clock64();
       const unsigned long long sc_end = __builtin_readcyclecounter();
       unsigned hwid, xcc;

@@ -172,6 +172,7 @@ struct hsm_ctx {
   bool dense_bits = true;        // env HSM_DENSE_BITS=0: dense scans keep the keyed update (map_update.h)
   int exact_cached = -1;         // env HSM_EXACT_CACHED=0|1: the texel-cache exact form (gn_match_exact.h) never / always; -1 = on maps above 2^23 cells
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
+  bool auto_parity = true;  // HSM_PARITY_AUTO (default): batched matches on maps above 2^23 cells run in HSM_PARITY_EXACT, the rest FAST
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -438,7 +439,23 @@ int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stre
   return launch_match_t<WPS, SPB, 17>(h, P, stream);
 }
 
+int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream);
+
+// HSM_PARITY_AUTO: a BATCH on a map of more than 2^23 cells takes the reference's summation order.  Measured
+// (profiles/r03/README.md, tests/test_gpu_full_size.py): on the 2048^2 workloads the fast tree is within 1e-4 m of the
+// reference on 36 864 of 36 864 scans; on the 4096^2 pyramid with its 160 m room -- long beams on coarse far walls, 30 % of
+// the scans not settled in the reference itself -- it misses on 0.7 %.  Map size is the proxy for that regime that the
+// context knows; hsm_set_parity pins either mode.  Single scans keep the fast tree (their cost is latency).
 int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  const bool saved = h->exact;
+  if (h->auto_parity && !h->relaxed && P.begin_world && !P.trace && P.batch > 1 && h->levels[0].cells() > ((size_t)1 << 23))
+    h->exact = true;  // (the caller holds the context's mutex)
+  const int rc = launch_match_mode(h, P, max_n, stream);
+  h->exact = saved;
+  return rc;
+}
+
+int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   switch (choose_wps(h, P.batch, max_n)) {
     case 1: {
       // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
@@ -451,6 +468,7 @@ int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream
       return launch_match_w<1, 4>(h, P, max_n, stream);
     }
     case 2: {
+#if defined(HSM_EXPERIMENTS)
       // experimental (HSM_CACHED_WPS2=1, explicit waves_per_scan = 2): the texel-cache form on a PAIR of waves per scan
       // -- nine beams per lane, five waves per SIMD, 1.6 generations of waves for a 4096-scan launch (gn_match.h)
       const int per_lane = (max_n + 127) / 128;
@@ -466,6 +484,7 @@ int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream
         h->last_cfg[5] = 1;
         return HSM_OK;
       }
+#endif
       return launch_match_w<2, 1>(h, P, max_n, stream);
     }
     case 4: return launch_match_w<4, 1>(h, P, max_n, stream);
@@ -793,6 +812,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_PARITY")) {
     h->exact = strcmp(env, "exact") == 0;
     h->relaxed = strcmp(env, "relaxed") == 0;
+    h->auto_parity = strcmp(env, "auto") == 0;
   }
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
@@ -937,15 +957,17 @@ int hsm_on_map_updated(hsm_ctx* h) { return h ? HSM_OK : fail(HSM_ERR_INVALID, "
 
 int hsm_set_parity(hsm_ctx* h, int mode) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
-  if (mode != HSM_PARITY_FAST && mode != HSM_PARITY_EXACT && mode != HSM_PARITY_RELAXED)
+  if (mode != HSM_PARITY_FAST && mode != HSM_PARITY_EXACT && mode != HSM_PARITY_RELAXED && mode != HSM_PARITY_AUTO)
     return fail(HSM_ERR_INVALID, "hsm_set_parity: unknown mode");
   std::lock_guard<std::mutex> lk(h->mu);
   h->exact = mode == HSM_PARITY_EXACT;
   h->relaxed = mode == HSM_PARITY_RELAXED;
+  h->auto_parity = mode == HSM_PARITY_AUTO;
   return HSM_OK;
 }
 int hsm_parity(const hsm_ctx* h) {
-  return !h ? HSM_PARITY_FAST : (h->exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : HSM_PARITY_FAST));
+  if (!h) return HSM_PARITY_FAST;
+  return h->exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : (h->auto_parity ? HSM_PARITY_AUTO : HSM_PARITY_FAST));
 }
 
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {

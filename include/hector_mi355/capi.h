@@ -64,8 +64,11 @@ typedef struct hsm_opts {
  *   RELAXED  FAST with the multiply-add pairs of the per-beam arithmetic contracted to fused operations (32 instead of
  *          51 fp32 operations per beam) in the batched throughput kernel; everything else runs as FAST.  Per-beam terms
  *          are no longer bit-exact; the bar is north_star's 1e-4 m / 1e-4 rad on the pose, measured at full size.
- * Default FAST; env HSM_PARITY=exact|relaxed selects a mode at hsm_create, hsm_set_parity switches at run time. */
-enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2 };
+ *   AUTO   (default) FAST, except that BATCHED matches on maps of more than 2^23 cells run EXACT: that is where the fast
+ *          tree was measured to miss the 1e-4 m bar (0.7 % of the scans of the 4096^2 / 160 m-room workload; none of
+ *          36 864 on the 2048^2 workloads).  Single scans stay FAST.
+ * env HSM_PARITY=fast|exact|relaxed|auto selects a mode at hsm_create, hsm_set_parity switches at run time. */
+enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2, HSM_PARITY_AUTO = 3 };
 
 /* ---- construction ---------------------------------------------------------
  * replaces: MapRepMultiMap::MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, numDepth,
@@ -90,7 +93,7 @@ int hsm_set_update_factor_occupied(hsm_ctx* h, float occupied_factor);
  * The device probability texels are refreshed eagerly by update_by_scan, so this
  * only has to exist; it returns HSM_OK. */
 int hsm_on_map_updated(hsm_ctx* h);
-/* no reference counterpart: selects HSM_PARITY_FAST / _EXACT / _RELAXED for all later matches of the context */
+/* no reference counterpart: selects HSM_PARITY_FAST / _EXACT / _RELAXED / _AUTO for all later matches of the context */
 int hsm_set_parity(hsm_ctx* h, int mode);
 int hsm_parity(const hsm_ctx* h);
 

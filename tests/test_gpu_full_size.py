@@ -81,15 +81,20 @@ def batch_properties(capi, oracle_mod, sc, g, init, scans, rng, fast_within_tol,
     from hector_slam_amd import synth
     B = len(scans)
     pts, offs = synth.pack_scans(scans)
+    # ---- the default (HSM_PARITY_AUTO): exact summation for batches on maps above 2^23 cells, the fast tree below
+    assert g.parity() == capi.PARITY_AUTO
+    pose_auto, _ = g.match_batch(init, pts, offs)
     # ---- exact mode: the WHOLE batch against the reference, bit for bit, no predicate
     g.set_parity(capi.PARITY_EXACT)
     pose_x, cov_x = g.match_batch(init, pts, offs)
     cpu = oracle_match_all(oracle_mod, sc, init, pts, offs)
     same = (bits(pose_x) == bits(cpu)).all(1)
     assert same.all(), f"exact mode: {(~same).sum()} of {B} poses differ from the reference ({KIND})"
-    # ---- fast mode (default), measured against the exact mode
+    # ---- fast mode, measured against the exact mode
     g.set_parity(capi.PARITY_FAST)
     pose, cov = g.match_batch(init, pts, offs)
+    big = sc.map_size * sc.map_size > (1 << 23)
+    assert np.array_equal(bits(pose_auto), bits(pose_x if big else pose)), "HSM_PARITY_AUTO: exact above 2^23 cells, fast below"
     assert np.isfinite(pose).all() and np.isfinite(cov).all()
     d = np.abs(pose.astype(np.float64) - pose_x)
     dxy, dth = d[:, :2].max(1), ang_diff(pose[:, 2], pose_x[:, 2])
@@ -161,10 +166,11 @@ def test_config4_share_4096map_pyramid(capi, oracle_mod):
     a, b = g.download_level(0), o.download_level(0)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
     # 30 % of these scans have not settled in the REFERENCE (restarted from its own result it still moves > 1 mm: the far
-    # walls of the 160 m room are mapped as dotted lines); the exact mode reproduces them all the same, the fast mode
-    # agrees to 1e-4 m on >= 96 % and stays in the same basin on the rest
+    # walls of the 160 m room are mapped as dotted lines); the exact mode -- the default for batches on a map of this size
+    # -- reproduces them all the same; the fast mode agrees to 1e-4 m on 99.2 % (measured) and stays in the same basin on
+    # the rest (worst measured 0.07 m)
     batch_properties(capi, oracle_mod, sc, g, sc.query_init, sc.query_scans, np.random.default_rng(6),
-                     fast_within_tol=0.96, fast_max_m=0.5)
+                     fast_within_tol=0.99, fast_max_m=0.1)
 
 
 def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):

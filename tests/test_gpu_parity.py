@@ -24,6 +24,10 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
+# fast (tree) summation measured against the exact mode on maps made of a handful of scans, where Gauss-Newton has often not
+# settled (test_randomised_geometries, test_processor_lifecycle_*): bounds = what MI355X measures, with a margin
+FAST_RANDOM_WITHIN, FAST_RANDOM_WORST_M = 0.5, 0.05
+FAST_LIFECYCLE_WITHIN, FAST_LIFECYCLE_WORST_M = 0.5, 5e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -560,14 +564,15 @@ def test_concurrent_callers_are_serialised(capi, oracle_mod, pyramid_scene, kind
 def test_randomised_geometries(capi, oracle_mod, kind):
     """odd map sizes (partial edge rows, cells % 4 != 0), 1..4 levels, off-centre start coordinates, random update
     factors, rooms larger than the map.  Every step matches the same scan against IDENTICAL maps on both sides
-    (both maps are then updated with the oracle's pose, and stay bit-identical on every level to the end).  The
-    pose tolerance is held wherever the reference's own Gauss-Newton has settled (restarted from its result it
-    stays within 1 mm); on the young, tiny maps of the first steps it often has not -- there its output is a
-    chaotic function of the last bits (first GN steps agree to 1e-6, tests/tools/dev_random.py) and only the
-    basin is checked."""
+    (both maps are then updated with the oracle's pose, and stay bit-identical on every level to the end).
+    No convergence predicate: HSM_PARITY_EXACT equals the reference on EVERY step, pose and covariance, bit for bit --
+    also on the young, tiny maps of the first steps, where Gauss-Newton has not settled and the result is a chaotic
+    function of the last bits; the default (fast) summation is MEASURED against the exact mode on the same context, with
+    the bound stated below."""
     from hector_slam_amd import synth
     rng = np.random.default_rng(20240925)
-    settled_total = steps_total = 0
+    steps_total = fast_within = 0
+    fast_worst = 0.0
     for trial in range(6):
         size = int(rng.choice([96, 125, 250, 333, 512]))
         levels = int(rng.integers(1, 5))
@@ -599,25 +604,20 @@ def test_randomised_geometries(capi, oracle_mod, kind):
         for t in range(14):
             hint = pose + (poses[t] - poses[max(t - 1, 0)])
             po, co = o.match(hint, scans[t], origos[t])
-            pg, cg = g.matchData(hint, scans[t], None, origos[t])
+            g.set_parity(capi.PARITY_EXACT)
+            px, cx = g.matchData(hint, scans[t], None, origos[t])
+            g.set_parity(capi.PARITY_FAST)
+            assert np.array_equal(bits(px), bits(po)) and np.array_equal(bits(cx), bits(co)), \
+                f"exact mode: trial {trial} size {size} res {res} levels {levels} t={t}"
+            pg, cg = g.matchData(hint, scans[t], None, origos[t])  # (the retained containers are the same scan either way)
             assert np.isfinite(pg).all()
-            po2, _ = o.match(po, scans[t], origos[t])
             steps_total += 1
-            # ... and well determined: a valley of the cost (wall-parallel sliding direction on a map made of one
-            # or two scans) leaves the position along it to rounding even when the iteration has stopped moving
-            Hxy = co.reshape(3, 3).T.astype(np.float64)[:2, :2]
-            ev = np.linalg.eigvalsh(Hxy)
-            well = ev[0] > 0 and ev[1] / ev[0] < 50.0
-            if well and np.abs(po2.astype(np.float64) - po)[:2].max() <= 1e-3:
-                settled_total += 1
-                # north_star's 1e-4 m is 2e-3 level-0 cells at its 0.05 m resolution; on the coarser random
-                # maps here (0.1 / 0.2 m cells) the same 2e-3 cells are 2e-4 / 4e-4 m
-                d = np.abs(pg.astype(np.float64) - po)
-                tol_m = max(POSE_TOL_M, 2e-3 * res)
-                assert d[0] <= tol_m and d[1] <= tol_m and ang_diff(pg[2], po[2]) <= POSE_TOL_RAD, \
-                    (f"trial {trial} size {size} res {res} levels {levels} t={t} cond_xy {ev[1] / ev[0]:.1f}", d)
-            else:
-                assert np.abs(pg.astype(np.float64) - po)[:2].max() <= 0.05, (trial, t, pg, po)
+            # north_star's 1e-4 m is 2e-3 level-0 cells at its 0.05 m resolution; on the coarser random maps here
+            # (0.1 / 0.2 m cells) the same 2e-3 cells are 2e-4 / 4e-4 m
+            d = np.abs(pg.astype(np.float64) - px)
+            tol_m = max(POSE_TOL_M, 2e-3 * res)
+            fast_within += bool(d[0] <= tol_m and d[1] <= tol_m and ang_diff(pg[2], px[2]) <= POSE_TOL_RAD)
+            fast_worst = max(fast_worst, float(d[:2].max()))
             o.update_by_scan(po, scans[t], origos[t])
             o.on_map_updated()
             g.updateByScan(scans[t], po, origos[t])
@@ -626,8 +626,10 @@ def test_randomised_geometries(capi, oracle_mod, kind):
             a, b = g.download_level(lvl), o.download_level(lvl)
             assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), (trial, lvl)
             assert np.array_equal(g.occupancy_grid(lvl), o.occupancy_grid(lvl))
-    assert settled_total >= 0.4 * steps_total, (settled_total, steps_total)
-    print(f"settled + well-determined: {settled_total}/{steps_total}")
+    # fast mode against the exact mode (= the reference) over all 84 steps, young maps included.  Measured on MI355X:
+    # see the printed line; the bounds leave a margin for the summation tree's sensitivity to the launch shape
+    print(f"fast vs exact: {fast_within}/{steps_total} within tolerance, worst {fast_worst:.2e} m")
+    assert fast_worst <= FAST_RANDOM_WORST_M and fast_within >= FAST_RANDOM_WITHIN * steps_total, (fast_within, steps_total, fast_worst)
 
 
 def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
@@ -821,7 +823,8 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
 def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, levels, kind):
     """level counts other than the default 3 (MapRepSingleMap-like 1, launch-file default 2, deep 5), a reset in the
     middle of a run, update factors changed on the fly (they only affect later updates), a first scan mapped without
-    matching: poses follow the oracle; with identical poses the maps are bit-identical"""
+    matching: HSM_PARITY_EXACT equals the reference on every step (no convergence predicate); the fast mode is measured
+    against it with the bound stated at the end; with identical poses the maps are bit-identical"""
     from hector_slam_amd import synth
     sc = synth.make_scene(n_beams=720, map_size=1024, levels=levels, resolution=0.05, n_build=40, n_query=2,
                           room=(30.0, 22.0), seed=31 + levels)
@@ -836,7 +839,8 @@ def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, l
     both(g.setUpdateFactorFree, o.set_update_factor_free, 0.4)
     both(g.setUpdateFactorOccupied, o.set_update_factor_occupied, 0.9)
     pose = sc.build_poses[0].copy()
-    settled = 0
+    fast_n = fast_within = 0
+    fast_worst = 0.0
     for t in range(36):
         if t == 14:  # syscommand "reset" (HectorMappingRos.cpp:383-392)
             g.reset()
@@ -849,22 +853,21 @@ def test_processor_lifecycle_levels_reset_and_factor_changes(capi, oracle_mod, l
             po = pg = hint.astype(np.float32)
         else:
             po, co = o.match(hint, sc.build_scans[t])
+            g.set_parity(capi.PARITY_EXACT)
+            px, cx = g.matchData(hint, sc.build_scans[t])
+            g.set_parity(capi.PARITY_FAST)
+            assert np.array_equal(bits(px), bits(po)) and np.array_equal(bits(cx), bits(co)), (levels, t)
             pg, cg = g.matchData(hint, sc.build_scans[t])
-            po2, _ = o.match(po, sc.build_scans[t])
-            ev = np.linalg.eigvalsh(co.reshape(3, 3).T.astype(np.float64)[:2, :2])
-            young = (t % 14 if t >= 14 else t) < 6  # the map holds only a handful of scans (after start / reset):
-            # its cost surface is a few isolated ridges with several fixed points a fraction of a millimetre apart,
-            # and which one the 14 GN steps end on depends on the last bits
-            if young:
-                assert np.abs(pg.astype(np.float64) - po)[:2].max() <= 5e-3, (levels, t)
-            elif ev[0] > 0 and ev[1] / ev[0] < 50 and np.abs(po2.astype(np.float64) - po)[:2].max() <= 1e-3:
-                settled += 1
-                assert_pose_close(pg, po, f"levels {levels} t={t}")
+            d = np.abs(pg.astype(np.float64) - px)
+            fast_n += 1
+            fast_within += bool(d[0] <= POSE_TOL_M and d[1] <= POSE_TOL_M and ang_diff(pg[2], px[2]) <= POSE_TOL_RAD)
+            fast_worst = max(fast_worst, float(d[:2].max()))
         o.update_by_scan(po, sc.build_scans[t])
         o.on_map_updated()
         g.updateByScan(sc.build_scans[t], po)
         pose = po
-    assert settled >= 12, settled
+    print(f"levels {levels}: fast vs exact: {fast_within}/{fast_n} within 1e-4, worst {fast_worst:.2e} m")
+    assert fast_worst <= FAST_LIFECYCLE_WORST_M and fast_within >= FAST_LIFECYCLE_WITHIN * fast_n, (fast_within, fast_n, fast_worst)
     for lvl in range(levels):
         a, b = g.download_level(lvl), o.download_level(lvl)
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1]), lvl
@@ -971,42 +974,6 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
         assert np.array_equal(bits(pc), bits(pp)) and np.array_equal(bits(cc), bits(cp)), sizes[:3]
     po = np.stack([o.match(init[j], scans[j])[0] for j in range(8)])
     assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
-
-
-def test_two_wave_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch):
-    """the experimental two-waves-per-scan texel-cache form (HSM_CACHED_WPS2=1, waves_per_scan=2: nine beams per lane, five
-    waves per SIMD) == gn_match_kernel<2,1> bit for bit -- same beam -> thread mapping, same team reduction"""
-    from hector_slam_amd import synth
-    g, o = pyr
-    sc = pyramid_scene
-    monkeypatch.setenv("HSM_CACHED_WPS2", "1")
-    cached = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=2, layout=capi.LAYOUT_QUAD)
-    monkeypatch.setenv("HSM_CACHED_WPS2", "0")
-    plain = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=2, layout=capi.LAYOUT_QUAD)
-    for lvl in range(sc.levels):
-        lv = o.download_level(lvl)
-        cached.upload_level(lvl, *lv)
-        plain.upload_level(lvl, *lv)
-    rng = np.random.default_rng(32)
-    nq = len(sc.query_scans)
-    for sizes in ([1081] * 70, list(rng.integers(200, 1081, 40)) + [0, 1, 127, 128, 129, 1081, 0], [600] * 9):
-        scans, init = [], []
-        for j, n in enumerate(sizes):
-            full = sc.query_scans[j % nq]
-            n = min(int(n), full.shape[0])
-            scans.append(full[np.sort(rng.choice(full.shape[0], n, replace=False))] if n else np.zeros((0, 2), np.float32))
-            init.append(sc.query_init[j % nq] + (rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]).astype(np.float32))
-        init = np.asarray(init, np.float32)
-        pts, offs = synth.pack_scans(scans)
-        pc, cc = cached.match_batch(init, pts, offs)
-        cfg = cached.last_launch_config()
-        pp, cp = plain.match_batch(init, pts, offs)
-        assert cfg["texel_cache"] and cfg["waves_per_scan"] == 2 and not plain.last_launch_config()["texel_cache"], cfg
-        assert np.array_equal(bits(pc), bits(pp)) and np.array_equal(bits(cc), bits(cp)), sizes[:3]
-    po = np.stack([o.match(init[j], scans[j])[0] for j in range(6)])
-    assert_pose_close(pc[:6], po, "two-wave texel-cache form vs oracle")
-    cached.close()
-    plain.close()
 
 
 def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, monkeypatch):

@@ -48,7 +48,7 @@ def test_texel_cache_matcher_fits_four_waves_per_simd(device_asm):
     assert ks
     for k, v in ks.items():
         assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)   # 512 VGPRs per SIMD lane / 4 waves
-        m = re.search(r"gn_match_cached_kernelILi(\d+)ELi\d+ELi\d+ELi(\d+)E", k)
+        m = re.search(r"gn_match_cached_kernelILi(\d+)ELi\d+ELi\d+ELi(\d+)ELb[01]E", k)
         waves = int(m.group(1)) * int(m.group(2))                # scans per workgroup x waves per scan
         per_cu = 20 if int(m.group(2)) == 2 else 16              # five / four waves per SIMD
         if int(m.group(2)) == 2:
@@ -60,9 +60,103 @@ def test_counted_waits_are_static_in_the_peeled_step(device_asm):
     """the waits of the peeled first step must have folded to immediates (s_waitcnt vmcnt(n) in straight-line code): the
     quad-layout 17-beam kernel then contains the schedule's values (endpoints 4 ahead: 4..8 while they stream in, 2 / 1
     for a texel with the next endpoint + gather or only the next gather behind it)"""
-    m = re.search(r"^_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1EEEvNS_11MatchParamsE:(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
+    m = re.search(r"^_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE:(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
     assert m
     body = m.group(1)
     seen = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)}
     assert {0, 1, 2, 4, 5, 6, 7, 8} <= seen, sorted(seen)
     assert "scratch_" not in body
+
+
+# ---- the inline-asm gather contract, checked on the ISA ------------------------------------------------------------------
+# The texel-cache kernels issue their gathers from inline asm into registers the compiler believes are already written, and
+# wait for them with counted s_waitcnt.  That is only correct if NOTHING touches a destination register between the load
+# and the wait that covers it -- no copy (v_mov, v_accvgpr_write), no spill, no use as any operand.  The walker below keeps
+# the queue of vector-memory operations in flight (loads return in issue order; stores count in vmcnt too on gfx9) and
+# flags every instruction that names a register of a load still in flight.
+_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    out = set()
+    for a, lo, hi in _REG.findall(text):
+        if a:
+            out.add(int(a))
+        else:
+            out.update(range(int(lo), int(hi) + 1))
+    return out
+
+
+def gather_contract_violations(body):
+    """body: the kernel's assembly text.  Returns a list of (line number, instruction, registers) violations."""
+    lines = [ln.split(";")[0].strip() for ln in body.split("\n")]
+    lines = [ln for ln in lines if ln and not ln.startswith((".", "//"))]
+    inflight = []  # [(set of destination VGPRs, text)], oldest first
+    bad = []
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        op = ln.split()[0]
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", ln)
+            if m:
+                n = int(m.group(1))
+                # `vmcnt(1); s_branch 2f; 1: vmcnt(0); 2:` is ONE wait whose weaker arm may be the one taken
+                nxt = lines[i + 1:i + 5]
+                if n == 1 and len(nxt) >= 4 and nxt[0].startswith("s_branch") and nxt[2].startswith("s_waitcnt") and "vmcnt(0)" in nxt[2]:
+                    i += 4
+                del inflight[:max(0, len(inflight) - n)]
+        elif op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
+            dst = ln.split(None, 1)[1].split(",")[0]
+            used = _vregs(ln.split(",", 1)[1]) if "," in ln else set()
+            for regs, what in inflight:
+                if regs & (used | _vregs(dst)):
+                    bad.append((i, ln, sorted(regs & (used | _vregs(dst)))))
+            inflight.append((_vregs(dst), ln))
+        elif op.startswith(("global_store", "buffer_store", "flat_store", "scratch_store", "global_atomic", "flat_atomic")):
+            used = _vregs(ln)
+            for regs, what in inflight:
+                if regs & used:
+                    bad.append((i, ln, sorted(regs & used)))
+            inflight.append((set(), ln))
+        elif not op.endswith(":"):
+            used = _vregs(ln)
+            for regs, what in inflight:
+                if regs & used:
+                    bad.append((i, ln, sorted(regs & used)))
+        i += 1
+    return bad
+
+
+def test_gather_contract_walker_catches_a_broken_sequence():
+    ok = """
+    global_load_dwordx4 v[10:13], v20, s[2:3]
+    v_add_f32_e32 v1, v2, v3
+    global_load_dwordx4 v[14:17], v21, s[2:3]
+    s_waitcnt vmcnt(1)
+    v_mul_f32_e32 v4, v10, v11
+    s_waitcnt vmcnt(0)
+    v_mul_f32_e32 v5, v14, v15
+    """
+    assert gather_contract_violations(ok) == []
+    for broken in ("v_mov_b32_e32 v30, v12", "v_accvgpr_write_b32 a0, v10", "scratch_store_dwordx4 off, v[10:13], off",
+                   "v_mul_f32_e32 v4, v14, v1"):
+        text = ok.replace("s_waitcnt vmcnt(1)", broken + "\n    s_waitcnt vmcnt(1)")
+        assert gather_contract_violations(text), broken
+    # a consumer placed behind a wait that does not cover its load (the newest one is still in flight)
+    text = ok.replace("v_mul_f32_e32 v4, v10, v11", "v_mul_f32_e32 v4, v14, v11")
+    assert gather_contract_violations(text)
+
+
+@pytest.mark.parametrize("kernel", ["_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE",
+                                    "_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1EEEvNS_11MatchParamsE",
+                                    "_ZN3hsm22gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE",
+                                    "_ZN3hsm22gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0EEEvNS_11MatchParamsE",
+                                    "_ZN3hsm28gn_match_exact_cached_kernelILi8ELi17ELi14EEEvNS_11MatchParamsE"])
+def test_no_register_of_an_inflight_gather_is_touched(device_asm, kernel):
+    m = re.search(r"^" + re.escape(kernel) + r":(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
+    assert m, kernel
+    body = m.group(1)
+    assert body.count("global_load_dwordx4") >= 9
+    bad = gather_contract_violations(body)
+    assert not bad, bad[:5]

@@ -101,6 +101,8 @@ def main():
             m = context(w, env or {})
             if env is not None:
                 m.set_parity(capi.PARITY_RELAXED if env.get("MODE") == "relaxed" else capi.PARITY_EXACT)
+            else:
+                m.set_parity(capi.PARITY_FAST)
             d_pose.zero_()
             d_cov.zero_()
             ms = timed(m, args.steps)

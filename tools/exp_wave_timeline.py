@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-wave start/end time stamps of headline launches (library built with -DHSM_EXP_TIMESTAMPS: the kernel writes them
+"""Per-wave start/end time stamps of headline launches (library built with -DHSM_EXPERIMENTS -DHSM_EXP_TIMESTAMPS: the kernel writes them
 over the covariance output): how do finish times spread over XCDs / CUs / SIMDs, how long does the endpoint staging
 take, and is a wave's lifetime a property of its scan (data) or of where it ran (hardware)?
 usage: HSM_LIB=.../libhector_mi355_ts.so python tools/exp_wave_timeline.py [--shuffle]"""
