@@ -26,8 +26,9 @@ POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
 # fast (tree) summation measured against the exact mode on maps made of a handful of scans, where Gauss-Newton has often not
 # settled (test_randomised_geometries, test_processor_lifecycle_*): bounds = what MI355X measures, with a margin
-FAST_RANDOM_WITHIN, FAST_RANDOM_WORST_M = 0.5, 0.05
-FAST_LIFECYCLE_WITHIN, FAST_LIFECYCLE_WORST_M = 0.5, 5e-3
+# (measured: 83 / 84 within tolerance, worst 2.1e-3 m; lifecycle 34/34, 34/34, 33/34 within 1e-4 m, worst 4.1e-4 m)
+FAST_RANDOM_WITHIN, FAST_RANDOM_WORST_M = 0.95, 1e-2
+FAST_LIFECYCLE_WITHIN, FAST_LIFECYCLE_WORST_M = 0.94, 2e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
