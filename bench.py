@@ -66,6 +66,27 @@ WORKLOADS = {
 }
 
 
+def multi_rank_record(dt_local: float, kern_ms_local: float, dev, gathered=None):
+    """N > 1: what every rank measured and whether all ranks hold the same gathered poses -- the self-check of the
+    multi-rank path (a broken gather or a rank that did not run shows up in the line itself)"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = torch.tensor([dt_local, kern_ms_local], dtype=torch.float64, device=dev)
+    allv = torch.empty((world, 2), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allv, mine.reshape(1, 2))
+    rec = {"world_size": world, "backend": dist.get_backend(), "per_rank_timed_region_s": [float(x) for x in allv[:, 0].cpu()],
+           "per_rank_kernel_ms": [float(x) for x in allv[:, 1].cpu()]}
+    if gathered is not None:
+        g = gathered.contiguous().view(torch.int32).to(torch.int64)
+        dig = torch.stack([g.sum(), (g * torch.arange(1, g.numel() + 1, device=g.device).reshape(g.shape)).sum()]).reshape(1, 2)
+        alld = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(alld, dig.to(dev))
+        rec["gathered_poses_identical_on_all_ranks"] = bool((alld == alld[0:1]).all().item())
+        rec["gathered_rows"] = int(gathered.shape[0])
+    return rec
+
+
 def algorithmic_bytes_per_iteration(n_beams: int) -> int:
     return 24 * n_beams + 60  # 8 B endpoint + 4 x 4 B samples per beam; 12 B pose in + 48 B H,dTr out
 
@@ -273,6 +294,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             torch.cuda.synchronize()
             return
         if nranks > 1:
+            out["ranks"] = multi_rank_record(dt, 0.0, dev)
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -537,6 +559,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
             d_pose.copy_(allp[rank * B:(rank + 1) * B])
         if nranks > 1:
+            timed.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -564,6 +587,8 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                            "batch_per_gpu": B, "global_batch": total, "beams": beams, "map": size, "levels": levels,
                            "gn_iterations_per_scan": its, "parallelism": f"dp{nranks}", "kernel": cfg},
                 })
+    if nranks > 1:
+        out["ranks"] = getattr(timed, "ranks", None)
     fast_kernel = "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
     pv = perr = None
     if rank == 0 and nranks == 1 and not args.no_pmc and not under_profiler():
@@ -924,6 +949,7 @@ def main():
             allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
             d_pose.copy_(allp[rank * B:(rank + 1) * B])
         if world > 1:
+            run.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -1035,6 +1061,8 @@ def main():
         "roofline": roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
                                    sclk_hz=headline_sclk, committed_profile="r03"),
     }
+    if world > 1:
+        out["ranks"] = getattr(run, "ranks", None)
     conv = np.abs(gpu_pose.astype(np.float64) - truth.astype(np.float64))
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
                           "median_abs_err_theta_rad": float(np.median(conv[:, 2]))}

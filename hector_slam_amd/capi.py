@@ -206,6 +206,7 @@ class MapRepMultiMap:
         opts = HsmOpts(device, layout, waves_per_scan)
         _check(self._lib.hsm_create(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords[0],
                                     startCoords[1], C.byref(opts), C.byref(self._h)), "hsm_create")
+        self._iobuf = _SmallArgs()  # created here, not on first use: two threads' first calls must meet at ONE lock
         if parity is not None:
             self.set_parity(parity)
 

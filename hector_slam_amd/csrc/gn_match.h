@@ -194,13 +194,17 @@ __device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y,
 // sinf/cosf of the reference (float overloads; OccGridMapUtil.h:70-71 compile to one
 // sincosf call): glibc's algorithm operation for operation (libm_exact.h) -- identical bits for every
 // argument, ~20 fp64 operations, no table on the |theta| < 120 path the matcher lives on.
-__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) { libm::sincosf_glibc(th, s, c); }
+// PIN: the texel-cache forms pin the binary64 constants to their use (libm_exact.h at_use: they have no register to hoist
+// them into); the latency forms let the optimiser hoist them out of the 14-step chain
+template <bool PIN = false>
+__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) { libm::sincosf_glibc<PIN>(th, s, c); }
 
 // util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
+template <bool PIN = false>
 __device__ __forceinline__ float normalize_angle(float angle) {
-  const double two_pi = libm::at_use(2.0 * 3.14159265358979323846);  // materialised here, not hoisted over the GN loops
+  const double two_pi = libm::at_use<PIN>(2.0 * 3.14159265358979323846);  // PIN: materialised here, not hoisted over the GN loops
   float a = (float)fmod(fmod((double)angle, two_pi) + two_pi, two_pi);
-  if ((double)a > libm::at_use(3.14159265358979323846)) {
+  if ((double)a > libm::at_use<PIN>(3.14159265358979323846)) {
     a = (float)((double)a - two_pi);
   }
   return a;
@@ -1076,7 +1080,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       }
       rotate_wave_priority(it + l);
       float sinRot, cosRot;
-      sincos_f32(eth, sinRot, cosRot);
+      sincos_f32<true>(eth, sinRot, cosRot);
       acc.zero();
       // the step's pose and rotation are wave-uniform: held in SGPRs (4 VGPRs less in a kernel that has none to spare)
       const f2 o2 = step_origin(ex, ey);
@@ -1284,7 +1288,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       it = 1;
     }
     for (; it < gn_steps; ++it) gn_step(std::false_type{}, it);
-    eth = normalize_angle(eth);
+    eth = normalize_angle<true>(eth);
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw2 = eth;
   }

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
     asm volatile("" : "+v"(zero_off));
     for (int it = 0; it < gn_steps; ++it, ++step_no) {
       float sinRot, cosRot;
-      sincos_f32(eth, sinRot, cosRot);
+      sincos_f32<true>(eth, sinRot, cosRot);
       const f2 o2 = step_origin(ex, ey);
       const f2 e2 = f2{uniform_f32(o2.x), uniform_f32(o2.y)};
       const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       gn_solve_and_step(acc, ex, ey, eth);
       ex = uniform_f32(ex), ey = uniform_f32(ey), eth = uniform_f32(eth);
     }
-    eth = normalize_angle(eth);
+    eth = normalize_angle<true>(eth);
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
   }

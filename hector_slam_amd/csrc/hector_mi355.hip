@@ -79,6 +79,7 @@ struct Level {
   unsigned int serial = 0;  // key-plane generation (map_update.h)
   int bbox[4] = {0, 0, -1, -1};   // cell box touched by the last update
   int dirty[4] = {0, 0, -1, -1};  // union of those boxes since hsm_take_dirty_bbox was last called
+  int key_rows[2] = {0, -1};      // rows that carry keys of the current key generation (union of the boxes since the planes were last cleared)
   size_t cells() const { return (size_t)sx * sy; }
   int tiles_x() const { return (sx + 3) / 4; }
   int quad_texels() const {
@@ -556,9 +557,22 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
   L.bbox[2] = L.bbox[3] = -1;
   if (n > 0) {
     if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than HSM_MAX_UPDATE_BEAMS beams");
-    if (++L.serial > kSerialMax) {  // key generation wrapped: clear the key planes once
-      HIP_TRY(hipMemsetAsync(L.d_key_free, 0, key_free_cells(L.sx, L.sy) * sizeof(unsigned int), h->stream));
-      HIP_TRY(hipMemsetAsync(L.d_key_occ, 0, L.cells() * sizeof(unsigned int), h->stream));
+    if (++L.serial > kSerialMax) {
+      // key generation wrapped (every 4095 updates of a level): clear the rows that carry keys -- the union of the update
+      // boxes since the last clear, not the whole planes (an 8192^2 level would be a 512 MB memset in the middle of a
+      // 40 Hz update stream)
+      if (L.key_rows[1] >= L.key_rows[0]) {
+        const size_t y0 = (size_t)L.key_rows[0], y1 = (size_t)L.key_rows[1];
+        HIP_TRY(hipMemsetAsync(L.d_key_occ + y0 * L.sx, 0, (y1 - y0 + 1) * L.sx * sizeof(unsigned int), h->stream));
+#if HSM_KEYFREE_TILE
+        const size_t row_words = (size_t)((L.sx + 7) / 8) * 32u;  // one row of 8x4-cell tiles
+        HIP_TRY(hipMemsetAsync(L.d_key_free + (y0 >> 2) * row_words, 0, ((y1 >> 2) - (y0 >> 2) + 1) * row_words * sizeof(unsigned int), h->stream));
+#else
+        HIP_TRY(hipMemsetAsync(L.d_key_free + y0 * L.sx, 0, (y1 - y0 + 1) * L.sx * sizeof(unsigned int), h->stream));
+#endif
+      }
+      L.key_rows[0] = 0;
+      L.key_rows[1] = -1;
       L.serial = 1;
     }
     UpdateParams P;
@@ -643,6 +657,13 @@ void level_bbox(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, const UpdatePar
     L.bbox[1] = P.y0 = y0 < byi ? y0 : byi;
     L.bbox[2] = P.x1 = x1 > bxi ? x1 : bxi;
     L.bbox[3] = P.y1 = y1 > byi ? y1 : byi;
+    if (L.key_rows[1] < L.key_rows[0]) {
+      L.key_rows[0] = L.bbox[1];
+      L.key_rows[1] = L.bbox[3];
+    } else {
+      if (L.bbox[1] < L.key_rows[0]) L.key_rows[0] = L.bbox[1];
+      if (L.bbox[3] > L.key_rows[1]) L.key_rows[1] = L.bbox[3];
+    }
     if (L.dirty[2] < L.dirty[0]) {
       for (int k = 0; k < 4; ++k) L.dirty[k] = L.bbox[k];
     } else {
@@ -2188,6 +2209,7 @@ int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value) {
 
 int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial) {
   if (int rc = valid_level(h, level)) return rc;
+  if (serial > kSerialMax) return fail(HSM_ERR_INVALID, "hsm_debug_set_update_serial: serial exceeds the key generation field");
   std::lock_guard<std::mutex> lk(h->mu);
   h->levels[level].serial = serial;
   return HSM_OK;

@@ -54,14 +54,15 @@ HSM_HD double bits_f64(uint64_t u) {
 // ~10 constants of sincosf out of the matcher's Gauss-Newton loop into registers (SGPR pairs, VGPR pairs for second operands) that stay live across the whole beam
 // loop -- in kernels that keep a per-beam texel cache in all 128 (gn_match_exact.h: spills, which the asynchronous
 // inline-asm gathers cannot tolerate).  The volatile asm is not loop invariant; the value is unchanged.
-#if defined(__HIP_DEVICE_COMPILE__)
+// PIN = false (the latency forms, which have registers to spare): the plain constant -- hoisting it IS the right thing there
+// (re-materialising ten constants costs ~20 scalar moves per Gauss-Newton step on a 14-step dependent chain).
+template <bool PIN = true>
 HSM_HD double at_use(double c) {
-  asm volatile("" : "+s"(c));
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (PIN) asm volatile("" : "+s"(c));
+#endif
   return c;
 }
-#else
-HSM_HD double at_use(double c) { return c; }
-#endif
 
 // ---- sincosf ----------------------------------------------------------------------------------
 // Polynomial stage shared by all argument ranges.  xs = reduced argument times the quadrant sign,
@@ -70,10 +71,11 @@ HSM_HD double at_use(double c) { return c; }
 //   sin ~ xs + xs^3 S1 + xs^5 (S2 + x2 S3)          cos ~ C0 + x2 C1 + x4 C2 + x6 (C3 + x2 C4)
 // Quadrants 2,3 use the table with negated cosine coefficients: every operation of that chain is
 // odd in the coefficients, so its result is the exact negation of the first table's.
+template <bool PIN = true>
 HSM_HD void sincosf_poly(double xs, double x2, int n, float& sinp, float& cosp) {
-  const double C0 = 0x1p0, C1 = at_use(-0x1.ffffffd0c621cp-2), C2 = at_use(0x1.55553e1068f19p-5),
-               C3 = at_use(-0x1.6c087e89a359dp-10), C4 = at_use(0x1.99343027bf8c3p-16);
-  const double S1 = at_use(-0x1.555545995a603p-3), S2 = at_use(0x1.1107605230bc4p-7), S3 = at_use(-0x1.994eb3774cf24p-13);
+  const double C0 = 0x1p0, C1 = at_use<PIN>(-0x1.ffffffd0c621cp-2), C2 = at_use<PIN>(0x1.55553e1068f19p-5),
+               C3 = at_use<PIN>(-0x1.6c087e89a359dp-10), C4 = at_use<PIN>(0x1.99343027bf8c3p-16);
+  const double S1 = at_use<PIN>(-0x1.555545995a603p-3), S2 = at_use<PIN>(0x1.1107605230bc4p-7), S3 = at_use<PIN>(-0x1.994eb3774cf24p-13);
   const double x3 = x2 * xs;
   const double x4 = x2 * x2;
   const double s1 = __builtin_fma(x2, S3, S2);
@@ -113,6 +115,7 @@ HSM_HD double reduce_large(uint32_t xi, int& np) {
   return (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
 }
 
+template <bool PIN = true>
 HSM_HD void sincosf_glibc(float y, float& sinp, float& cosp) {
   const uint32_t xi = f32_bits(y);
   const uint32_t top = (xi >> 20) & 0x7ff;
@@ -123,20 +126,20 @@ HSM_HD void sincosf_glibc(float y, float& sinp, float& cosp) {
       cosp = 1.0f;
       return;
     }
-    sincosf_poly(x, x * x, 0, sinp, cosp);
+    sincosf_poly<PIN>(x, x * x, 0, sinp, cosp);
   } else if (top < 0x42f) {  // |y| < 120
-    const double r = x * at_use(0x1.45F306DC9C883p+23);  // 2/pi * 2^24
+    const double r = x * at_use<PIN>(0x1.45F306DC9C883p+23);  // 2/pi * 2^24
     const int n = ((int32_t)r + 0x800000) >> 24;
-    const double xr = __builtin_fma(-(double)n, at_use(0x1.921FB54442D18p0), x);
+    const double xr = __builtin_fma(-(double)n, at_use<PIN>(0x1.921FB54442D18p0), x);
     const double sign = ((n ^ (n >> 1)) & 1) ? -1.0 : 1.0;  // +,-,-,+ for quadrants 0..3
-    sincosf_poly(xr * sign, xr * xr, n, sinp, cosp);
+    sincosf_poly<PIN>(xr * sign, xr * xr, n, sinp, cosp);
   } else if (top < 0x7f8) {
     int n;
     const double xr = reduce_large(xi, n);
     const int q = n + (int)(xi >> 31);
     const double sign = ((q ^ (q >> 1)) & 1) ? -1.0 : 1.0;
     // table (cosine sign) from q, swap from n -- as the source does
-    sincosf_poly(xr * sign, xr * xr, (q & 2) | (n & 1), sinp, cosp);
+    sincosf_poly<PIN>(xr * sign, xr * xr, (q & 2) | (n & 1), sinp, cosp);
   } else {  // inf / NaN
     sinp = cosp = y - y;
   }

@@ -129,15 +129,21 @@ class ReplicaSync:
         if rank == src:
             p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
             n = p.shape[0]
-            assert n <= self.max_beams
+            # an oversize scan must not leave the other ranks blocked in the collective: it travels as the count -1 and every
+            # rank raises the same error after the broadcast
+            bad = n > self.max_beams
+            if bad:
+                p, n = p[:0], 0
             host = np.empty(4 + 2 * n, np.float32)
             host[:3] = np.asarray(pose, np.float32)
-            host[3:4] = np.array([n], np.int32).view(np.float32)  # the count travels as raw bits
+            host[3:4] = np.array([-1 if bad else n], np.int32).view(np.float32)  # the count travels as raw bits
             host[4:] = p.reshape(-1)
             self.buf[: 4 + 2 * n].copy_(torch.from_numpy(host))
         dist.broadcast(self.buf, src=src, group=self.group)  # fixed-size payload: one collective, no size exchange
         head = self.buf[:4].cpu().numpy()
         n = int(head[3:4].view(np.int32)[0])
+        if not 0 <= n <= self.max_beams:
+            raise ValueError(f"ReplicaSync.broadcast: scan of the source rank does not fit the {self.max_beams}-beam buffer (count {n})")
         body = self.buf[4: 4 + 2 * n].cpu().numpy().reshape(n, 2).copy()
         return head[:3].copy(), body
 
