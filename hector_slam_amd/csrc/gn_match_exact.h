@@ -38,7 +38,7 @@ constexpr unsigned kTermRowA = 0u | 1u << 2 | 2u << 4 | 0u << 6 | 1u << 8 | 2u <
 constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
 
 #ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
-#define HSM_XBPC 14
+#define HSM_XBPC 15
 #endif
 #ifndef HSM_XLDS_AHEAD
 #define HSM_XLDS_AHEAD 1
@@ -245,30 +245,36 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
       // running sum.  The two rows stream through three 16-byte slots each (24 VGPRs): a slot is refilled right after its
       // values are consumed, so a read has two compute periods to land in.  (Measured, profiles/r03/README.md: ~1 240
-      // cycles per job, loaded or not -- a single wavefront issues an instruction every 4-5 cycles -- and a hand-scheduled
-      // body with the multiplications one slot ahead of the additions is no faster.)
-      auto chain_job = [&](int j) {
+      // cycles per 220-instruction job, loaded or not -- a single wavefront issues an instruction every 4-5 cycles -- and a
+      // hand-scheduled body with the multiplications one slot ahead of the additions is no faster: what counts is the
+      // instruction count, hence the packed multiplies and the division-free unit arithmetic.)
+      auto chain_job = [&](int j, int k) {
         // the lane index is re-read here (volatile asm): everything below depends on it, so the per-lane unit / address
         // arithmetic of the ~20 jobs of a step is not hoisted out of the GN loop into VGPRs that are not there
         const int u = 64 * j + lane_id_now();
-        const int ku = u / NCP, c = u - ku * NCP;  // round, chain
+        // a job that completes with round k holds units of rounds k-1 and k only (64 <= NCP): no division
+        const bool prev = u < k * NCP;
+        const int ku = prev ? k - 1 : k, c = u - ku * NCP;  // round, chain
         if (u < units && c < NC) {
-          const int sj = c / 9, t = c - 9 * sj;  // scan of the workgroup, term
+          const int sj = (c * 57) >> 9, t = c - 9 * sj;  // scan of the workgroup (c / 9 for c < 144), term
           const unsigned ra = (kTermRowA >> (2 * t)) & 3u, rb = (kTermRowB >> (2 * t)) & 3u;
-          const float* base = &stage[0][0][0][0] + ((ku % NB) * NS + sj) * (4 * kXRow);
-          const float4* pa = reinterpret_cast<const float4*>(base + ra * kXRow);
-          const float4* pb = reinterpret_cast<const float4*>(base + rb * kXRow);
+          const int buf = prev ? (k + NB - 1) % NB : k % NB;
+          const float* base = &stage[0][0][0][0] + (buf * NS + sj) * (4 * kXRow);
+          const f4v* pa = reinterpret_cast<const f4v*>(base + ra * kXRow);
+          const f4v* pb = reinterpret_cast<const f4v*>(base + rb * kXRow);
           float run = ku == 0 ? 0.0f : runs[c];
-          float4 a[3], b[3];
+          f4v a[3], b[3];
 #pragma unroll
           for (int q = 0; q < 3; ++q) a[q] = pa[q], b[q] = pb[q];
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float4 x = a[q % 3], y = b[q % 3];
-            run += x.x * y.x;
-            run += x.y * y.y;
-            run += x.z * y.z;
-            run += x.w * y.w;
+            // the four products as two packed multiplies (a single wavefront issues an instruction every 4-5 cycles whatever
+            // it is: the job's length is its instruction count), then the four additions in beam order
+            const f4v pr = a[q % 3] * b[q % 3];
+            run += pr.x;
+            run += pr.y;
+            run += pr.z;
+            run += pr.w;
             // fences: a refill stays behind the use of its slot and in its own period (the scheduler would hoist all 32 reads)
             asm volatile("" : "+v"(run) : : "memory");
             if (q + 3 < 16) a[q % 3] = pa[q + 3], b[q % 3] = pb[q + 3];
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         if (j_lo >= j_hi) return;
         if (wave != (int)((unsigned)(k + step_no) % (unsigned)NS)) return;  // wave-uniform
         __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
-        for (int j = j_lo; j < j_hi; ++j) chain_job(j);
+        for (int j = j_lo; j < j_hi; ++j) chain_job(j, k);
         __builtin_amdgcn_s_setprio(0);
       };
       {

@@ -171,7 +171,7 @@ struct hsm_ctx {
   int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
   int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
   bool dense_bits = true;        // env HSM_DENSE_BITS=0: dense scans keep the keyed update (map_update.h)
-  int exact_cached = -1;         // env HSM_EXACT_CACHED=0|1: the texel-cache exact form (gn_match_exact.h) never / always; -1 = on maps above 2^23 cells
+  bool exact_cached = true;      // env HSM_EXACT_CACHED=0: exact-mode batches keep round 2's producer / chain-wavefront form (gn_match.h)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
   bool auto_parity = true;  // HSM_PARITY_AUTO (default): batched matches on maps above 2^23 cells run in HSM_PARITY_EXACT, the rest FAST
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
@@ -368,16 +368,16 @@ int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
 
 template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  // throughput launches of the quad layout on maps whose gathers miss the L2: every wavefront a producer with the texel
-  // cache, packed rotating chain jobs (gn_match_exact.h; 4096^2 pyramid 295 -> 217 us).  On smaller maps round 2's form
-  // below is the faster one (2048^2 headline 93 vs 100 us).  env HSM_EXACT_CACHED=0|1 pins the choice.
-  if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 &&
-      (h->exact_cached == 1 || (h->exact_cached < 0 && h->levels[0].cells() > ((size_t)1 << 23)))) {
+  // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
+  // 36-lane chain job per round behind the round's barrier (gn_match_exact.h).  Measured against round 2's producer /
+  // chain-wavefront form below (profiles/r03/README.md): 89 vs 92 us on the 2048^2 headline batch, 195 vs 199 us on the
+  // 3-level batch, 199 vs 291 us on the 4096^2 pyramid.  env HSM_EXACT_CACHED=0 keeps round 2's form.
+  if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
     const int per_lane = (max_n + 63) / 64;
     if (per_lane <= 17 + 4) {  // scans of up to 17 beams per lane (up to four rows more stream their tail)
-      if (per_lane <= 5) return launch_match_exact_cached<8, 5>(h, P, stream);
-      if (per_lane <= 9) return launch_match_exact_cached<8, 9>(h, P, stream);
-      return launch_match_exact_cached<8, 17, HSM_XBPC>(h, P, stream);
+      if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
+      if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
+      return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
     }
   }
   // throughput launches: producer wavefronts + chain wavefronts per workgroup (gn_match.h).  Measured

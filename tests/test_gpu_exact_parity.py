@@ -162,7 +162,7 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         assert g.last_launch_config()["block"] == (640 if form == "throughput-8+2" else 512), g.last_launch_config()
     if form.startswith("cached"):
         cfg = g.last_launch_config()
-        assert cfg["texel_cache"] and cfg["block"] == 512, cfg
+        assert cfg["texel_cache"] and cfg["block"] == 256, cfg
     for q, sq in enumerate(scans):
         po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
         assert same(pb[q], po), (q, sq.shape[0])

@@ -977,6 +977,77 @@ def test_texel_cache_form_is_bit_identical(capi, pyr, pyramid_scene, monkeypatch
     assert_pose_close(pc[:8], po, "texel-cache form vs oracle")
 
 
+def test_relaxed_mode_meets_the_pose_tolerance(capi, pyr, pyramid_scene):
+    """HSM_PARITY_RELAXED (opt-in; gn_match_cached_kernel<.., RELAXED>: multiply-add pairs contracted to v_fma_f32): the batch
+    kernel's poses stay within north_star's 1e-4 m / 1e-4 rad of the reference on every scan of the batch, ragged scans and
+    all three levels included; single scans and every other entry run as in the fast mode (bit-identical to it)"""
+    from hector_slam_amd import synth
+    g, o = pyr
+    sc = pyramid_scene
+    m = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, waves_per_scan=1, layout=capi.LAYOUT_QUAD)
+    for lvl in range(sc.levels):
+        m.upload_level(lvl, *o.download_level(lvl))
+    rng = np.random.default_rng(33)
+    nq = len(sc.query_scans)
+    scans, init = [], []
+    for j, n in enumerate([1081] * 48 + list(rng.integers(400, 1081, 30)) + [0, 600]):
+        full = sc.query_scans[j % nq]
+        n = min(int(n), full.shape[0])
+        scans.append(full[np.sort(rng.choice(full.shape[0], n, replace=False))] if n else np.zeros((0, 2), np.float32))
+        init.append(sc.query_init[j % nq] + (rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]).astype(np.float32))
+    init = np.asarray(init, np.float32)
+    pts, offs = synth.pack_scans(scans)
+    m.set_parity(capi.PARITY_FAST)
+    pf, _ = m.match_batch(init, pts, offs)
+    ps_fast, _ = m.matchData(init[0], scans[0])
+    m.set_parity(capi.PARITY_RELAXED)
+    assert m.parity() == capi.PARITY_RELAXED and m.last_launch_config()["parity"] == "relaxed"
+    pr, cr = m.match_batch(init, pts, offs)
+    assert m.last_launch_config()["texel_cache"]
+    assert np.isfinite(pr).all() and np.isfinite(cr).all()
+    assert not np.array_equal(bits(pr), bits(pf))  # it IS another arithmetic ...
+    po = np.stack([o.match(init[j], scans[j])[0] for j in range(len(scans))])
+    assert_pose_close(pr, po, "relaxed batch vs oracle")  # ... within the tolerance on every scan
+    ps_rel, _ = m.matchData(init[0], scans[0])
+    assert np.array_equal(bits(ps_rel), bits(ps_fast))  # single scans: the fast kernels
+    m.close()
+
+
+def test_dense_update_forms_agree_bit_for_bit(capi, oracle_mod, kind, monkeypatch):
+    """scans of >= 4096 beams: the byte-map form of updateByScan (update_mark_free_dense_kernel / update_apply_dense_kernel)
+    == the keyed form (HSM_DENSE_BITS=0) == the oracle, both layouts, all levels -- incl. a map whose rows are NOT a multiple
+    of 64 cells, where the library falls back to the keyed form by itself"""
+    from hector_slam_amd import synth
+    for size, levels in ((512, 3), (500, 2)):
+        sc = synth.make_scene(n_beams=6000, map_size=size, levels=levels, resolution=0.05, n_build=6, n_query=1,
+                              room=(20.0, 15.0), seed=17)
+        o = make_oracle(oracle_mod, kind, sc, build=False)
+        gs = []
+        for env, lay in (("1", capi.LAYOUT_QUAD), ("1", capi.LAYOUT_PLANE), ("0", capi.LAYOUT_QUAD)):
+            monkeypatch.setenv("HSM_DENSE_BITS", env)
+            gs.append(make_gpu(capi, sc, build=False, layout=lay))
+        for t in range(6):
+            o.match(sc.build_poses[t], sc.build_scans[t])
+            o.update_by_scan(sc.build_poses[t], sc.build_scans[t])
+            for g in gs:
+                g.matchData(sc.build_poses[t], sc.build_scans[t])
+                g.updateByScan(sc.build_scans[t], sc.build_poses[t])
+        for lvl in range(levels):
+            lo_o, ui_o = o.download_level(lvl)
+            assert (ui_o >= 0).sum() > 1000
+            _, prob = oracle_mod.libm_expf(lo_o.reshape(-1), o.kind)
+            for g in gs:
+                lo_g, ui_g = g.download_level(lvl)
+                assert np.array_equal(bits(lo_g), bits(lo_o)) and np.array_equal(ui_g, ui_o), (size, lvl)
+                assert np.array_equal(bits(g.download_prob(lvl)).reshape(-1), bits(prob)), (size, lvl)
+        # the quad-layout contexts hold identical texels (the matcher's view of the map): same pose from the same start
+        p0, _ = gs[0].matchData(sc.query_init[0], sc.query_scans[0])
+        p2, _ = gs[2].matchData(sc.query_init[0], sc.query_scans[0])
+        assert np.array_equal(bits(p0), bits(p2)), size
+        for g in gs:
+            g.close()
+
+
 def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, monkeypatch):
     """xcd_block(): whichever mapping a launch uses -- chunks of 16 workgroups dealt to the XCDs (default), odd chunk
     sizes, one contiguous eighth per XCD -- every scan is matched exactly once: a 1003-scan batch (251 workgroups: one

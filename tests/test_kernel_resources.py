@@ -152,7 +152,7 @@ def test_gather_contract_walker_catches_a_broken_sequence():
                                     "_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1EEEvNS_11MatchParamsE",
                                     "_ZN3hsm22gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE",
                                     "_ZN3hsm22gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0EEEvNS_11MatchParamsE",
-                                    "_ZN3hsm28gn_match_exact_cached_kernelILi8ELi17ELi14EEEvNS_11MatchParamsE"])
+                                    "_ZN3hsm28gn_match_exact_cached_kernelILi4ELi17ELi15EEEvNS_11MatchParamsE"])
 def test_no_register_of_an_inflight_gather_is_touched(device_asm, kernel):
     m = re.search(r"^" + re.escape(kernel) + r":(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
     assert m, kernel
