@@ -1,4 +1,4 @@
-// gn_match_exact.h -- HSM_PARITY_EXACT for batches on LARGE maps: the exact-order matcher with the texel cache (round 3).
+// gn_match_exact.h -- HSM_PARITY_EXACT for batches: the exact-order matcher with the texel cache (round 3).
 //
 // What it computes: the same coarse-to-fine Gauss-Newton match as gn_match.h, with the nine sums of
 // OccGridMapUtil::getCompleteHessianDerivs (HSL/map/OccGridMapUtil.h:76-98) accumulated in the REFERENCE's order --
@@ -6,26 +6,28 @@
 // covariance are bit-identical to the reference CPU matcher.
 //
 // How (measurements and the variants that lost: profiles/r03/README.md):
-//   * one wavefront per scan, 8 scans per workgroup; every wavefront is a PRODUCER with gn_match_cached_kernel's
-//     machinery: the last texel + byte offset of its first BPC beams per lane stay in VGPRs (the other rows gather in
-//     every step), exec-masked inline-asm gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the
-//     first rows in VGPRs: the LDS share of 16 scans per CU does not hold all 17 rows next to the stage);
+//   * one wavefront per scan, NS scans per workgroup (4 as launched: one wavefront per SIMD and workgroup, four independent
+//     workgroups per CU); every wavefront is a PRODUCER with gn_match_cached_kernel's machinery: the last texel + byte
+//     offset of its first BPC beams per lane stay in VGPRs (the other rows gather in every step), exec-masked inline-asm
+//     gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the first rows in VGPRs where the LDS share
+//     of 16 scans per CU does not hold all rows next to the stage);
 //   * per ROUND k (beam k of every lane = beams 64k .. 64k+63 of the scan) a producer stages FOUR values per beam --
 //     gx, gy (the source's dM/dx, dM/dy), rotDeriv, funVal -- not the nine products: every product of :83-97 is a
 //     product of two of those four, so the chain lane multiplies (unfused, one rounding, like the reference) and adds;
-//     4 instead of 9 LDS rows per scan is what lets a triple-buffered stage and the endpoints of 16 scans share 160 KB;
-//   * the chains: 72 sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
-//     lane l runs chain-round unit u = 64 j + l, u = k * 72 + (9 scan + term): jobs are PACKED across round boundaries,
-//     so all 64 lanes work (1.125 jobs per round instead of two 36-lane jobs); a chain's running sum travels from job to
-//     job through LDS.  The jobs that complete with round k run right behind round k's barrier on ONE wavefront (they
-//     depend on each other through the carried sums), the owner rotating from round to round, while the other
-//     wavefronts already produce round k+1.  A job may still read round k-1's rows, hence three stage buffers; one
+//     4 instead of 9 LDS rows per scan is what lets the stage and the endpoints of 16 scans share 160 KB;
+//   * the chains: 9 NS sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
+//     lane l runs chain-round unit u = 64 j + l.  NS = 4: a round is padded to 64 units -- one 36-lane job per round, two
+//     stage buffers.  NS >= 8 (9 NS >= 64 chains): u = k * 9 NS + (9 scan + term), jobs PACKED across round boundaries
+//     so that all 64 lanes work, three stage buffers (a job may still read round k-1's rows); a chain's running sum
+//     travels from job to job through LDS.  The jobs that complete with round k run right behind round k's barrier on
+//     ONE wavefront, the owner rotating from round to round, while the other wavefronts already produce round k+1; one
 //     workgroup barrier per round.
+//   * a job's length is its instruction count (a single wavefront issues an instruction every 4-5 cycles whatever it is):
+//     two v_pk_mul_f32 per 16-byte slot, no divisions in the unit arithmetic -- 176 instructions per job.
 //   Same arithmetic on the same texels in the same order as gn_match_kernel<.., EXACT>: identical bits.
 //   Against round 2's producer / chain-wavefront form (gn_match_exact_batch_kernel: endpoints streamed, no texel cache,
-//   nine staged products): 26 % fewer VALU instructions; 295 -> 217 us on the 4096^2 pyramid, whose gathers miss the L2,
-//   but 93 -> 100 us on the 2048^2 headline batch (the job sits on every round's critical path) -- so the host takes this
-//   form for maps above 2^23 cells only.
+//   nine staged products): 89 vs 92 us on the 2048^2 headline batch, 195 vs 199 us on the 3-level batch, 199 vs 291 us on
+//   the 4096^2 pyramid, whose gathers miss the L2.
 #pragma once
 #include "gn_match.h"
 
