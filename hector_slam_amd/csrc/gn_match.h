@@ -1500,6 +1500,9 @@ gn_match_exact_batch_kernel(const MatchParams P) {
 #ifndef HSM_COOP_BARRIER
 #define HSM_COOP_BARRIER 1
 #endif
+#ifndef HSM_COOP_TAGGED  // 1 (default, round 3): no grid barrier at all -- tagged 16-byte records, see the kernel
+#define HSM_COOP_TAGGED 1
+#endif
 __device__ __forceinline__ void coop_barrier(unsigned* counter, unsigned target) {
   __syncthreads();  // the workgroup's partials are written
   if (threadIdx.x == 0) {
@@ -1559,6 +1562,53 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
         r[6] = acc.h01; r[7] = acc.hr.x; r[8] = acc.hr.y;
       }
       __syncthreads();
+#if HSM_COOP_TAGGED
+      // Exchange WITHOUT a barrier: every workgroup publishes its nine partials as three self-describing 16-byte granules
+      // {p, p, p, tag} (tag = the step's global sequence number) with device-coherent stores, and every workgroup polls the K
+      // records of the step until all their granules carry the tag.  A 16-byte sc0 sc1 store is observed untorn, sc1 loads are
+      // served by memory-side coherent L2 -- no release write-back, no acquire invalidate (1.7 us each on this machine), no
+      // counter round trip.  Two record buffers by step parity: a workgroup overwrites buffer s & 1 for step s + 2 only after
+      // it has read every workgroup's step-(s + 1) record, which that workgroup published after it finished reading step s.
+      const unsigned tag = bar_base + (unsigned)step + 1u;
+      f4v* const recs = reinterpret_cast<f4v*>(partials) + (size_t)(step & 1) * 64 * 3;
+      if (threadIdx.x < 3) {
+        const int t0 = 3 * (int)threadIdx.x;
+        f4v g;
+        g.x = ((red[0][t0] + red[1][t0]) + red[2][t0]) + red[3][t0];
+        g.y = ((red[0][t0 + 1] + red[1][t0 + 1]) + red[2][t0 + 1]) + red[3][t0 + 1];
+        g.z = ((red[0][t0 + 2] + red[1][t0 + 2]) + red[2][t0 + 2]) + red[3][t0 + 2];
+        g.w = __uint_as_float(tag);
+        f4v* dst = recs + 3 * blockIdx.x + threadIdx.x;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(g) : "memory");
+      }
+      if (wave == 0) {
+        Acc9 t;
+        t.zero();
+        const f4v* src = recs + 3 * (lane < K ? lane : 0);
+        f4v g0, g1, g2;
+        for (int spin = 0;; ++spin) {
+          asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                       "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                       "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(g0), "=&v"(g1), "=&v"(g2) : "v"(src) : "memory");
+          const bool ok = lane >= K || (__float_as_uint(g0.w) == tag && __float_as_uint(g1.w) == tag && __float_as_uint(g2.w) == tag);
+          if (__ballot(!ok) == 0ull || spin > (1 << 22)) break;  // (bounded: a lost workgroup must not hang the device)
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane < K) {
+          t.d01 = f2{g0.x, g0.y}; t.d2 = g0.z;
+          t.hd = f2{g1.x, g1.y}; t.h22 = g1.z;
+          t.h01 = g2.x; t.hr = f2{g2.y, g2.z};
+        }
+        wave_allreduce9(t);
+        if (lane == 0) {
+          tot[0] = t.d01.x; tot[1] = t.d01.y; tot[2] = t.d2;
+          tot[3] = t.hd.x; tot[4] = t.hd.y; tot[5] = t.h22;
+          tot[6] = t.h01; tot[7] = t.hr.x; tot[8] = t.hr.y;
+        }
+      }
+#else
       float* mine = partials + ((size_t)(step & 1) * K + blockIdx.x) * 9;
       if (threadIdx.x < 9) mine[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 #if HSM_COOP_BARRIER
@@ -1583,6 +1633,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
           tot[6] = t.h01; tot[7] = t.hr.x; tot[8] = t.hr.y;
         }
       }
+#endif
       __syncthreads();
       acc.d01 = f2{tot[0], tot[1]}; acc.d2 = tot[2];
       acc.hd = f2{tot[3], tot[4]}; acc.h22 = tot[5];

@@ -859,8 +859,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   CREATE_TRY(hipSetDevice(h->device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc((void**)&h->d_small, kSmallFloats * sizeof(float)));
-  CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 9 * sizeof(float) + 64));  // + the grid-barrier counter
-  CREATE_TRY(hipMemset(h->d_partials, 0, 2 * 64 * 9 * sizeof(float) + 64));
+  CREATE_TRY(hipMalloc((void**)&h->d_partials, 2 * 64 * 12 * sizeof(float) + 64));  // [2][64] records of 3 x {p,p,p,tag}; + the grid-barrier counter
+  CREATE_TRY(hipMemset(h->d_partials, 0, 2 * 64 * 12 * sizeof(float) + 64));
   CREATE_TRY(hipHostMalloc((void**)&h->h_small, kSmallFloats * sizeof(float),
                            hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_small, 0, kSmallFloats * sizeof(float));
@@ -1184,12 +1184,12 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   if (n >= h->coop_min_beams && h->wps_override == 0 && !h->exact) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
-    int K = (n + 1023) / 1024;  // ~4 beams per lane
+    int K = (n + 511) / 512;  // ~2 beams per lane (16 k beams: 79.8 / 71 / 66-70 / 64 us per matchData for K = 16 / 24 / 32 / 64)
     if (const char* env = getenv("HSM_COOP_K")) K = atoi(env);
     if (K > 64) K = 64;
     if (K < 2) K = 2;
     float* partials = h->d_partials;
-    unsigned* bar_counter = reinterpret_cast<unsigned*>(h->d_partials + 2 * 64 * 9);
+    unsigned* bar_counter = reinterpret_cast<unsigned*>(h->d_partials + 2 * 64 * 12);
     unsigned bar_base = h->coop_bar_base;
     void* args[] = {(void*)&P, (void*)&partials, (void*)&bar_counter, (void*)&bar_base};
     const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane>
@@ -2202,7 +2202,7 @@ int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value) {
   std::lock_guard<std::mutex> lk(h->mu);
   if (int rc = select_device(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(h->d_partials + 2 * 64 * 9, &value, sizeof value, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_partials + 2 * 64 * 12, &value, sizeof value, hipMemcpyHostToDevice));
   h->coop_bar_base = value;
   return HSM_OK;
 }
