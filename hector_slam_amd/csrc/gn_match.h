@@ -584,31 +584,32 @@ __device__ __forceinline__ void wave_allreduce9(Acc9& a) {
   a.hr.y = wave_allreduce(a.hr.y);
 }
 
-// team-wide totals: wave all-reduce, then (WPS > 1) LDS staging of the per-wave
-// partials; every thread of the team returns with identical bits.
+// team-wide totals: wave all-reduce, then (WPS > 1) LDS staging of the per-wave partials; every thread of the team
+// returns with identical bits.  The stage is TRANSPOSED, red[buf][term][wave]: after the barrier lane t (t < 9) reads the
+// WPS partials of term t as 16-byte rows and adds them in wave order (the same order as ever: w = 0, 1, 2, ...), and nine
+// v_readlane hand the totals to every lane as SGPRs -- 1 + 3 + 9 instructions for four waves instead of the 36 LDS reads
+// and 27 additions every lane used to do on its own (the exchange sits on the 14-step dependent chain of a single-scan
+// match: its cost grows with WPS, which is what held wider teams back).
 template <int WPS>
-__device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[WPS][9], int buf, int wave_in_team,
+__device__ __forceinline__ void team_allreduce9(Acc9& a, float (*red)[9][WPS < 4 ? 4 : WPS], int buf, int wave_in_team,
                                                 int lane) {
   wave_allreduce9(a);
   if (WPS > 1) {
     if (lane == 0) {
-      float* r = red[buf][wave_in_team];
-      r[0] = a.d01.x; r[1] = a.d01.y; r[2] = a.d2;
-      r[3] = a.hd.x; r[4] = a.hd.y; r[5] = a.h22;
-      r[6] = a.h01; r[7] = a.hr.x; r[8] = a.hr.y;
+      float(*r)[WPS < 4 ? 4 : WPS] = red[buf];
+      r[0][wave_in_team] = a.d01.x; r[1][wave_in_team] = a.d01.y; r[2][wave_in_team] = a.d2;
+      r[3][wave_in_team] = a.hd.x; r[4][wave_in_team] = a.hd.y; r[5][wave_in_team] = a.h22;
+      r[6][wave_in_team] = a.h01; r[7][wave_in_team] = a.hr.x; r[8][wave_in_team] = a.hr.y;
     }
     __syncthreads();
-    float t[9];
+    const float* row = red[buf][lane < 9 ? lane : 8];
+    float t = row[0];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = red[buf][0][k];
-#pragma unroll
-    for (int w = 1; w < WPS; ++w) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) t[k] += red[buf][w][k];
-    }
-    a.d01 = f2{t[0], t[1]}; a.d2 = t[2];
-    a.hd = f2{t[3], t[4]}; a.h22 = t[5];
-    a.h01 = t[6]; a.hr = f2{t[7], t[8]};
+    for (int w = 1; w < WPS; ++w) t += row[w];
+    auto total = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), k)); };
+    a.d01 = f2{total(0), total(1)}; a.d2 = total(2);
+    a.hd = f2{total(3), total(4)}; a.h22 = total(5);
+    a.h01 = total(6); a.hr = f2{total(7), total(8)};
   }
 }
 
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   static_assert(WPS == 1 || SPB == 1, "barrier-synchronised teams own their workgroup");
   static_assert(!EXACT || BPL == 0, "the exact-order form streams the endpoints");
   constexpr int T = 64 * WPS;  // lanes per team
-  __shared__ float red[2][WPS][9];
+  __shared__ __attribute__((aligned(16))) float red[2][9][WPS < 4 ? 4 : WPS];
   __shared__ float stage[EXACT ? SPB * 9 * (T + kExactPad) : 1];  // exact_round(): [team][term][beam of the round]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -824,10 +825,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
           for (int k = 0; k < 9; ++k) t[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(run), k));
         } else {
           // threads 0..8 publish; the next write of red[] lies behind the >= 2 barriers of the next step's rounds
-          if (tid_in_team < 9) red[0][0][tid_in_team] = run;
+          if (tid_in_team < 9) (&red[0][0][0])[tid_in_team] = run;
           __syncthreads();
 #pragma unroll
-          for (int k = 0; k < 9; ++k) t[k] = red[0][0][k];
+          for (int k = 0; k < 9; ++k) t[k] = (&red[0][0][0])[k];
         }
         acc.d01 = f2{t[0], t[1]}; acc.d2 = t[2];
         acc.hd = f2{t[3], t[4]}; acc.h22 = t[5];
@@ -973,7 +974,7 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
   static_assert(WPS == 1 || SPB == 1, "a pair of waves owns its workgroup (one barrier per GN step)");
   constexpr int T = 64 * WPS;  // lanes per scan
   __shared__ f2 lds_pts[SPB * WPS][BPL][64];
-  __shared__ float red[2][WPS][9];
+  __shared__ __attribute__((aligned(16))) float red[2][9][WPS < 4 ? 4 : WPS];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wit = __builtin_amdgcn_readfirstlane(wave % WPS);  // wave in team
@@ -1672,7 +1673,7 @@ template <int LAYOUT, bool EXACT = false>
 __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const float2* __restrict__ pts,
                                                       int n, float ex, float ey, float eth,
                                                       float* out12 /* H[9] col-major, dTr[3] */) {
-  __shared__ float red[2][16][9];
+  __shared__ __attribute__((aligned(16))) float red[2][9][16];
   __shared__ float stage[EXACT ? 9 * (1024 + kExactPad) : 1];
   const int lane = threadIdx.x & 63;
   const int wit = threadIdx.x >> 6;
@@ -1693,11 +1694,12 @@ __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const 
       beam_products(b, r, pr);
       run = exact_round<1024>(pr, stage, (int)threadIdx.x, run);
     }
-    if (threadIdx.x < 9) red[0][0][threadIdx.x] = run;
+    float* const redf = &red[0][0][0];
+    if (threadIdx.x < 9) redf[threadIdx.x] = run;
     __syncthreads();
-    acc.d01 = f2{red[0][0][0], red[0][0][1]}; acc.d2 = red[0][0][2];
-    acc.hd = f2{red[0][0][3], red[0][0][4]}; acc.h22 = red[0][0][5];
-    acc.h01 = red[0][0][6]; acc.hr = f2{red[0][0][7], red[0][0][8]};
+    acc.d01 = f2{redf[0], redf[1]}; acc.d2 = redf[2];
+    acc.hd = f2{redf[3], redf[4]}; acc.h22 = redf[5];
+    acc.h01 = redf[6]; acc.hr = f2{redf[7], redf[8]};
   } else {
     for (int i = threadIdx.x; i < n; i += 1024) {
       const float2 p = pts[i];
