@@ -435,6 +435,7 @@ int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stre
   const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
   if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
   if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
+  if (per_lane <= 3) return launch_match_t<WPS, SPB, 3>(h, P, stream);
   if (per_lane <= 5) return launch_match_t<WPS, SPB, 5>(h, P, stream);
   if (per_lane <= 9) return launch_match_t<WPS, SPB, 9>(h, P, stream);
   return launch_match_t<WPS, SPB, 17>(h, P, stream);
