@@ -34,9 +34,27 @@ def available(kind: str) -> bool:
     return os.path.exists(_LIBS[kind])
 
 
+def host_libm_is_fma_variant() -> bool:
+    """glibc >= 2.28 dispatches sincosf / expf to its *_fma ifunc variants on x86-64 CPUs with FMA + AVX2; those are the
+    variants the product's libm_exact.h restates operation for operation.  On any other host the checker's libm may differ
+    from the model in the last bit, and every "bit-exact against the reference" statement would silently compare against
+    another function."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                f = line.split()
+                return "fma" in f and "avx2" in f
+    except OSError:
+        pass
+    return False
+
+
 def _load(kind: str):
     if kind in _loaded:
         return _loaded[kind]
+    # the checker is only a checker of the bit-exact claims on a host whose libm is the one the model restates
+    assert host_libm_is_fma_variant(), ("oracle host without FMA + AVX2: glibc evaluates sincosf / expf unfused here, the "
+                                        "bit-exact parity of the device's libm (csrc/libm_exact.h) is UNPINNED on this host")
     if not os.path.exists(_LIBS[kind]):
         if kind == "ho":
             build()

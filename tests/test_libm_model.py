@@ -5,8 +5,9 @@ against glibc's sincosf / expf.  The default run covers every 61st float bit pat
 exponents, both signs, NaN/inf/denormals); `HSM_LIBM_SWEEP_STRIDE=1` sweeps all 2^32 (18 s on 8 cores; the result of
 that run is committed as profiles/r02/libm_model_exhaustive_cpu.txt: 0 mismatches for both functions).
 
-The model follows glibc's FMA ifunc variants (what any x86-64 CPU with FMA+AVX2 runs); on a host without FMA the
-test is skipped -- glibc then evaluates the same polynomials unfused and the last bit may differ.
+The model follows glibc's FMA ifunc variants (what any x86-64 CPU with FMA+AVX2 runs).  A host without FMA is not a valid
+checker host -- glibc then evaluates the same polynomials unfused and the last bit may differ: the test FAILS there (and
+oracle/pyoracle.py refuses to load), it does not skip.
 """
 import json
 import os
@@ -30,8 +31,7 @@ def _cpu_has_fma():
 
 @pytest.mark.parametrize("where", ["cpu", pytest.param("gpubox", marks=pytest.mark.gpu)])
 def test_libm_model_equals_host_libm(tmp_path, where):
-    if not _cpu_has_fma():
-        pytest.skip("host CPU without FMA/AVX2: glibc uses its unfused variants")
+    assert _cpu_has_fma(), "host CPU without FMA/AVX2: glibc uses its unfused sincosf / expf variants; parity would be unpinned"
     exe = tmp_path / "libm_model_check"
     subprocess.run(["g++", "-O2", "-ffp-contract=off", "-pthread", os.path.join(HERE, "cpp", "libm_model_check.cpp"),
                     "-o", str(exe), "-lm"], check=True)
