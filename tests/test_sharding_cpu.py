@@ -159,3 +159,41 @@ def test_two_rank_replica_replay_keeps_maps_identical():
         assert p.exitcode == 0
     assert all(same for _, same, _, _ in res) and not any(bad for _, _, bad, _ in res)
     assert res[0][3] == res[1][3] and all(d > 0 for d in res[0][3])
+
+
+def _worker_oversize(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from hector_slam_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sync = sharding.ReplicaSync(max_beams=16, device="cpu")
+        # a scan that fits, then one that does not: EVERY rank must raise (nobody may stay blocked in the collective), and the
+        # protocol must still work afterwards
+        ok1 = sync.broadcast(np.zeros(3, np.float32), np.ones((16, 2), np.float32))[1].shape == (16, 2) if rank == 0 else \
+            sync.broadcast(None, None)[1].shape == (16, 2)
+        raised = False
+        try:
+            sync.broadcast(np.zeros(3, np.float32), np.ones((17, 2), np.float32)) if rank == 0 else sync.broadcast(None, None)
+        except ValueError:
+            raised = True
+        after = sync.broadcast(np.full(3, 2.0, np.float32), np.full((3, 2), 5.0, np.float32)) if rank == 0 else sync.broadcast(None, None)
+        q.put((rank, bool(ok1), raised, after[0].tolist(), after[1].shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replica_broadcast_rejects_an_oversize_scan_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_oversize, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok1, raised, pose, shape in res:
+        assert ok1 and raised and pose == [2.0, 2.0, 2.0] and shape == (3, 2), (rank, ok1, raised, pose, shape)
