@@ -1081,6 +1081,9 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
       }
       rotate_wave_priority(it + l);
       float sinRot, cosRot;
+      // (the tolerance mode keeps glibc's sincosf: with v_sin_f32 / v_cos_f32 or a 1-ulp fp32 polynomial it is 15-20 % instead of
+      // 10-18 % faster than the fast mode, but one scan of the 32 768-scan sweep then lands 1.07e-4 m from the reference and
+      // the worst case of the 3-level batch grows from 7.6e-6 to 9.5e-5 m -- profiles/r03/README.md)
       sincos_f32<true>(eth, sinRot, cosRot);
       acc.zero();
       // the step's pose and rotation are wave-uniform: held in SGPRs (4 VGPRs less in a kernel that has none to spare)

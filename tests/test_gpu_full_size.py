@@ -272,6 +272,8 @@ def test_parity_sweep_32768_scans(capi, oracle_mod):
     exact = gpu_all()
     g.set_parity(capi.PARITY_FAST)
     fast = gpu_all()
+    g.set_parity(capi.PARITY_RELAXED)
+    relaxed = gpu_all()
     cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
     same = (bits(exact) == bits(cpu)).all(1)
     d = np.abs(fast.astype(np.float64) - cpu)
@@ -282,6 +284,13 @@ def test_parity_sweep_32768_scans(capi, oracle_mod):
     record(test="parity_sweep_32768", checker=KIND, exact_bit_identical_to_reference=int(same.sum()), scans=int(same.size),
            fast_bit_identical_to_reference=float(ident.mean()), fast_within_1e4=float(ok.mean()),
            fast_worst_dxy_m=float(d[:, :2].max()))
+    dr = np.abs(relaxed.astype(np.float64) - cpu)
+    okr = (dr[:, 0] <= TOL_M) & (dr[:, 1] <= TOL_M) & (ang_diff(relaxed[:, 2], cpu[:, 2]) <= TOL_RAD)
+    print(f"relaxed mode: within tolerance {okr.mean():.5f} ({int(okr.sum())}/{okr.size}), bit-identical "
+          f"{(bits(relaxed) == bits(cpu)).all(1).mean():.4f}, worst {dr[:, :2].max():.2e} m")
+    record(test="parity_sweep_32768_relaxed", checker=KIND, scans=int(okr.size), relaxed_within_1e4=float(okr.mean()),
+           relaxed_bit_identical_to_reference=float((bits(relaxed) == bits(cpu)).all(1).mean()), relaxed_worst_dxy_m=float(dr[:, :2].max()))
     assert same.all(), (~same).sum()
     assert ok.mean() >= 0.998 and ident.mean() >= 0.95
     assert d[:, :2].max() <= 1e-3
+    assert okr.mean() >= 0.998 and dr[:, :2].max() <= 1e-3  # the tolerance mode: the fast mode's bar
