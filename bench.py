@@ -963,7 +963,7 @@ def main():
 
     def kernel_of(cfg):
         if cfg.get("parity") == "exact":
-            return "gn_match_kernel"
+            return "gn_match_exact_cached_kernel" if cfg.get("texel_cache") else "gn_match_exact_batch_kernel"
         return "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"
 
     # ---------------- child legs -------------------------------------------------------------------------------
@@ -1078,7 +1078,7 @@ def main():
         out["exact_parity"] = {"mode": "HSM_PARITY_EXACT: H/dTr summed in the reference's beam order (9 sequential fp32 "
                                        "chains per scan); poses bit-identical to the reference",
                                "value": B * its * steps_x / dtx, "unit": "GN it/s", "kernel_ms": kx, "steps": steps_x,
-                               "kernel": kernel_of({"parity": "exact"}),
+                               "kernel": kernel_of(dict(matcher.last_launch_config(), parity="exact")),
                                "fast_vs_exact_all_scans": {
                                    "scans": B, "bit_identical": float((gpu_pose.view(np.uint32) == exact_pose.view(np.uint32)).all(1).mean()),
                                    "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()),
