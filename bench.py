@@ -821,6 +821,12 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
                                 "frac_at_measured_clock": rf["achieved"] / (1024 * sclk_hz / 2 / 1e9),
                                 "source": "s_memtime vs the 100 MHz wall clock over the lifetime of the wave of scan 0 in the last "
                                           "timed launch (hsm_set_clock_probe)"}
+    if rf.get("achieved"):
+        # what a stream of NOTHING BUT independent v_mul_f32 / v_add_f32 sustains on this part with the kernel's occupancy
+        # (tools/ubench_valu.hip, 4 wavefronts per SIMD, 30 back-to-back launches): 1.9 shader cycles per instruction, but the
+        # engine clock settles at 1.5-1.7 GHz under that load, so the chip issues 875-917 G wave64 instr/s, not 1228.8.
+        rf["sustained_valu_stream"] = {"G_wave64_instr_per_s": 900.0, "frac": rf["achieved"] / 900.0,
+                                       "source": "profiles/r03/ubench_valu.jsonl (measured once on MI355X; not re-measured in this run)"}
     return rf
 
 
