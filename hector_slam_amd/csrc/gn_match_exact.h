@@ -45,6 +45,10 @@ constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u <
 #ifndef HSM_XLDS_AHEAD
 #define HSM_XLDS_AHEAD 1
 #endif
+#ifndef HSM_XSTAGE9  // 1: producers stage the nine products (chain job = read + add); 0: the four factors (job multiplies)
+#define HSM_XSTAGE9 1
+#endif
+constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
 #endif
@@ -64,13 +68,13 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   constexpr int NB = NCP % 64 == 0 ? 2 : 3;
   // endpoint rows in VGPRs: what the LDS share of a workgroup (16 wavefronts per CU) does not hold next to the stage
   constexpr int kLdsShare = 160 * 1024 / (16 / NS);
-  constexpr int kRowsFit = (kLdsShare - NB * NS * 4 * kXRow * 4 - NC * 4 - 64) / (NS * 512);
+  constexpr int kRowsFit = (kLdsShare - NB * NS * kXRows * kXRow * 4 - NC * 4 - 64) / (NS * 512);
   constexpr int RV = BPL <= kRowsFit ? 0 : BPL - kRowsFit;
   static_assert(RV < BPL && RV <= 8, "endpoint rows kept in VGPRs");
   static_assert(64 * NS <= 1024, "one workgroup");
   // ONE shared object with the stage first: its LDS address must fit M0[15:0] (ds_write_addtid_b32 below)
   struct alignas(16) Smem {
-    float stage[NB][NS][4][kXRow];
+    float stage[NB][NS][kXRows][kXRow];
     float runs[NC];
     int nmax;
     f2 pts[NS][BPL - RV][64];
@@ -230,8 +234,34 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         const float gy = ((i2 - i0) * yFacInv) + ((i3 - i1) * fy);
         const float funVal = 1.0f - M;
         const float rotDeriv = r.r.x * gy - r.r.y * gx;
-        // four rows, lane l at row + 4 l: ds_write_addtid_b32 (address = M0 + offset + 4 * lane) needs no address VGPR and
-        // half the LDS cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS)
+        // lane l at row + 4 l: ds_write_addtid_b32 (address = M0 + offset + 4 * lane) needs no address VGPR and half the LDS
+        // cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).  M0 is reserved, not allocatable: nothing else in this kernel
+        // uses it (gfx9+ DS operations do not)
+        const unsigned m0v = st_wave + (unsigned)buf * (NS * kXRows * kXRow * 4);
+#if HSM_XSTAGE9
+        // the nine products of :83-97, one rounding each like the reference's; the chain lane only adds
+        const float p0 = gx * funVal, p1 = gy * funVal, p2 = rotDeriv * funVal;
+        const float p3 = gx * gx, p4 = gy * gy, p5 = rotDeriv * rotDeriv;
+        const float p6 = gx * gy, p7 = gx * rotDeriv, p8 = gy * rotDeriv;
+        asm volatile(
+            "s_mov_b32 m0, %[m]\n\t"
+            "s_nop 0\n\t"
+            "ds_write_addtid_b32 %[p0] offset:%[o0]\n\t"
+            "ds_write_addtid_b32 %[p1] offset:%[o1]\n\t"
+            "ds_write_addtid_b32 %[p2] offset:%[o2]\n\t"
+            "ds_write_addtid_b32 %[p3] offset:%[o3]\n\t"
+            "ds_write_addtid_b32 %[p4] offset:%[o4]\n\t"
+            "ds_write_addtid_b32 %[p5] offset:%[o5]\n\t"
+            "ds_write_addtid_b32 %[p6] offset:%[o6]\n\t"
+            "ds_write_addtid_b32 %[p7] offset:%[o7]\n\t"
+            "ds_write_addtid_b32 %[p8] offset:%[o8]"
+            :
+            : [m] "s"(m0v), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6),
+              [p7] "v"(p7), [p8] "v"(p8), [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4),
+              [o3] "n"(3 * kXRow * 4), [o4] "n"(4 * kXRow * 4), [o5] "n"(5 * kXRow * 4), [o6] "n"(6 * kXRow * 4),
+              [o7] "n"(7 * kXRow * 4), [o8] "n"(8 * kXRow * 4)
+            : "memory");
+#else
         asm volatile(
             "s_mov_b32 m0, %[m]\n\t"
             "s_nop 0\n\t"
@@ -240,9 +270,10 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
             "ds_write_addtid_b32 %[c] offset:%[o2]\n\t"
             "ds_write_addtid_b32 %[d] offset:%[o3]"
             :
-            : [m] "s"(st_wave + (unsigned)buf * (NS * 4 * kXRow * 4)), [a] "v"(gx), [b] "v"(gy), [c] "v"(rotDeriv), [d] "v"(funVal),
+            : [m] "s"(m0v), [a] "v"(gx), [b] "v"(gy), [c] "v"(rotDeriv), [d] "v"(funVal),
               [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4), [o3] "n"(3 * kXRow * 4)
-            : "memory");  // M0 is reserved, not allocatable: nothing else in this kernel uses it (gfx9+ DS operations do not)
+            : "memory");
+#endif
       };
       // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
       // running sum.  The two rows stream through three 16-byte slots each (24 VGPRs): a slot is refilled right after its
@@ -258,13 +289,32 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         const bool prev = u < k * NCP;
         const int ku = prev ? k - 1 : k, c = u - ku * NCP;  // round, chain
         if (u < units && c < NC) {
-          const int sj = (c * 57) >> 9, t = c - 9 * sj;  // scan of the workgroup (c / 9 for c < 144), term
-          const unsigned ra = (kTermRowA >> (2 * t)) & 3u, rb = (kTermRowB >> (2 * t)) & 3u;
           const int buf = prev ? (k + NB - 1) % NB : k % NB;
-          const float* base = &stage[0][0][0][0] + (buf * NS + sj) * (4 * kXRow);
+          float run = ku == 0 ? 0.0f : runs[c];
+#if HSM_XSTAGE9
+          // chain c = 9 scan + term is row c of the buffer; it streams through three 16-byte slots, a slot refilled right
+          // after its values are consumed
+          const f4v* pa = reinterpret_cast<const f4v*>(&stage[0][0][0][0] + (buf * NC + c) * kXRow);
+          f4v a[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a[q] = pa[q];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const f4v pr = a[q % 3];
+            run += pr.x;
+            run += pr.y;
+            run += pr.z;
+            run += pr.w;
+            asm volatile("" : "+v"(run) : : "memory");
+            if (q + 3 < 16) a[q % 3] = pa[q + 3];
+            asm volatile("" ::: "memory");
+          }
+#else
+          const int sj = (c * 57) >> 9, t = c - 9 * sj;  // scan of the workgroup (c / 9 for c < 144), term
+          const float* base = &stage[0][0][0][0] + (buf * NS + sj) * (kXRows * kXRow);
+          const unsigned ra = (kTermRowA >> (2 * t)) & 3u, rb = (kTermRowB >> (2 * t)) & 3u;
           const f4v* pa = reinterpret_cast<const f4v*>(base + ra * kXRow);
           const f4v* pb = reinterpret_cast<const f4v*>(base + rb * kXRow);
-          float run = ku == 0 ? 0.0f : runs[c];
           f4v a[3], b[3];
 #pragma unroll
           for (int q = 0; q < 3; ++q) a[q] = pa[q], b[q] = pb[q];
@@ -282,6 +332,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
             if (q + 3 < 16) a[q % 3] = pa[q + 3], b[q % 3] = pb[q + 3];
             asm volatile("" ::: "memory");
           }
+#endif
           runs[c] = run;
         }
       };
