@@ -49,6 +49,12 @@ constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u <
 #define HSM_XSTAGE9 1
 #endif
 constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
+#ifndef HSM_XOWNER_PRIO_P  // priority the job's owner keeps while it produces its next row (until the next barrier)
+#define HSM_XOWNER_PRIO_P 1
+#endif
+#ifndef HSM_XOWNER_SHIFT  // >= 0: the owner rotation of workgroup b starts at (b >> SHIFT) & 3 (workgroups of one CU out of phase)
+#define HSM_XOWNER_SHIFT 8
+#endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
 #endif
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   acc.zero();
   float reg_scale = 1.0f;
   int step_no = 0;
+  const int owner_phase = HSM_XOWNER_SHIFT >= 0 ? (int)((blockIdx.x >> (HSM_XOWNER_SHIFT >= 0 ? HSM_XOWNER_SHIFT : 0)) & 3u) : 0;
   // LDS byte address of this wavefront's stage rows in buffer 0 (wave-uniform; a generic LDS pointer's low half)
   const unsigned st_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&stage[0][wave][0][0]);
   for (int l = P.first_level; l >= P.last_level; --l) {
@@ -282,13 +289,15 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       // hand-scheduled body with the multiplications one slot ahead of the additions is no faster: what counts is the
       // instruction count, hence the packed multiplies and the division-free unit arithmetic.)
       auto chain_job = [&](int j, int k) {
-        // the lane index is re-read here (volatile asm): everything below depends on it, so the per-lane unit / address
-        // arithmetic of the ~20 jobs of a step is not hoisted out of the GN loop into VGPRs that are not there
-        const int u = 64 * j + lane_id_now();
+        // one job per round (NCP == 64): job j is round k, lane l is chain l -- nothing to derive
+        constexpr bool kOneJob = NCP == 64;
+        // otherwise the lane index is re-read here (volatile asm): everything below depends on it, so the per-lane unit /
+        // address arithmetic of the ~20 jobs of a step is not hoisted out of the GN loop into VGPRs that are not there
+        const int u = kOneJob ? 64 * k + lane : 64 * j + lane_id_now();
         // a job that completes with round k holds units of rounds k-1 and k only (64 <= NCP): no division
-        const bool prev = u < k * NCP;
-        const int ku = prev ? k - 1 : k, c = u - ku * NCP;  // round, chain
-        if (u < units && c < NC) {
+        const bool prev = kOneJob ? false : u < k * NCP;
+        const int ku = prev ? k - 1 : k, c = kOneJob ? lane : u - ku * NCP;  // round, chain
+        if ((kOneJob || u < units) && c < NC) {
           const int buf = prev ? (k + NB - 1) % NB : k % NB;
           float run = ku == 0 ? 0.0f : runs[c];
 #if HSM_XSTAGE9
@@ -337,15 +346,22 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         }
       };
       // round k is staged: meet, then (one wavefront) run the chain jobs that are complete with it
+      const int my_rounds =
+          __builtin_amdgcn_readfirstlane((int)((unsigned)(wave + 64 * NS - (step_no + owner_phase) % NS) % (unsigned)NS));
       auto round_done = [&](int k, bool last_round) {
+        if (HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int j_lo = (k * NCP) >> 6;
         const int j_hi = last_round ? (units + 63) >> 6 : ((k + 1) * NCP) >> 6;
         if (j_lo >= j_hi) return;
-        if (wave != (int)((unsigned)(k + step_no) % (unsigned)NS)) return;  // wave-uniform
+        // round k's owner is wave (k + step_no + phase) % NS.  Compared afresh in an SGPR at every round: kept as booleans
+        // across the unrolled rounds the NS outcomes come back through v_cndmask / v_cmp pairs in every round
+        int mine_now = my_rounds;
+        asm volatile("" : "+s"(mine_now));
+        if ((int)((unsigned)k % (unsigned)NS) != mine_now) return;
         __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
         for (int j = j_lo; j < j_hi; ++j) chain_job(j, k);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(HSM_XOWNER_PRIO_P);
       };
       {
         BeamRot rc, rn;
