@@ -55,6 +55,12 @@ constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #ifndef HSM_XOWNER_SHIFT  // >= 0: the owner rotation of workgroup b starts at (b >> SHIFT) & 3 (workgroups of one CU out of phase)
 #define HSM_XOWNER_SHIFT 8
 #endif
+#ifndef HSM_XPEEL  // the first GN step takes the endpoints from their load registers (gn_match_cached_kernel's peeled step)
+#define HSM_XPEEL 1
+#endif
+#ifndef HSM_XEP_AHEAD  // endpoint loads in flight ahead of the beam being located in that step
+#define HSM_XEP_AHEAD 2
+#endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
 #endif
@@ -128,17 +134,29 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   // rounds for scans longer than the host's length hint
   const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
   const int units = rounds * NCP;
-  const float2* __restrict__ pts = P.pts + beg;
+  const float2* __restrict__ pts = P.pts + (n > 0 ? beg : 0);  // an empty scan's loads (clamped to element 0) stay inside the array
   f2(*mine)[64] = lds_pts[wave];
   f2 pv[RV > 0 ? RV : 1];
+  // Endpoint staging.  All wavefronts of a launch start together and each needs its 8.6 KB of endpoints: 35 MB at once,
+  // 6 us with nothing to compute.  As in gn_match_cached_kernel the FIRST GN step of the first level is peeled: beam k
+  // takes its endpoint from the register of a load issued kEpAhead beams earlier (and stores it, scaled for the level,
+  // for the later steps), every lane gathers its texel (a level's first step), and all waits are counted from
+  // peel_schedule()'s static issue order.
+  constexpr bool kPeel = HSM_XPEEL != 0;
+  constexpr int kEpAhead = HSM_XEP_AHEAD < BPL ? HSM_XEP_AHEAD : BPL - 1;
+  static_assert(BPL <= 31, "PeelSchedule holds 32 positions per load kind");
+  constexpr PeelSchedule kSched = peel_schedule(BPL, kEpAhead);
+  const bool peel = kPeel && P.lv[P.first_level].gn_steps > 0;  // workgroup-uniform
+  if (!peel) {
 #pragma unroll
-  for (int k = 0; k < BPL; ++k) {
-    const int i = lane + 64 * k;
-    const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 contributions (gn_match_kernel)
-    if (k < RV)
-      pv[k] = f2{q.x, q.y};
-    else
-      mine[k - RV][lane] = f2{q.x, q.y};
+    for (int k = 0; k < BPL; ++k) {
+      const int i = lane + 64 * k;
+      const float2 q = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 contributions (gn_match_kernel)
+      if (k < RV)
+        pv[k] = f2{q.x, q.y};
+      else
+        mine[k - RV][lane] = f2{q.x, q.y};
+    }
   }
   f4v tq[BPC];
   unsigned toff[BPC];
@@ -160,9 +178,10 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
     const LevelRegs R = level_regs<kLayoutQuad>(L);
     const float ratio = ps / reg_scale;  // powers of two: exact
     reg_scale = ps;
+    const bool peel_here = peel && l == P.first_level;  // the peeled step stages the endpoints, scaled for this level
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
-      if (ratio != 1.0f) {
+      if (!peel_here && ratio != 1.0f) {
         if (k < RV)
           pv[k] *= f2{ratio, ratio};
         else
@@ -172,13 +191,39 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
     }
     unsigned zero_off = (unsigned)R.zero_index << 4;
     asm volatile("" : "+v"(zero_off));
-    for (int it = 0; it < gn_steps; ++it, ++step_no) {
+    // one GN step; FIRST = the peeled step (compile-time)
+    auto gn_step = [&](auto FIRST) {
+      constexpr bool kFirst = decltype(FIRST)::value;
+      f2 pq[kFirst ? BPL : 1];  // the peeled step's endpoint load registers
+      auto endpoint_issue = [&](int k) {
+        int i = max(min((int)lane_id_now() + 64 * k, n - 1), 0);
+        asm volatile("" : "+v"(i));  // the offset is computed at the load, not hoisted into 17 VGPRs
+        const unsigned byte_off = (unsigned)i << 3;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pq[kFirst ? k : 0]) : "v"(byte_off), "s"(pts) : "memory");
+      };
+      if (kFirst) {
+#pragma unroll
+        for (int k = 0; k <= kEpAhead; ++k) endpoint_issue(k);
+      }
       float sinRot, cosRot;
       sincos_f32<true>(eth, sinRot, cosRot);
       const f2 o2 = step_origin(ex, ey);
       const f2 e2 = f2{uniform_f32(o2.x), uniform_f32(o2.y)};
       const f2 cs = f2{uniform_f32(cosRot), uniform_f32(sinRot)}, sc = f2{cs.y, cs.x};
-      auto endpoint = [&](int k) -> f2 { return k < RV ? pv[k < RV ? k : 0] : mine[k < RV ? 0 : k - RV][lane]; };
+      auto endpoint = [&](int k) -> f2 {
+        if (kFirst) {  // from its load register (beam k's gather is the next load in issue order), padded, scaled, kept
+          wait_vmcnt(kSched.posG[k] - kSched.posE[k] - 1, pq[kFirst ? k : 0]);
+          const bool pad = (int)lane_id_now() + 64 * k >= n;
+          const f2 q = pq[kFirst ? k : 0];
+          const f2 p = f2{(pad ? 1.0e30f : q.x) * ps, (pad ? 1.0e30f : q.y) * ps};
+          if (k < RV)
+            pv[k < RV ? k : 0] = p;
+          else
+            mine[k < RV ? 0 : k - RV][lane] = p;
+          return p;
+        }
+        return k < RV ? pv[k < RV ? k : 0] : mine[k < RV ? 0 : k - RV][lane];
+      };
       // rotate, bounds test, cell offset, fractions; gather only in the lanes whose cell changed (gn_match_cached_kernel)
       f4v tu[2];  // texels of the uncached rows (k >= BPC), alternating
       auto locate = [&](int k, f2 p, BeamRot& r, float& fx, float& fy) -> unsigned long long {
@@ -195,6 +240,11 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
           return ~0ull;
         }
         const int kc = k < BPC ? k : 0;
+        if (kFirst) {  // a level's first step: every lane gathers (toff[] holds no offset yet); one load, statically counted
+          asm volatile("global_load_dwordx4 %[t], %[o], %[b]" : [t] "=v"(tq[kc]) : [o] "v"(off), [b] "s"(R.quad) : "memory");
+          toff[kc] = off;
+          return ~0ull;
+        }
         unsigned long long moved, saved;
         asm volatile(
             "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
@@ -212,7 +262,9 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       };
       auto texel_ready = [&](int k, unsigned long long next_moved, bool has_next) {
         f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
-        if (has_next && k + 1 >= BPC) {  // the next row's gather is unconditional
+        if (kFirst) {  // static schedule: everything issued after beam k's gather may still be in flight
+          wait_vmcnt((has_next ? kSched.posG[k + 1] + 1 : kSched.total) - kSched.posG[k] - 1, tx);
+        } else if (has_next && k + 1 >= BPC) {  // the next row's gather is unconditional
           asm volatile("s_waitcnt vmcnt(1)" : "+v"(tx) : : "memory");
         } else if (has_next) {
           asm volatile(
@@ -367,19 +419,20 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         BeamRot rc, rn;
         float fxc, fyc, fxn = 0.0f, fyn = 0.0f;
         unsigned long long next_moved = 0ull;
-#if HSM_XLDS_AHEAD
-        f2 p_next = endpoint(BPL > 1 ? 1 : 0);
-#endif
+        constexpr bool kAhead = HSM_XLDS_AHEAD != 0 && !kFirst;
+        f2 p_next = f2{0.0f, 0.0f};
+        if (kAhead) p_next = endpoint(BPL > 1 ? 1 : 0);
         locate(0, endpoint(0), rc, fxc, fyc);
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-#if HSM_XLDS_AHEAD  // endpoint of beam k+2 read from LDS before beam k+1 is located (two more VGPRs)
-          const f2 p_cur = p_next;
-          if (k + 2 < BPL) p_next = endpoint(k + 2);
-          if (k + 1 < BPL) next_moved = locate(k + 1, p_cur, rn, fxn, fyn);
-#else
-          if (k + 1 < BPL) next_moved = locate(k + 1, endpoint(k + 1), rn, fxn, fyn);
-#endif
+          if (kFirst && k + 1 + kEpAhead < BPL) endpoint_issue(k + 1 + kEpAhead);
+          if (kAhead) {  // endpoint of beam k+2 read from LDS before beam k+1 is located (two more VGPRs)
+            const f2 p_cur = p_next;
+            if (k + 2 < BPL) p_next = endpoint(k + 2);
+            if (k + 1 < BPL) next_moved = locate(k + 1, p_cur, rn, fxn, fyn);
+          } else {
+            if (k + 1 < BPL) next_moved = locate(k + 1, endpoint(k + 1), rn, fxn, fyn);
+          }
           texel_ready(k, next_moved, k + 1 < BPL);
           {
             const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
@@ -412,7 +465,14 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       }
       gn_solve_and_step(acc, ex, ey, eth);
       ex = uniform_f32(ex), ey = uniform_f32(ey), eth = uniform_f32(eth);
+    };
+    int it = 0;
+    if (kPeel && peel_here) {
+      gn_step(std::true_type{});
+      ++step_no;
+      it = 1;
     }
+    for (; it < gn_steps; ++it, ++step_no) gn_step(std::false_type{});
     eth = normalize_angle<true>(eth);
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
