@@ -61,6 +61,9 @@ constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #ifndef HSM_XEP_AHEAD  // endpoint loads in flight ahead of the beam being located in that step
 #define HSM_XEP_AHEAD 2
 #endif
+#ifndef HSM_XJOB_PAIRS  // chain job reads its row in 32-byte halves (one s_waitcnt per eight additions) instead of three 16-byte slots
+#define HSM_XJOB_PAIRS 1
+#endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
 #endif
@@ -356,6 +359,26 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
           // chain c = 9 scan + term is row c of the buffer; it streams through three 16-byte slots, a slot refilled right
           // after its values are consumed
           const f4v* pa = reinterpret_cast<const f4v*>(&stage[0][0][0][0] + (buf * NC + c) * kXRow);
+#if HSM_XJOB_PAIRS  // two 32-byte halves, one wait per eight additions (16 VGPRs)
+          f4v a[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = pa[q];
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const f4v p0 = a[2 * (h & 1)], p1 = a[2 * (h & 1) + 1];
+            run += p0.x;
+            run += p0.y;
+            run += p0.z;
+            run += p0.w;
+            run += p1.x;
+            run += p1.y;
+            run += p1.z;
+            run += p1.w;
+            asm volatile("" : "+v"(run) : : "memory");
+            if (h + 2 < 8) a[2 * (h & 1)] = pa[2 * h + 4], a[2 * (h & 1) + 1] = pa[2 * h + 5];
+            asm volatile("" ::: "memory");
+          }
+#else
           f4v a[3];
 #pragma unroll
           for (int q = 0; q < 3; ++q) a[q] = pa[q];
@@ -370,6 +393,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
             if (q + 3 < 16) a[q % 3] = pa[q + 3];
             asm volatile("" ::: "memory");
           }
+#endif
 #else
           const int sj = (c * 57) >> 9, t = c - 9 * sj;  // scan of the workgroup (c / 9 for c < 144), term
           const float* base = &stage[0][0][0][0] + (buf * NS + sj) * (kXRows * kXRow);
