@@ -436,6 +436,15 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         asm volatile("" : "+s"(mine_now));
         if ((int)((unsigned)k % (unsigned)NS) != mine_now) return;
         __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+#if defined(HSM_EXPERIMENTS) && defined(HSM_XWHATIF)  // timing experiment: every job runs twice (same sums: the second run starts from the first's input)
+        for (int j = j_lo; j < j_hi; ++j) {
+          const float keep = lane < NC ? runs[lane] : 0.0f;
+          chain_job(j, k);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane < NC) runs[lane] = keep;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#endif
         for (int j = j_lo; j < j_hi; ++j) chain_job(j, k);
         __builtin_amdgcn_s_setprio(HSM_XOWNER_PRIO_P);
       };
