@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         asm volatile("" : "+s"(mine_now));
         if ((int)((unsigned)k % (unsigned)NS) != mine_now) return;
         __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
-#if defined(HSM_EXPERIMENTS) && defined(HSM_XWHATIF)  // timing experiment: every job runs twice (same sums: the second run starts from the first's input)
+#if defined(HSM_EXPERIMENTS) && defined(HSM_XWHATIF) && HSM_XWHATIF == 1  // timing experiment: every job runs twice (same sums: the second run starts from the first's input)
         for (int j = j_lo; j < j_hi; ++j) {
           const float keep = lane < NC ? runs[lane] : 0.0f;
           chain_job(j, k);
@@ -466,6 +466,9 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
           } else {
             if (k + 1 < BPL) next_moved = locate(k + 1, endpoint(k + 1), rn, fxn, fyn);
           }
+#if defined(HSM_EXPERIMENTS) && defined(HSM_XWHATIF) && HSM_XWHATIF == 2  // timing experiment: a second workgroup barrier per round
+          asm volatile("s_barrier" ::: "memory");
+#endif
           texel_ready(k, next_moved, k + 1 < BPL);
           {
             const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
