@@ -5,29 +5,30 @@
 // one fp32 chain per term, beam 0 .. n-1 -- so H, dTr, every GN step (ScanMatcher.h:194-221), the pose and the
 // covariance are bit-identical to the reference CPU matcher.
 //
-// How (measurements and the variants that lost: profiles/r03/README.md):
+// How (measurements, what-if builds and the variants that lost: profiles/r03/README.md):
 //   * one wavefront per scan, NS scans per workgroup (4 as launched: one wavefront per SIMD and workgroup, four independent
 //     workgroups per CU); every wavefront is a PRODUCER with gn_match_cached_kernel's machinery: the last texel + byte
 //     offset of its first BPC beams per lane stay in VGPRs (the other rows gather in every step), exec-masked inline-asm
 //     gathers issued one beam ahead with counted s_waitcnt, endpoints in LDS (the first rows in VGPRs where the LDS share
-//     of 16 scans per CU does not hold all rows next to the stage);
-//   * per ROUND k (beam k of every lane = beams 64k .. 64k+63 of the scan) a producer stages FOUR values per beam --
-//     gx, gy (the source's dM/dx, dM/dy), rotDeriv, funVal -- not the nine products: every product of :83-97 is a
-//     product of two of those four, so the chain lane multiplies (unfused, one rounding, like the reference) and adds;
-//     4 instead of 9 LDS rows per scan is what lets the stage and the endpoints of 16 scans share 160 KB;
+//     of 16 scans per CU does not hold all rows next to the stage), the first GN step peeled (endpoints straight from
+//     their load registers while they stream in);
+//   * per ROUND k (beam k of every lane = beams 64k .. 64k+63 of the scan) a producer stages the NINE products of
+//     :83-97 (each one rounding, like the reference's) in LDS rows, written with ds_write_addtid_b32;
 //   * the chains: 9 NS sequential sums per workgroup, 64 additions each per round.  A chain JOB is one wavefront whose
-//     lane l runs chain-round unit u = 64 j + l.  NS = 4: a round is padded to 64 units -- one 36-lane job per round, two
-//     stage buffers.  NS >= 8 (9 NS >= 64 chains): u = k * 9 NS + (9 scan + term), jobs PACKED across round boundaries
-//     so that all 64 lanes work, three stage buffers (a job may still read round k-1's rows); a chain's running sum
-//     travels from job to job through LDS.  The jobs that complete with round k run right behind round k's barrier on
-//     ONE wavefront, the owner rotating from round to round, while the other wavefronts already produce round k+1; one
-//     workgroup barrier per round.
-//   * a job's length is its instruction count (a single wavefront issues an instruction every 4-5 cycles whatever it is):
-//     two v_pk_mul_f32 per 16-byte slot, no divisions in the unit arithmetic -- 176 instructions per job.
+//     lane l runs chain l of the round: 64 dependent v_add_f32 fed by ds_read_b128 in 32-byte halves.  The job of round k
+//     runs right behind round k's barrier on ONE wavefront, the owner rotating from round to round (out of phase between the
+//     workgroups of a CU), while the other wavefronts already produce round k+1; one workgroup barrier per round; a
+//     chain's running sum travels from job to job through LDS.  (NS >= 8 -- 72+ chains -- packs jobs across round
+//     boundaries, u = k * 9 NS + chain, three stage buffers; kept in the template, not launched.)
+//   * what bounds it (measured): a dependent v_add_f32 of a lone wavefront costs 8.5 cycles (tools/ubench_chain.hip), so a
+//     job is >= 544 cycles however few instructions surround the additions, and it sits on the round's critical path
+//     together with its owner's own production (a build that runs every job twice is 28 us = 102 x 590 cycles slower).
+//     Hence: everything that can be done by the producers in parallel is done there (the multiplications), the owner
+//     keeps a raised priority until its next row is staged, and the job itself is only reads + adds.
 //   Same arithmetic on the same texels in the same order as gn_match_kernel<.., EXACT>: identical bits.
-//   Against round 2's producer / chain-wavefront form (gn_match_exact_batch_kernel: endpoints streamed, no texel cache,
-//   nine staged products): 89 vs 92 us on the 2048^2 headline batch, 195 vs 199 us on the 3-level batch, 199 vs 291 us on
-//   the 4096^2 pyramid, whose gathers miss the L2.
+//   Against round 2's producer / chain-wavefront form (gn_match_exact_batch_kernel: endpoints streamed, no texel cache):
+//   66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the 3-level batch, 156-162 vs 291 us on the 4096^2
+//   pyramid, whose gathers miss the L2.
 #pragma once
 #include "gn_match.h"
 
@@ -68,8 +69,8 @@ constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #define HSM_XJOB_PRIO 3
 #endif
 
-// BPL rows of beams per lane, the first BPC of them with a cached texel (5 VGPRs per row: the chain jobs need ~28
-// VGPRs of their own for the LDS rows they keep in flight, which 17 cached rows + 4 endpoint rows do not leave at 128);
+// BPL rows of beams per lane, the first BPC of them with a cached texel (5 VGPRs per row; a chain job needs 16 VGPRs for
+// the LDS rows it keeps in flight and 7 endpoint rows live in VGPRs, which 17 cached rows do not leave at 128);
 // rows BPC .. BPL-1 gather in every step.
 template <int NS, int BPL, int BPC = BPL>
 __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const MatchParams P) {

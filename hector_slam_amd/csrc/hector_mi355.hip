@@ -370,8 +370,8 @@ template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
   // 36-lane chain job per round behind the round's barrier (gn_match_exact.h).  Measured against round 2's producer /
-  // chain-wavefront form below (profiles/r03/README.md): 89 vs 92 us on the 2048^2 headline batch, 195 vs 199 us on the
-  // 3-level batch, 199 vs 291 us on the 4096^2 pyramid.  env HSM_EXACT_CACHED=0 keeps round 2's form.
+  // chain-wavefront form below (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
+  // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  env HSM_EXACT_CACHED=0 keeps round 2's form.
   if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
     const int per_lane = (max_n + 63) / 64;
     if (per_lane <= 17 + 4) {  // scans of up to 17 beams per lane (up to four rows more stream their tail)
