@@ -65,6 +65,9 @@ constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #ifndef HSM_XJOB_PAIRS  // chain job reads its row in 32-byte halves (one s_waitcnt per eight additions) instead of three 16-byte slots
 #define HSM_XJOB_PAIRS 1
 #endif
+#ifndef HSM_XGATHER_ALWAYS  // lane 0 re-reads its texel at every beam: exactly one load per beam, static waits, no branches
+#define HSM_XGATHER_ALWAYS 0
+#endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
 #endif
@@ -250,6 +253,19 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
           return ~0ull;
         }
         unsigned long long moved, saved;
+#if HSM_XGATHER_ALWAYS
+        asm volatile(
+            "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
+            "s_or_b32 vcc_lo, vcc_lo, 1\n\t"
+            "s_and_saveexec_b64 %[sv], vcc\n\t"
+            "global_load_dwordx4 %[t], %[o], %[b]\n\t"
+            "v_mov_b32 %[to], %[o]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [t] "+v"(tq[kc]), [to] "+v"(toff[kc]), [sv] "=&s"(saved)
+            : [o] "v"(off), [b] "s"(R.quad)
+            : "vcc", "scc", "memory");
+        return ~0ull;
+#endif
         asm volatile(
             "v_cmp_ne_u32 vcc, %[o], %[to]\n\t"
             "s_mov_b64 %[mv], vcc\n\t"
@@ -268,7 +284,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
         if (kFirst) {  // static schedule: everything issued after beam k's gather may still be in flight
           wait_vmcnt((has_next ? kSched.posG[k + 1] + 1 : kSched.total) - kSched.posG[k] - 1, tx);
-        } else if (has_next && k + 1 >= BPC) {  // the next row's gather is unconditional
+        } else if (has_next && (k + 1 >= BPC || HSM_XGATHER_ALWAYS)) {  // the next row's gather is unconditional
           asm volatile("s_waitcnt vmcnt(1)" : "+v"(tx) : : "memory");
         } else if (has_next) {
           asm volatile(
