@@ -210,6 +210,36 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch 
   mark_occ_block(B.lv[blockIdx.y], blockIdx.x);
 }
 
+#ifndef HSM_DENSE_FLAGS  // dense scans: "a beam ends here" is bit 1 of the cell's mark byte instead of the row-major end-cell bitmap
+#define HSM_DENSE_FLAGS 1
+#endif
+constexpr unsigned char kMarkCrossed = 1, kMarkEnd = 2;
+
+// pass 1a of a dense scan (HSM_DENSE_FLAGS): the occ key as above; the end-cell flag goes into the cell's MARK BYTE (value 2)
+// -- the byte the line walk of pass 1b reads and writes anyway, in the same tiled plane -- and the bitmap is not touched.
+// All writers of a byte store the same value; the launch boundary orders them before pass 1b.
+__global__ void __launch_bounds__(256) update_mark_occ_dense_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  const int beam = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (((int)(blockIdx.x * blockDim.x) + (int)(threadIdx.x & ~63u)) >= P.n) return;  // whole wave beyond the scan
+  bool valid = beam < P.n;
+  unsigned int c = 0xffffffffu, kc = 0u;
+  if (valid) {
+    const BeamLine b = beam_line(P, beam);
+    valid = b.valid;
+    if (valid) {
+      c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
+      kc = key_free_index(P.lv, (unsigned int)b.x1, (unsigned int)b.y1);
+    }
+  }
+  const unsigned int c_prev = (unsigned int)__shfl_up((int)c, 1);
+  if (valid && (lane == 0 || c_prev != c)) {  // of a run of adjacent lanes with the same end cell the first = lowest beam index
+    atomicMax(&P.lv.key_occ[c], (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam));
+    P.lv.free_bytes[kc] = kMarkEnd;
+  }
+}
+
 // pass 1b: line cells (after 1a has completed).  WHICH beam crossed a cell first only matters
 // where some beam also ENDS (the free-then-occupied revert, OccGridMapBase.h:231-233); everywhere
 // else "some beam of this scan crossed it" is all the apply pass needs.  So a cell that is nobody's
@@ -389,45 +419,114 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
 //     there is no race on the marks, and the byte map is all zero again between updates (no generation tag to wrap).
 //     Untouched cells cost 1 byte + 1 bit instead of 4 bytes + 1 bit.
 // Same cells, same rule, same order-dependent artefacts: the maps stay bit-identical to the reference.
+#ifndef HSM_MARK_XCD_CHUNK  // workgroups of consecutive beams per XCD turn (xcd_block); < 0: the hardware's round robin
+#define HSM_MARK_XCD_CHUNK 16
+#endif
+__host__ __device__ __forceinline__ int mark_dense_blocks(int n) {  // workgroups of 4 wavefronts, a multiple of 8 (see the kernel)
+  return ((n + 3) / 4 + 7) / 8 * 8;
+}
+
+// a wave-uniform kernel argument pinned in SGPRs before a loop (left alone, the compiler re-loads it from the kernarg segment
+// -- s_load + s_waitcnt -- inside every conditional block of every iteration)
+template <class T>
+__device__ __forceinline__ T pinned_sgpr(T v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// What bounds this kernel was measured (profiles/r03/README.md, what-if builds): with NO memory operation in the walk it
+// still took 50 of its 77 us -- instruction issue, not HBM, L2 atomics or load latency (unrolling the walk for four loads in
+// flight, several beams per wavefront, plain stores instead of the atomics: no gain).  So the walk is kept short: the cell
+// coordinates advance incrementally (no multiplications: v_mad_u64_u32 / v_mul_lo_u32 are quarter rate), the tile row
+// offset is a 24-bit multiply, the kernel arguments sit in SGPRs, the per-beam divisions are float reciprocals with an
+// exact fix-up (every operand is below 2^24).
+__device__ __forceinline__ unsigned int div_small(unsigned int num, unsigned int den) {  // num, den < 2^24, den > 0: exact
+  unsigned int q = (unsigned int)(__builtin_amdgcn_rcpf((float)den) * (float)num);
+  // the estimate is within one of the quotient
+  int rem = (int)(num - q * den);
+  if (rem < 0) {
+    --q;
+    rem += (int)den;
+  }
+  if (rem >= (int)den) ++q;
+  return q;
+}
+
 __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int beam = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // Neighbouring beams cross the same cells for most of their length, and a mark byte read from another XCD's L2 is stale
+  // (this kernel's stores stay in the writer's L2 until they are evicted): with the hardware's round robin of workgroups
+  // over the XCDs every XCD walks every part of the fan.  Chunks of consecutive workgroups per XCD (the grid's x extent is
+  // a multiple of 8, so workgroup b of any level runs on XCD b % 8) keep a sector's lines in ONE L2, where the walk sees
+  // its neighbours' marks and skips the stores.
+  const int wg = HSM_MARK_XCD_CHUNK >= 0 ? xcd_block((int)blockIdx.x, (int)gridDim.x, HSM_MARK_XCD_CHUNK) : (int)blockIdx.x;
+  const int beam = wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
   const unsigned int key = (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam);
   if ((unsigned int)lane >= b.abs_da) return;
+  // lane k visits steps k, k + 64, ...: quotient / remainder of (e0 + i*db) / da carried forward by the per-64-steps increment
+  const bool small = b.abs_da < (1u << 17);  // (e0 + 63 db, 64 db < 2^24: always, for maps below 131072 cells a side)
   const unsigned int num0 = b.e0 + (unsigned int)lane * b.abs_db;
-  unsigned int q = num0 / b.abs_da, r = num0 - q * b.abs_da;
+  unsigned int q = small ? div_small(num0, b.abs_da) : num0 / b.abs_da;
+  unsigned int r = num0 - q * b.abs_da;
   const unsigned int inc = 64u * b.abs_db;
-  const unsigned int q64 = inc / b.abs_da, r64 = inc - q64 * b.abs_da;
+  const unsigned int q64 = small ? div_small(inc, b.abs_da) : inc / b.abs_da, r64 = inc - q64 * b.abs_da;
+  // duplicate suppression against the previous beam (mark_free_block)
   const BeamLine pb = beam > 0 ? beam_line(P, beam - 1) : b;
   const bool dedup = beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
+  const bool psmall = pb.abs_da < (1u << 17);
+  const unsigned int pden = dedup ? pb.abs_da : 1u;
   const unsigned int pnum0 = pb.e0 + (unsigned int)lane * pb.abs_db;
-  unsigned int pq = dedup ? pnum0 / pb.abs_da : 0u, pr = dedup ? pnum0 - pq * pb.abs_da : 0u;
+  unsigned int pq = dedup ? (psmall ? div_small(pnum0, pden) : pnum0 / pden) : 0u, pr = dedup ? pnum0 - pq * pden : 0u;
   const unsigned int pinc = 64u * pb.abs_db;
-  const unsigned int pq64 = dedup ? pinc / pb.abs_da : 0u, pr64 = dedup ? pinc - pq64 * pb.abs_da : 0u;
+  const unsigned int pq64 = dedup ? (psmall ? div_small(pinc, pden) : pinc / pden) : 0u, pr64 = dedup ? pinc - pq64 * pden : 0u;
   const unsigned int pda = dedup ? pb.abs_da : 0u;  // no step is "also the previous beam's" without dedup
-  // the walk in (x, y): i steps along the major axis, q along the minor one (wave-uniform direction, hoisted out of the loop)
+  // the walk in (x, y): i steps along the major axis, q along the minor one; both advance by additions
   const int sgn_a = b.offset_a > 0 ? 1 : -1, sgn_b = b.offset_b > 0 ? 1 : -1;
   const int ax = b.x_major ? sgn_a : 0, ay = b.x_major ? 0 : sgn_a, mx = b.x_major ? 0 : sgn_b, my = b.x_major ? sgn_b : 0;
-  for (unsigned int i = lane; i < b.abs_da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
+  int cx = P.bx + ax * lane + mx * (int)q, cy = P.by + ay * lane + my * (int)q;
+  const int dx64 = 64 * ax + mx * (int)q64, dy64 = 64 * ay + my * (int)q64;  // per iteration, before the remainder's carry
+  const unsigned int tiles_x = pinned_sgpr((unsigned int)P.lv.kf_tiles_x);
+  unsigned char* const marks = pinned_sgpr(P.lv.free_bytes);
+  unsigned int* const keys = pinned_sgpr(P.lv.key_free);
+  const unsigned int da = b.abs_da;
+  for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
-      const unsigned int cx = (unsigned int)(P.bx + ax * (int)i + mx * (int)q), cy = (unsigned int)(P.by + ay * (int)i + my * (int)q);
-      const unsigned int c = cy * (unsigned int)P.lv.sx + cx;  // == line_cell(b, i)
-      const unsigned int kc = key_free_index(P.lv, cx, cy);
-      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {
-        atomicMax(&P.lv.key_free[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
-      } else {
-        P.lv.free_bytes[kc] = 1;
+#if HSM_KEYFREE_TILE
+      const unsigned int kc = ((__umul24((unsigned int)cy >> 2, tiles_x) + ((unsigned int)cx >> 3)) << 5) | (((unsigned int)cy & 3u) << 3) |
+                              ((unsigned int)cx & 7u);  // == key_free_index(P.lv, cx, cy): rows of tiles and tiles per row are below 2^24
+#else
+      const unsigned int kc = key_free_index(P.lv, (unsigned int)cx, (unsigned int)cy);
+#endif
+#if HSM_DENSE_FLAGS
+      // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
+      const unsigned char m = marks[kc];
+      if (m & kMarkEnd) {
+        atomicMax(&keys[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
+      } else if (m == 0) {          // (a stale 0 only repeats the store)
+        marks[kc] = kMarkCrossed;
       }
+#else
+      const unsigned int c = (unsigned int)cy * (unsigned int)P.lv.sx + (unsigned int)cx;  // == line_cell(b, i)
+      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {
+        atomicMax(&keys[kc], key);
+      } else {
+        marks[kc] = 1;
+      }
+#endif
     }
     q += q64;
     r += r64;
-    if (r >= b.abs_da) {
-      r -= b.abs_da;
+    cx += dx64;
+    cy += dy64;
+    if (r >= da) {
+      r -= da;
       ++q;
+      cx += mx;
+      cy += my;
     }
     pq += pq64;
     pr += pr64;
@@ -456,14 +555,16 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
     const unsigned int tile0 = (((unsigned int)(Y0 >> 2) * (unsigned int)P.lv.kf_tiles_x) + (unsigned int)(X0 >> 3)) << 5;  // byte index
     unsigned int* const fwp = reinterpret_cast<unsigned int*>(P.lv.free_bytes + tile0) + lane;
     const unsigned int fw = *fwp;
-    unsigned int ow[4];
+    unsigned int ow[4] = {0u, 0u, 0u, 0u};
     bool any = fw != 0u;
+#if !HSM_DENSE_FLAGS
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy) {
       const int y = Y0 + dy;
       ow[dy] = y < P.lv.sy ? P.lv.occ_bits[((size_t)y * P.lv.sx + x) >> 5] : 0u;
       any |= ow[dy] != 0u;
     }
+#endif
     if (__ballot(any) == 0ull) continue;  // nothing of this scan in the block
     if (fw != 0u) *fwp = 0u;
 #pragma unroll
@@ -471,11 +572,17 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
       const int y = Y0 + dy;
       if (y >= P.lv.sy) break;
       const size_t c = (size_t)y * P.lv.sx + x;
-      if (ow[dy] != 0u && (lane & 31) == 0) P.lv.occ_bits[c >> 5] = 0u;
-      bool occ = (ow[dy] >> (lane & 31)) & 1u;
       // the byte of cell (x, Y0 + dy): tile lane / 8, byte dy * 8 + lane % 8 = dword (lane & ~7) + 2 dy + (lane & 7) / 4, byte lane & 3
       const unsigned int fwd = (unsigned int)__shfl((int)fw, (lane & ~7) + 2 * dy + ((lane & 7) >> 2));
-      bool fre = ((fwd >> ((lane & 3) << 3)) & 0xffu) != 0u;
+      const unsigned int mark = (fwd >> ((lane & 3) << 3)) & 0xffu;
+#if HSM_DENSE_FLAGS
+      bool occ = (mark & kMarkEnd) != 0u;
+      bool fre = (mark & kMarkCrossed) != 0u;
+#else
+      if (ow[dy] != 0u && (lane & 31) == 0) P.lv.occ_bits[c >> 5] = 0u;
+      bool occ = (ow[dy] >> (lane & 31)) & 1u;
+      bool fre = mark != 0u;
+#endif
       if (!fre && !occ) continue;
       unsigned int ko = 0u, kf = 0u;
       if (occ) {
