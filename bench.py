@@ -347,7 +347,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                "achieved": upd_alg_bytes / (t_upd / args.steps) / 1e9, "frac": upd_alg_bytes / (t_upd / args.steps) / HBM_PEAK,
                "time_basis": "update_ms of the step (host timed: step - matchData)", "traffic": None, "kernels": None}
         if not args.no_pmc and nranks == 1 and not under_profiler():
-            names = ["update_mark_occ_kernel", "update_mark_free_dense_kernel", "update_apply_dense_kernel", "update_mark_free_kernel",
+            names = ["update_mark_occ_dense_kernel", "update_mark_occ_kernel", "update_mark_free_dense_kernel", "update_apply_dense_kernel", "update_mark_free_kernel",
                      "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel"]
             pv, perr = pmc_collect(["--workload", "config5", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=2)
             if pv:

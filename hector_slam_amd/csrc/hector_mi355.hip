@@ -697,11 +697,7 @@ int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
     if (batch.lv[i].n > max_n) max_n = batch.lv[i].n;
   const unsigned ny = (unsigned)batch.nlev;
   if (use_dense_bits(h, batch, max_n)) {
-#if HSM_DENSE_FLAGS
     hipLaunchKernelGGL(update_mark_occ_dense_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
-#else
-    hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
-#endif
     // x extent a multiple of 8: workgroup b of every level then runs on XCD b % 8 (the kernel's beam -> XCD mapping)
     hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3(mark_dense_blocks(max_n), ny), dim3(256), 0, h->stream, batch);
     HIP_TRY(hipGetLastError());

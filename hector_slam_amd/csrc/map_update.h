@@ -210,12 +210,10 @@ __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch 
   mark_occ_block(B.lv[blockIdx.y], blockIdx.x);
 }
 
-#ifndef HSM_DENSE_FLAGS  // dense scans: "a beam ends here" is bit 1 of the cell's mark byte instead of the row-major end-cell bitmap
-#define HSM_DENSE_FLAGS 1
-#endif
+// dense scans: "a beam ends here" is bit 1 of the cell's mark byte instead of a bit of the row-major end-cell bitmap
 constexpr unsigned char kMarkCrossed = 1, kMarkEnd = 2;
 
-// pass 1a of a dense scan (HSM_DENSE_FLAGS): the occ key as above; the end-cell flag goes into the cell's MARK BYTE (value 2)
+// pass 1a of a dense scan: the occ key as above; the end-cell flag goes into the cell's MARK BYTE (value 2)
 // -- the byte the line walk of pass 1b reads and writes anyway, in the same tiled plane -- and the bitmap is not touched.
 // All writers of a byte store the same value; the launch boundary orders them before pass 1b.
 __global__ void __launch_bounds__(256) update_mark_occ_dense_kernel(const UpdateBatch B) {
@@ -501,7 +499,6 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
 #else
       const unsigned int kc = key_free_index(P.lv, (unsigned int)cx, (unsigned int)cy);
 #endif
-#if HSM_DENSE_FLAGS
       // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
       const unsigned char m = marks[kc];
       if (m & kMarkEnd) {
@@ -509,14 +506,6 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
       } else if (m == 0) {          // (a stale 0 only repeats the store)
         marks[kc] = kMarkCrossed;
       }
-#else
-      const unsigned int c = (unsigned int)cy * (unsigned int)P.lv.sx + (unsigned int)cx;  // == line_cell(b, i)
-      if ((P.lv.occ_bits[c >> 5] >> (c & 31u)) & 1u) {
-        atomicMax(&keys[kc], key);
-      } else {
-        marks[kc] = 1;
-      }
-#endif
     }
     q += q64;
     r += r64;
@@ -538,6 +527,9 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
 }
 
 // requires sx % 64 == 0 and HSM_KEYFREE_TILE (the host checks): the box is widened to 64-column / 4-row boundaries
+#ifndef HSM_APPLY_BLOCKS  // 64 x 4-cell blocks a wavefront of the dense apply pass has in flight
+#define HSM_APPLY_BLOCKS 1
+#endif
 template <bool SCATTER_TEXELS>
 __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
@@ -547,83 +539,108 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
   const int nbx = ((P.x1 | 63) - bx0 + 1) >> 6, nby = (((P.y1 | 3) - by0) >> 2) + 1;
   const int nblocks = nbx * nby;
   const int waves = (int)((gridDim.x * blockDim.x) >> 6);
-  for (int blk = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); blk < nblocks; blk += waves) {
+  const int sx = P.lv.sx, sy = P.lv.sy;
+  // A wavefront's blocks are a chain of memory round trips (marks -> log-odds rows -> stores), a dozen blocks long, and the
+  // pass was waiting for them 84 % of the time (profiles/r03/README.md).  So the marks of the NEXT block are requested
+  // before this one is processed, and the rows of a block are all requested before the first is computed.
+  // the block's 256 mark bytes: lane l reads ONE dword of them (tile l / 8, row (l % 8) / 2, half l % 2)
+  auto marks_of = [&](int blk) -> unsigned int* {
     const int X0 = bx0 + ((blk % nbx) << 6), Y0 = by0 + ((blk / nbx) << 2);
-    const int x = X0 + lane;
-    // the block's 256 mark bytes: lane l reads ONE dword of them (tile l / 8, row (l % 8) / 2, half l % 2) -- and its 8
-    // end-cell words (two per row)
     const unsigned int tile0 = (((unsigned int)(Y0 >> 2) * (unsigned int)P.lv.kf_tiles_x) + (unsigned int)(X0 >> 3)) << 5;  // byte index
-    unsigned int* const fwp = reinterpret_cast<unsigned int*>(P.lv.free_bytes + tile0) + lane;
-    const unsigned int fw = *fwp;
-    unsigned int ow[4] = {0u, 0u, 0u, 0u};
-    bool any = fw != 0u;
-#if !HSM_DENSE_FLAGS
+    return reinterpret_cast<unsigned int*>(P.lv.free_bytes + tile0) + lane;
+  };
+  // kApplyBlocks blocks per iteration: their rows are all in flight together (Little's law: 32 wavefronts per CU with
+  // four 256-byte rows each in flight sustain ~4 TB/s at this latency, which is what the one-block form measured)
+  constexpr int NBLK = HSM_APPLY_BLOCKS;
+  int blk = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * NBLK;
+  if (blk >= nblocks) return;
+  unsigned int fw_next[NBLK];
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-      const int y = Y0 + dy;
-      ow[dy] = y < P.lv.sy ? P.lv.occ_bits[((size_t)y * P.lv.sx + x) >> 5] : 0u;
-      any |= ow[dy] != 0u;
-    }
-#endif
-    if (__ballot(any) == 0ull) continue;  // nothing of this scan in the block
-    if (fw != 0u) *fwp = 0u;
+  for (int j = 0; j < NBLK; ++j) fw_next[j] = blk + j < nblocks ? *marks_of(blk + j) : 0u;
+  for (; blk < nblocks; blk += waves * NBLK) {
+    unsigned int fw[NBLK];
+    bool live[NBLK];
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-      const int y = Y0 + dy;
-      if (y >= P.lv.sy) break;
-      const size_t c = (size_t)y * P.lv.sx + x;
-      // the byte of cell (x, Y0 + dy): tile lane / 8, byte dy * 8 + lane % 8 = dword (lane & ~7) + 2 dy + (lane & 7) / 4, byte lane & 3
-      const unsigned int fwd = (unsigned int)__shfl((int)fw, (lane & ~7) + 2 * dy + ((lane & 7) >> 2));
-      const unsigned int mark = (fwd >> ((lane & 3) << 3)) & 0xffu;
-#if HSM_DENSE_FLAGS
-      bool occ = (mark & kMarkEnd) != 0u;
-      bool fre = (mark & kMarkCrossed) != 0u;
-#else
-      if (ow[dy] != 0u && (lane & 31) == 0) P.lv.occ_bits[c >> 5] = 0u;
-      bool occ = (ow[dy] >> (lane & 31)) & 1u;
-      bool fre = mark != 0u;
-#endif
-      if (!fre && !occ) continue;
-      unsigned int ko = 0u, kf = 0u;
-      if (occ) {
-        ko = P.lv.key_occ[c];
-        occ = (ko >> kBeamBits) == P.serial;  // (a bit without this scan's key cannot occur; cheap to insist)
-        kf = P.lv.key_free[key_free_index(P.lv, (unsigned int)x, (unsigned int)y)];
-        fre = (kf >> kBeamBits) == P.serial;
-      }
-      if (!fre && !occ) continue;
-      float l = P.lv.logodds[c];
-      int stamp;
-      if (occ) {
-        // free-touched by an earlier beam of this scan: applied, then reverted (OccGridMapBase.h:231-233)
-        if (fre && (kBeamMask - (kf & kBeamMask)) < (kBeamMask - (ko & kBeamMask))) {
-          l += P.log_odds_free;
-          l -= P.log_odds_free;
+    for (int j = 0; j < NBLK; ++j) fw[j] = fw_next[j];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) fw_next[j] = blk + waves * NBLK + j < nblocks ? *marks_of(blk + waves * NBLK + j) : 0u;
+    bool fre[NBLK][4], occ[NBLK][4];
+    float l[NBLK][4];
+    unsigned int ko[NBLK][4], kf[NBLK][4];
+    // phase 1: classify the four cells of this lane's column in every block and request what their update needs
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      live[j] = blk + j < nblocks && __ballot(fw[j] != 0u) != 0ull;  // wave-uniform: something of this scan in the block
+      if (!live[j]) continue;
+      const int X0 = bx0 + (((blk + j) % nbx) << 6), Y0 = by0 + (((blk + j) / nbx) << 2);
+      const int x = X0 + lane;
+      if (fw[j] != 0u) *marks_of(blk + j) = 0u;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy) {
+        const int y = Y0 + dy;
+        const size_t c = (size_t)y * sx + x;
+        // the byte of cell (x, Y0 + dy): tile lane / 8, byte dy * 8 + lane % 8 = dword (lane & ~7) + 2 dy + (lane & 7) / 4, byte lane & 3
+        const unsigned int fwd = (unsigned int)__shfl((int)fw[j], (lane & ~7) + 2 * dy + ((lane & 7) >> 2));
+        const unsigned int mark = (fwd >> ((lane & 3) << 3)) & 0xffu;
+        occ[j][dy] = (mark & kMarkEnd) != 0u && y < sy;
+        fre[j][dy] = (mark & kMarkCrossed) != 0u && y < sy;
+        l[j][dy] = 0.0f;
+        ko[j][dy] = kf[j][dy] = 0u;
+        if (fre[j][dy] || occ[j][dy]) l[j][dy] = P.lv.logodds[c];
+        if (occ[j][dy]) {
+          ko[j][dy] = P.lv.key_occ[c];
+          kf[j][dy] = P.lv.key_free[key_free_index(P.lv, (unsigned int)x, (unsigned int)y)];
         }
-        if (l < 50.0f) l += P.log_odds_occ;  // updateSetOccupied
-        stamp = P.mark_occ;
-      } else {
-        l += P.log_odds_free;                // updateSetFree
-        stamp = P.mark_free;
       }
-      P.lv.logodds[c] = l;
-      P.lv.update_index[c] = stamp;
-      const float p = grid_probability(l);
-      P.lv.prob[c] = p;
-      if (SCATTER_TEXELS) {
-        float* q = reinterpret_cast<float*>(P.lv.quad);
-        const int sx = P.lv.sx, sy = P.lv.sy;
-        const bool lastx = x == sx - 1, lasty = y == sy - 1;
-        auto put = [&](int tx, int ty, int comp) { q[4 * (size_t)quad_index(tx, ty, P.lv.tiles_x, sx) + comp] = p; };
-        put(x, y, 0);
-        if (x > 0) put(x - 1, y, 1);
-        if (lastx) put(x, y, 1);
-        if (y > 0) put(x, y - 1, 2);
-        if (lasty) put(x, y, 2);
-        if (x > 0 && y > 0) put(x - 1, y - 1, 3);
-        if (lastx && y > 0) put(x, y - 1, 3);
-        if (lasty && x > 0) put(x - 1, y, 3);
-        if (lastx && lasty) put(x, y, 3);
+    }
+    // phase 2: the reference's rule, row by row (coalesced 256-byte rows)
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      if (!live[j]) continue;
+      const int X0 = bx0 + (((blk + j) % nbx) << 6), Y0 = by0 + (((blk + j) / nbx) << 2);
+      const int x = X0 + lane;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy) {
+        const int y = Y0 + dy;
+        const size_t c = (size_t)y * sx + x;
+        bool is_occ = occ[j][dy], is_fre = fre[j][dy];
+        if (is_occ) {
+          is_occ = (ko[j][dy] >> kBeamBits) == P.serial;  // (a flag without this scan's key cannot occur; cheap to insist)
+          is_fre = (kf[j][dy] >> kBeamBits) == P.serial;
+        }
+        if (!is_fre && !is_occ) continue;
+        float lo = l[j][dy];
+        int stamp;
+        if (is_occ) {
+          // free-touched by an earlier beam of this scan: applied, then reverted (OccGridMapBase.h:231-233)
+          if (is_fre && (kBeamMask - (kf[j][dy] & kBeamMask)) < (kBeamMask - (ko[j][dy] & kBeamMask))) {
+            lo += P.log_odds_free;
+            lo -= P.log_odds_free;
+          }
+          if (lo < 50.0f) lo += P.log_odds_occ;  // updateSetOccupied
+          stamp = P.mark_occ;
+        } else {
+          lo += P.log_odds_free;                 // updateSetFree
+          stamp = P.mark_free;
+        }
+        P.lv.logodds[c] = lo;
+        P.lv.update_index[c] = stamp;
+        const float p = grid_probability(lo);
+        P.lv.prob[c] = p;
+        if (SCATTER_TEXELS) {
+          float* q = reinterpret_cast<float*>(P.lv.quad);
+          const bool lastx = x == sx - 1, lasty = y == sy - 1;
+          auto put = [&](int tx, int ty, int comp) { q[4 * (size_t)quad_index(tx, ty, P.lv.tiles_x, sx) + comp] = p; };
+          put(x, y, 0);
+          if (x > 0) put(x - 1, y, 1);
+          if (lastx) put(x, y, 1);
+          if (y > 0) put(x, y - 1, 2);
+          if (lasty) put(x, y, 2);
+          if (x > 0 && y > 0) put(x - 1, y - 1, 3);
+          if (lastx && y > 0) put(x, y - 1, 3);
+          if (lasty && x > 0) put(x - 1, y, 3);
+          if (lastx && lasty) put(x, y, 3);
+        }
       }
     }
   }
