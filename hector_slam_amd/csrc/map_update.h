@@ -406,16 +406,19 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
 // -- the line walk writes a 4-byte tag per crossed cell and the dense apply pass reads a 4-byte key for EVERY cell of the
 // bounding box (2x the touched cells).  WHICH beam crossed a cell first only matters where a beam also ends (see
 // mark_free_block); everywhere else "crossed by this scan" is all there is to say.
+//   update_mark_occ_dense_kernel: the occ key of an end cell, and the value 2 in its mark byte ("a beam ends here").
 //   update_mark_free_dense_kernel: mark_free_block's walk (one wavefront per beam, lane k owns steps k, k+64, ...; duplicate
-//     suppression against the previous beam) storing ONE byte per crossed cell -- a quarter of the bytes, and consecutive
-//     lanes fill consecutive bytes of a tile row.  All writers store the same value: a benign race.  End cells (bit in the
-//     end-cell bitmap) take the keyed atomicMax as before.  (A bitmap with one atomicOr per tile and lane -- lane k walking
-//     8 consecutive steps -- was built first: 354 us against 110, every lane's accesses land in a different line.)
+//     suppression against the previous beam) on ONE byte per crossed cell -- a quarter of the bytes, and consecutive lanes
+//     touch consecutive bytes of a tile row.  A step loads the byte: flagged as an end cell, it takes the keyed atomicMax as
+//     before; already 1, nothing; else it stores 1.  All writers store the same value: a benign race.  (A bitmap with one
+//     atomicOr per tile and lane -- lane k walking 8 consecutive steps -- was built first: 354 us against 110, every lane's
+//     accesses land in a different line.  The end-cell flag first lived in the row-major bitmap of the keyed path: up to 64
+//     lines per access for a y-major beam, and four more words per lane in the apply pass.)
 //   update_apply_dense_kernel: one wavefront per 64 x 4-cell block of the box (8 tiles = 256 contiguous bytes of the byte
-//     map).  It reads the block's bytes and its 8 end-cell words, skips the block when all are zero, applies the reference's
-//     rule to the marked cells row by row (coalesced 256-byte rows), and clears what it read -- the block has ONE owner, so
-//     there is no race on the marks, and the byte map is all zero again between updates (no generation tag to wrap).
-//     Untouched cells cost 1 byte + 1 bit instead of 4 bytes + 1 bit.
+//     map).  It reads the block's bytes, skips the block when all are zero, applies the reference's rule to the marked
+//     cells row by row (coalesced 256-byte rows), and clears what it read -- the block has ONE owner, so there is no race
+//     on the marks, and the byte map is all zero again between updates (no generation tag to wrap).  Untouched cells cost
+//     1 byte instead of 4 bytes + 1 bit.
 // Same cells, same rule, same order-dependent artefacts: the maps stay bit-identical to the reference.
 #ifndef HSM_MARK_XCD_CHUNK  // workgroups of consecutive beams per XCD turn (xcd_block); < 0: the hardware's round robin
 #define HSM_MARK_XCD_CHUNK 16
