@@ -476,8 +476,11 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   const unsigned int inc = 64u * b.abs_db;
   const unsigned int q64 = small ? div_small(inc, b.abs_da) : inc / b.abs_da, r64 = inc - q64 * b.abs_da;
   // duplicate suppression against the previous beam (mark_free_block)
-  const BeamLine pb = beam > 0 ? beam_line(P, beam - 1) : b;
-  const bool dedup = beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
+#ifndef HSM_MARK_DEDUP
+#define HSM_MARK_DEDUP 1
+#endif
+  const BeamLine pb = (HSM_MARK_DEDUP && beam > 0) ? beam_line(P, beam - 1) : b;
+  const bool dedup = HSM_MARK_DEDUP && beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
   const bool psmall = pb.abs_da < (1u << 17);
   const unsigned int pden = dedup ? pb.abs_da : 1u;
   const unsigned int pnum0 = pb.e0 + (unsigned int)lane * pb.abs_db;

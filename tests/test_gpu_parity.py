@@ -1048,6 +1048,35 @@ def test_dense_update_forms_agree_bit_for_bit(capi, oracle_mod, kind, monkeypatc
             g.close()
 
 
+def test_dense_and_sparse_scans_alternate_on_one_map(capi, oracle_mod, kind):
+    """the dense path (>= 4096 beams: mark bytes with the end-cell flag, no bitmap) and the keyed path (fewer beams: key planes
+    + end-cell bitmap) share the key planes and the serial tags of ONE map: scans of 6000, 700, 4100, 90 ... beams in turn,
+    matchData + updateByScan each, must leave every level bit-identical to the reference -- nothing one path leaves behind
+    (a mark byte, a bitmap word, a key of an older serial) may leak into the other"""
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=6000, map_size=512, levels=3, resolution=0.05, n_build=10, n_query=1, room=(20.0, 15.0), seed=23)
+    o = make_oracle(oracle_mod, kind, sc, build=False)
+    g = make_gpu(capi, sc, build=False, layout=capi.LAYOUT_QUAD)
+    keep = (6000, 700, 4100, 90, 6000, 1081, 5000, 4095, 4096, 300)
+    for t, n in enumerate(keep):
+        scan = sc.build_scans[t]
+        scan = scan[np.linspace(0, scan.shape[0] - 1, min(n, scan.shape[0])).astype(np.int64)]
+        o.match(sc.build_poses[t], scan)
+        o.update_by_scan(sc.build_poses[t], scan)
+        g.matchData(sc.build_poses[t], scan)
+        g.updateByScan(scan, sc.build_poses[t])
+        o.on_map_updated()
+        for lvl in range(3):  # after EVERY update: a leak would show at the step it happens
+            lo_o, ui_o = o.download_level(lvl)
+            lo_g, ui_g = g.download_level(lvl)
+            assert np.array_equal(bits(lo_g), bits(lo_o)) and np.array_equal(ui_g, ui_o), (t, n, lvl)
+    g.set_parity(capi.PARITY_EXACT)  # the matcher's view of that map (texels): the reference's pose, bit for bit
+    p_o, c_o = o.match(sc.query_init[0], sc.query_scans[0])
+    p_g, c_g = g.matchData(sc.query_init[0], sc.query_scans[0])
+    assert np.array_equal(bits(p_g), bits(p_o)) and np.array_equal(bits(c_g), bits(c_o))
+    g.close()
+
+
 def test_workgroup_to_xcd_mapping_is_a_permutation(capi, pyr, pyramid_scene, monkeypatch):
     """xcd_block(): whichever mapping a launch uses -- chunks of 16 workgroups dealt to the XCDs (default), odd chunk
     sizes, one contiguous eighth per XCD -- every scan is matched exactly once: a 1003-scan batch (251 workgroups: one
