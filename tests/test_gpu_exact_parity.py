@@ -121,7 +121,7 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
         assert same(pg, po) and same(cg, co), it
 
 
-@pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "throughput", "throughput-8+2",
+@pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "cached-9rows", "cached-5rows", "throughput", "throughput-8+2",
                                   "throughput-plane", "one-wave-per-scan"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
@@ -134,7 +134,7 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     o = make_oracle(oracle_mod, kind, sc)
     if form == "one-wave-per-scan":
         monkeypatch.setenv("HSM_EXACT_BATCH", "0")
-    monkeypatch.setenv("HSM_EXACT_CACHED", "1" if form in ("cached", "cached-tail", "auto") else "0")
+    monkeypatch.setenv("HSM_EXACT_CACHED", "1" if form.startswith("cached") or form == "auto" else "0")
     monkeypatch.setenv("HSM_EXACT_SHAPE", "8" if form == "throughput-8+2" else "7")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
     if form == "throughput-plane":
@@ -155,6 +155,9 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         long_scan = long_scan[:1081]
     scans.append(long_scan)
     init.append(sc.query_init[3])
+    if form in ("cached-9rows", "cached-5rows"):  # the 9- and 5-row instantiations of the texel-cache exact form (short scans)
+        cap = 560 if form == "cached-9rows" else 300
+        scans = [sq[np.linspace(0, sq.shape[0] - 1, min(cap, sq.shape[0])).astype(int)] if sq.shape[0] else sq for sq in scans]
     init = np.stack(init)
     pts, offs = synth.pack_scans(scans)
     pb, cb = g.match_batch(init, pts, offs)
@@ -163,6 +166,8 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     if form.startswith("cached"):
         cfg = g.last_launch_config()
         assert cfg["texel_cache"] and cfg["block"] == 256, cfg
+        if form.endswith("rows"):
+            assert cfg["beams_per_lane"] == int(form.split("-")[1][0]), cfg
     for q, sq in enumerate(scans):
         po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
         assert same(pb[q], po), (q, sq.shape[0])
