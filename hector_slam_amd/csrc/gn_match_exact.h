@@ -35,10 +35,6 @@
 namespace hsm {
 
 constexpr int kXRow = 64 + kExactPad;  // floats per staged row: 16-byte aligned rows, chain lanes on distinct banks
-// term t of OccGridMapUtil.h:83-97 = row A_t * row B_t of {0: gx, 1: gy, 2: rotDeriv, 3: funVal}
-//   t:      dTr0     dTr1     dTr2     H00      H11      H22      H01      H02      H12
-constexpr unsigned kTermRowA = 0u | 1u << 2 | 2u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 0u << 12 | 0u << 14 | 1u << 16;
-constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
 
 #ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
 #define HSM_XBPC 15
@@ -46,10 +42,7 @@ constexpr unsigned kTermRowB = 3u | 3u << 2 | 3u << 4 | 0u << 6 | 1u << 8 | 2u <
 #ifndef HSM_XLDS_AHEAD
 #define HSM_XLDS_AHEAD 1
 #endif
-#ifndef HSM_XSTAGE9  // 1: producers stage the nine products (chain job = read + add); 0: the four factors (job multiplies)
-#define HSM_XSTAGE9 1
-#endif
-constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
+constexpr int kXRows = 9;  // staged rows per scan and round: the nine products of OccGridMapUtil.h:83-97
 #ifndef HSM_XOWNER_PRIO_P  // priority the job's owner keeps while it produces its next row (until the next barrier)
 #define HSM_XOWNER_PRIO_P 1
 #endif
@@ -61,9 +54,6 @@ constexpr int kXRows = HSM_XSTAGE9 ? 9 : 4;  // staged rows per scan and round
 #endif
 #ifndef HSM_XEP_AHEAD  // endpoint loads in flight ahead of the beam being located in that step
 #define HSM_XEP_AHEAD 2
-#endif
-#ifndef HSM_XJOB_PAIRS  // chain job reads its row in 32-byte halves (one s_waitcnt per eight additions) instead of three 16-byte slots
-#define HSM_XJOB_PAIRS 1
 #endif
 #ifndef HSM_XGATHER_ALWAYS  // lane 0 re-reads its texel at every beam: exactly one load per beam, static waits, no branches
 #define HSM_XGATHER_ALWAYS 0
@@ -317,7 +307,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         // cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).  M0 is reserved, not allocatable: nothing else in this kernel
         // uses it (gfx9+ DS operations do not)
         const unsigned m0v = st_wave + (unsigned)buf * (NS * kXRows * kXRow * 4);
-#if HSM_XSTAGE9
         // the nine products of :83-97, one rounding each like the reference's; the chain lane only adds
         const float p0 = gx * funVal, p1 = gy * funVal, p2 = rotDeriv * funVal;
         const float p3 = gx * gx, p4 = gy * gy, p5 = rotDeriv * rotDeriv;
@@ -340,26 +329,11 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
               [o3] "n"(3 * kXRow * 4), [o4] "n"(4 * kXRow * 4), [o5] "n"(5 * kXRow * 4), [o6] "n"(6 * kXRow * 4),
               [o7] "n"(7 * kXRow * 4), [o8] "n"(8 * kXRow * 4)
             : "memory");
-#else
-        asm volatile(
-            "s_mov_b32 m0, %[m]\n\t"
-            "s_nop 0\n\t"
-            "ds_write_addtid_b32 %[a] offset:%[o0]\n\t"
-            "ds_write_addtid_b32 %[b] offset:%[o1]\n\t"
-            "ds_write_addtid_b32 %[c] offset:%[o2]\n\t"
-            "ds_write_addtid_b32 %[d] offset:%[o3]"
-            :
-            : [m] "s"(m0v), [a] "v"(gx), [b] "v"(gy), [c] "v"(rotDeriv), [d] "v"(funVal),
-              [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4), [o3] "n"(3 * kXRow * 4)
-            : "memory");
-#endif
       };
       // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
-      // running sum.  The two rows stream through three 16-byte slots each (24 VGPRs): a slot is refilled right after its
-      // values are consumed, so a read has two compute periods to land in.  (Measured, profiles/r03/README.md: ~1 240
-      // cycles per 220-instruction job, loaded or not -- a single wavefront issues an instruction every 4-5 cycles -- and a
-      // hand-scheduled body with the multiplications one slot ahead of the additions is no faster: what counts is the
-      // instruction count, hence the packed multiplies and the division-free unit arithmetic.)
+      // running sum.  The chain's row streams through two 32-byte halves (16 VGPRs): a half is refilled right after its
+      // values are consumed, one s_waitcnt per eight additions.  (Measured, profiles/r03/README.md: a dependent v_add_f32 of
+      // a lone wavefront costs 8.5 cycles, so the 64 additions are the job's length and the reads hide in their bubbles.)
       auto chain_job = [&](int j, int k) {
         // one job per round (NCP == 64): job j is round k, lane l is chain l -- nothing to derive
         constexpr bool kOneJob = NCP == 64;
@@ -372,11 +346,8 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
         if ((kOneJob || u < units) && c < NC) {
           const int buf = prev ? (k + NB - 1) % NB : k % NB;
           float run = ku == 0 ? 0.0f : runs[c];
-#if HSM_XSTAGE9
-          // chain c = 9 scan + term is row c of the buffer; it streams through three 16-byte slots, a slot refilled right
-          // after its values are consumed
+          // chain c = 9 scan + term is row c of the buffer
           const f4v* pa = reinterpret_cast<const f4v*>(&stage[0][0][0][0] + (buf * NC + c) * kXRow);
-#if HSM_XJOB_PAIRS  // two 32-byte halves, one wait per eight additions (16 VGPRs)
           f4v a[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) a[q] = pa[q];
@@ -395,46 +366,6 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
             if (h + 2 < 8) a[2 * (h & 1)] = pa[2 * h + 4], a[2 * (h & 1) + 1] = pa[2 * h + 5];
             asm volatile("" ::: "memory");
           }
-#else
-          f4v a[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) a[q] = pa[q];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const f4v pr = a[q % 3];
-            run += pr.x;
-            run += pr.y;
-            run += pr.z;
-            run += pr.w;
-            asm volatile("" : "+v"(run) : : "memory");
-            if (q + 3 < 16) a[q % 3] = pa[q + 3];
-            asm volatile("" ::: "memory");
-          }
-#endif
-#else
-          const int sj = (c * 57) >> 9, t = c - 9 * sj;  // scan of the workgroup (c / 9 for c < 144), term
-          const float* base = &stage[0][0][0][0] + (buf * NS + sj) * (kXRows * kXRow);
-          const unsigned ra = (kTermRowA >> (2 * t)) & 3u, rb = (kTermRowB >> (2 * t)) & 3u;
-          const f4v* pa = reinterpret_cast<const f4v*>(base + ra * kXRow);
-          const f4v* pb = reinterpret_cast<const f4v*>(base + rb * kXRow);
-          f4v a[3], b[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) a[q] = pa[q], b[q] = pb[q];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            // the four products as two packed multiplies (a single wavefront issues an instruction every 4-5 cycles whatever
-            // it is: the job's length is its instruction count), then the four additions in beam order
-            const f4v pr = a[q % 3] * b[q % 3];
-            run += pr.x;
-            run += pr.y;
-            run += pr.z;
-            run += pr.w;
-            // fences: a refill stays behind the use of its slot and in its own period (the scheduler would hoist all 32 reads)
-            asm volatile("" : "+v"(run) : : "memory");
-            if (q + 3 < 16) a[q % 3] = pa[q + 3], b[q % 3] = pb[q + 3];
-            asm volatile("" ::: "memory");
-          }
-#endif
           runs[c] = run;
         }
       };
