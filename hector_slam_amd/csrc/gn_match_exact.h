@@ -56,7 +56,8 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
 #define HSM_XEP_AHEAD 2
 #endif
 #ifndef HSM_XGATHER_ALWAYS  // lane 0 re-reads its texel at every beam: exactly one load per beam, static waits, no branches
-#define HSM_XGATHER_ALWAYS 0
+                            // (four instructions less per row on the owner's path: ~1 us per launch, profiles/r03/README.md)
+#define HSM_XGATHER_ALWAYS 1
 #endif
 #ifndef HSM_XJOB_PRIO  // issue priority of a wavefront while it runs a chain job (the round's critical path)
 #define HSM_XJOB_PRIO 3
