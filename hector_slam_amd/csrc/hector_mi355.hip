@@ -1336,6 +1336,13 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   // level 0: the caller's container
   const float2* d_level0 = d_prestaged;
   int slot = -1;
+  // The usual flow updates with the scan that was just matched.  When the matcher put that scan into device memory (dense
+  // scans, multi-level maps: d_retained) and the caller hands over the same endpoints, they are already where the update
+  // kernels read them: no second upload (131 KB from pageable memory for a 16 k-beam scan, which the host waits for).
+  const int rn0 = h->retained_valid ? (int)(h->retained_pts.size() / 2) : 0;
+  const bool same_as_matched = !d_level0 && h->d_retained_current && rn0 == n && n > 0 &&
+                               memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0;
+  if (same_as_matched) d_level0 = h->d_retained;
   if (!d_level0 && h->async_update) {
     // stage the endpoints in pinned memory (a pageable hipMemcpyAsync would block the host until the copy
     // -- and everything queued before it -- has completed); small scans are then read in place over PCIe
@@ -1381,8 +1388,11 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   bool coarse_same_container = false;  // the usual flow: update with the container that was just matched
   if (h->levels.size() > 1) {
     const float2* d_coarse = nullptr;
-    if (rn == n && n > 0 && !h->d_retained_current &&
-        memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0) {
+    if (same_as_matched) {
+      d_coarse = d_level0;
+      coarse_same_container = h->retained_origo[0] == o[0] && h->retained_origo[1] == o[1];
+    } else if (rn == n && n > 0 && !h->d_retained_current &&
+               memcmp(h->retained_pts.data(), pts_xy, (size_t)n * sizeof(float2)) == 0) {
       d_coarse = d_level0;
       coarse_same_container = h->retained_origo[0] == o[0] && h->retained_origo[1] == o[1];
     } else {

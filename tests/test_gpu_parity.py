@@ -1070,6 +1070,21 @@ def test_dense_and_sparse_scans_alternate_on_one_map(capi, oracle_mod, kind):
             lo_o, ui_o = o.download_level(lvl)
             lo_g, ui_g = g.download_level(lvl)
             assert np.array_equal(bits(lo_g), bits(lo_o)) and np.array_equal(ui_g, ui_o), (t, n, lvl)
+    # a dense scan matched, then ANOTHER dense scan of the same length handed to updateByScan: level 0 takes the new
+    # endpoints, the coarse levels the container the match retained (MapRepMultiMap.h:143) -- the update must not take the
+    # matcher's device copy for the caller's scan just because the lengths agree
+    a, b = sc.build_scans[0][:5000], sc.build_scans[4][:5000].copy()
+    assert a.shape == b.shape and not np.array_equal(a, b)
+    for (mscan, uscan) in ((a, b), (b, b), (a, a)):
+        o.match(sc.build_poses[2], mscan)
+        o.update_by_scan(sc.build_poses[2], uscan)
+        g.matchData(sc.build_poses[2], mscan)
+        g.updateByScan(uscan, sc.build_poses[2])
+        o.on_map_updated()
+        for lvl in range(3):
+            lo_o, ui_o = o.download_level(lvl)
+            lo_g, ui_g = g.download_level(lvl)
+            assert np.array_equal(bits(lo_g), bits(lo_o)) and np.array_equal(ui_g, ui_o), ("matched != updated scan", lvl)
     g.set_parity(capi.PARITY_EXACT)  # the matcher's view of that map (texels): the reference's pose, bit for bit
     p_o, c_o = o.match(sc.query_init[0], sc.query_scans[0])
     p_g, c_g = g.matchData(sc.query_init[0], sc.query_scans[0])
