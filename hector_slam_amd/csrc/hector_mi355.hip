@@ -1186,7 +1186,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   if (n >= h->coop_min_beams && h->wps_override == 0 && !h->exact) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
-    int K = (n + 511) / 512;  // ~2 beams per lane (16 k beams: 79.8 / 71 / 66-70 / 64 us per matchData for K = 16 / 24 / 32 / 64)
+    // one beam per lane.  16 k beams, matchData us for K = 16 / 24 / 32 / 64 workgroups: 79.8 / 71 / 66-70 / 64 with round 2's grid
+    // barrier; 70 (24) / 67-71 (31) / 76 (48) / 63-64 (64) with the tagged exchange (profiles/r03/README.md)
+    int K = (n + 255) / 256;
     if (const char* env = getenv("HSM_COOP_K")) K = atoi(env);
     if (K > 64) K = 64;
     if (K < 2) K = 2;

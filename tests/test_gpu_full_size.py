@@ -199,7 +199,7 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
         step = sc.build_poses[t + 1] - sc.build_poses[t]
         hint_o, hint_g = po + step, pg + step
     cfg = p.mapRep.last_launch_config()
-    assert cfg["waves_per_scan"] == -cfg["grid"] and 28 <= cfg["grid"] <= 32  # ~n / 512 cooperating workgroups (multi-CU dense matcher)
+    assert cfg["waves_per_scan"] == -cfg["grid"] and 56 <= cfg["grid"] <= 64  # ~n / 256 cooperating workgroups (multi-CU dense matcher)
     for lvl in range(sc.levels):
         lo_g, _ = p.mapRep.download_level(lvl)
         lo_o, _ = o.download_level(lvl)
