@@ -54,6 +54,7 @@ SIGNATURES = {
     "hsm_on_map_updated": (_i, [_vp]),
     "hsm_set_parity": (_i, [_vp, _i]),
     "hsm_parity": (_i, [_vp]),
+    "hsm_last_launch_parity": (_i, [_vp]),
     "hsm_match": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
     "hsm_match_trace": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p, _f32p, _i, C.POINTER(_i)]),
     "hsm_match_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
     "hsm_debug_set_update_serial": (_i, [_vp, _i, C.c_uint]),
     "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
+    "hsm_debug_marks_nonzero": (_i, [_vp, _i, _vp]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_device_info": (_i, [_vp, _i32p]),
@@ -486,7 +488,9 @@ class MapRepMultiMap:
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
                 "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": max(int(cfg[4]), 0),
                 "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4])),
-                "parity": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed", PARITY_AUTO: "auto"}.get(self.parity(), "fast")}
+                "parity": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed", PARITY_AUTO: "auto"}.get(self.parity(), "fast"),
+                "parity_effective": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed"}.get(
+                    self._lib.hsm_last_launch_parity(self._h), "fast")}
 
     # ---- parity / debug ---------------------------------------------------------------------
     def hessian_derivs(self, level, pose_map, pts_level):
@@ -515,6 +519,12 @@ class MapRepMultiMap:
         e, p = np.empty_like(x), np.empty_like(x)
         _check(self._lib.hsm_debug_expf(self._h, x.size, x, e, p), "hsm_debug_expf")
         return e, p
+
+    def debug_marks_nonzero(self, level):
+        """(non-zero words of the dense update's byte map, non-zero words of the end-cell bitmap): both 0 between updates"""
+        out = np.zeros(2, np.uint64)
+        _check(self._lib.hsm_debug_marks_nonzero(self._h, level, out.ctypes.data), "hsm_debug_marks_nonzero")
+        return int(out[0]), int(out[1])
 
     def debug_set_coop_barrier(self, value):
         _check(self._lib.hsm_debug_set_coop_barrier(self._h, int(value) & 0xffffffff), "hsm_debug_set_coop_barrier")

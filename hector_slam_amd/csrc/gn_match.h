@@ -105,6 +105,8 @@ struct MatchParams {
   unsigned* done_flag;       // nullptr, or a host-visible word that receives done_seq (system-scope release)
   unsigned done_seq;         // after the single-scan results are written: the host polls it instead of
                              // waiting for the end-of-kernel signal
+  unsigned* err_flag;        // nullptr, or a host-visible word that receives done_seq when the cooperative matcher's
+                             // exchange gave up waiting for a workgroup's record (the pose is then not to be used)
   int xcd_chunk;             // workgroup -> scan mapping (xcd_block): 0 = one contiguous eighth of the batch per XCD,
                              // c > 0 = chunks of c workgroups dealt to the XCDs in turn
   int wg_sync;               // texel-cache form: the waves of a workgroup meet at a barrier before every beam (L1 sharing)
@@ -1504,8 +1506,11 @@ gn_match_exact_batch_kernel(const MatchParams P) {
 #ifndef HSM_COOP_BARRIER
 #define HSM_COOP_BARRIER 1
 #endif
-#ifndef HSM_COOP_TAGGED  // 1 (default, round 3): no grid barrier at all -- tagged 16-byte records, see the kernel
-#define HSM_COOP_TAGGED 1
+// TAGGED (default since round 3; env HSM_COOP_TAGGED=0 selects the counter barrier at run time): no grid barrier at all --
+// tagged 16-byte records, see the kernel.  That exchange relies on a 16-byte sc0 sc1 store being observed untorn, which is
+// documented behaviour of gfx942 / gfx950 only:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gn_match_coop_kernel's tagged exchange is written for gfx942 / gfx950"
 #endif
 __device__ __forceinline__ void coop_barrier(unsigned* counter, unsigned target) {
   __syncthreads();  // the workgroup's partials are written
@@ -1519,7 +1524,7 @@ __device__ __forceinline__ void coop_barrier(unsigned* counter, unsigned target)
   __syncthreads();
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool TAGGED = true>
 __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P, float* __restrict__ partials,
                                                             unsigned* __restrict__ bar_counter, unsigned bar_base) {
 #if !HSM_COOP_BARRIER
@@ -1566,7 +1571,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
         r[6] = acc.h01; r[7] = acc.hr.x; r[8] = acc.hr.y;
       }
       __syncthreads();
-#if HSM_COOP_TAGGED
+      if constexpr (TAGGED) {
       // Exchange WITHOUT a barrier: every workgroup publishes its nine partials as three self-describing 16-byte granules
       // {p, p, p, tag} (tag = the step's global sequence number) with device-coherent stores, and every workgroup polls the K
       // records of the step until all their granules carry the tag.  A 16-byte sc0 sc1 store is observed untorn, sc1 loads are
@@ -1597,7 +1602,17 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
                        "s_waitcnt vmcnt(0)"
                        : "=&v"(g0), "=&v"(g1), "=&v"(g2) : "v"(src) : "memory");
           const bool ok = lane >= K || (__float_as_uint(g0.w) == tag && __float_as_uint(g1.w) == tag && __float_as_uint(g2.w) == tag);
-          if (__ballot(!ok) == 0ull || spin > (1 << 22)) break;  // (bounded: a lost workgroup must not hang the device)
+          if (__ballot(!ok) == 0ull) break;
+          if (spin > (1 << 22)) {
+            // bounded: a lost workgroup must not hang the device.  The records are then stale or partial, and so is every
+            // step from here on: say so where the host looks (match_single turns it into an error return) -- ordered
+            // before this workgroup's next record, so that whoever consumes the wrong sums also finds the word
+            if (lane == 0 && P.err_flag) {
+              __hip_atomic_store(P.err_flag, P.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __threadfence_system();
+            }
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
         }
         if (lane < K) {
@@ -1612,7 +1627,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
           tot[6] = t.h01; tot[7] = t.hr.x; tot[8] = t.hr.y;
         }
       }
-#else
+      } else {
       float* mine = partials + ((size_t)(step & 1) * K + blockIdx.x) * 9;
       if (threadIdx.x < 9) mine[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 #if HSM_COOP_BARRIER
@@ -1637,7 +1652,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
           tot[6] = t.h01; tot[7] = t.hr.x; tot[8] = t.hr.y;
         }
       }
-#endif
+      }
       __syncthreads();
       acc.d01 = f2{tot[0], tot[1]}; acc.d2 = tot[2];
       acc.hd = f2{tot[3], tot[4]}; acc.h22 = tot[5];

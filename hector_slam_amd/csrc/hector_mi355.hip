@@ -55,6 +55,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // [16,28) eval H,dTr | [kTraceOff, kTraceOff + 12 * max steps) per-step trace
 constexpr int kTraceOff = 64;
 constexpr int kDoneFlagOff = 32;  // one word of the pinned block: single-scan completion sequence number
+constexpr int kErrFlagOff = 33;   // the next word: receives that number when the cooperative matcher's exchange timed out
 constexpr int kMaxTraceSteps = 6 + 4 * (HSM_MAX_LEVELS - 1);
 constexpr int kSmallFloats = kTraceOff + 12 * kMaxTraceSteps;
 
@@ -80,6 +81,7 @@ struct Level {
   int bbox[4] = {0, 0, -1, -1};   // cell box touched by the last update
   int dirty[4] = {0, 0, -1, -1};  // union of those boxes since hsm_take_dirty_bbox was last called
   int key_rows[2] = {0, -1};      // rows that carry keys of the current key generation (union of the boxes since the planes were last cleared)
+  bool marks_pending = false;     // a mark pass was queued on this level and its apply pass has not been (scrub_marks)
   size_t cells() const { return (size_t)sx * sy; }
   int tiles_x() const { return (sx + 3) / 4; }
   int quad_texels() const {
@@ -160,6 +162,7 @@ struct hsm_ctx {
   unsigned coop_bar_base = 0;   // value the grid-barrier counter has when the next cooperative launch starts
   float* d_partials = nullptr;  // [2][64][9] per-workgroup partial sums of gn_match_coop_kernel
   int coop_min_beams = 4096;    // single scans at least this long take the multi-workgroup matcher (env HSM_COOP_MIN)
+  bool coop_tagged = true;      // env HSM_COOP_TAGGED=0: the counter grid barrier instead of the tagged-record exchange
   void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
@@ -176,6 +179,7 @@ struct hsm_ctx {
   bool auto_parity = true;  // HSM_PARITY_AUTO (default): batched matches on maps above 2^23 cells run in HSM_PARITY_EXACT, the rest FAST
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
+  int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
 };
 
 namespace {
@@ -429,9 +433,18 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   return HSM_OK;
 }
 
+// HSM_PARITY_AUTO (the default): a BATCH on a map of more than 2^23 cells takes the reference's summation order.  Measured
+// (profiles/r03/README.md, tests/test_gpu_full_size.py): on the 2048^2 workloads the fast tree is within 1e-4 m of the
+// reference on 36 864 of 36 864 scans; on the 4096^2 pyramid with its 160 m room -- long beams on coarse far walls, 30 % of
+// the scans not settled in the reference itself -- it misses on 0.7 %.  Map size is the proxy for that regime that the
+// context knows; hsm_set_parity pins either mode.  Single scans keep the fast tree (their cost is latency).
+bool auto_wants_exact(const hsm_ctx* h, const MatchParams& P) {
+  return h->auto_parity && !h->relaxed && P.begin_world && !P.trace && P.batch > 1 && h->levels[0].cells() > ((size_t)1 << 23);
+}
+
 template <int WPS, int SPB>
-int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  if (h->exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
+int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
+  if (exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
   const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
   if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
   if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
@@ -441,40 +454,36 @@ int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stre
   return launch_match_t<WPS, SPB, 17>(h, P, stream);
 }
 
-int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream);
+int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact);
 
-// HSM_PARITY_AUTO: a BATCH on a map of more than 2^23 cells takes the reference's summation order.  Measured
-// (profiles/r03/README.md, tests/test_gpu_full_size.py): on the 2048^2 workloads the fast tree is within 1e-4 m of the
-// reference on 36 864 of 36 864 scans; on the 4096^2 pyramid with its 160 m room -- long beams on coarse far walls, 30 % of
-// the scans not settled in the reference itself -- it misses on 0.7 %.  Map size is the proxy for that regime that the
-// context knows; hsm_set_parity pins either mode.  Single scans keep the fast tree (their cost is latency).
+// HSM_PARITY_AUTO: which launches take the reference's summation order (see auto_wants_exact).  The effective mode is an
+// ARGUMENT of the launch helpers -- the context's flags are never changed by a launch (hsm_parity() reads them without the
+// mutex) -- and is recorded for hsm_last_launch_parity().
 int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  const bool saved = h->exact;
-  if (h->auto_parity && !h->relaxed && P.begin_world && !P.trace && P.batch > 1 && h->levels[0].cells() > ((size_t)1 << 23))
-    h->exact = true;  // (the caller holds the context's mutex)
-  const int rc = launch_match_mode(h, P, max_n, stream);
-  h->exact = saved;
+  const bool exact = h->exact || auto_wants_exact(h, P);
+  const int rc = launch_match_mode(h, P, max_n, stream, exact);
+  h->last_parity = exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : HSM_PARITY_FAST);
   return rc;
 }
 
-int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
   switch (choose_wps(h, P.batch, max_n)) {
     case 1: {
       // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
       // per-beam workgroup barrier (MatchParams::wg_sync) eight waves share the texel lines in the CU's L1 (4096^2
       // pyramid: 132.8 -> 129.1 us; 16 per workgroup: 133 us; no effect on the 2048^2 workloads, which keep four)
       const int per_lane = (max_n + 63) / 64;
-      if (h->spb_large == 8 && h->levels[0].cells() > ((size_t)1 << 23) && !h->exact && h->texel_cache && P.begin_world &&
+      if (h->spb_large == 8 && h->levels[0].cells() > ((size_t)1 << 23) && !exact && h->texel_cache && P.begin_world &&
           !P.trace && h->bpl_override != 0 && per_lane > 5 && per_lane <= 17)
         return per_lane <= 9 ? launch_match_t<1, 8, 9>(h, P, stream) : launch_match_t<1, 8, 17>(h, P, stream);
-      return launch_match_w<1, 4>(h, P, max_n, stream);
+      return launch_match_w<1, 4>(h, P, max_n, stream, exact);
     }
     case 2: {
 #if defined(HSM_EXPERIMENTS)
       // experimental (HSM_CACHED_WPS2=1, explicit waves_per_scan = 2): the texel-cache form on a PAIR of waves per scan
       // -- nine beams per lane, five waves per SIMD, 1.6 generations of waves for a 4096-scan launch (gn_match.h)
       const int per_lane = (max_n + 127) / 128;
-      if (h->cached_wps2 && !h->exact && h->texel_cache && P.begin_world && !P.trace && h->bpl_override != 0 &&
+      if (h->cached_wps2 && !exact && h->texel_cache && P.begin_world && !P.trace && h->bpl_override != 0 &&
           h->layout == kLayoutQuad && per_lane > 0 && per_lane <= 9) {
         hipLaunchKernelGGL((gn_match_cached_kernel<1, 9, kLayoutQuad, 2>), dim3(P.batch), dim3(128), 0, stream, P);
         HIP_TRY(hipGetLastError());
@@ -487,11 +496,11 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
         return HSM_OK;
       }
 #endif
-      return launch_match_w<2, 1>(h, P, max_n, stream);
+      return launch_match_w<2, 1>(h, P, max_n, stream, exact);
     }
-    case 4: return launch_match_w<4, 1>(h, P, max_n, stream);
-    case 8: return launch_match_w<8, 1>(h, P, max_n, stream);
-    default: return launch_match_w<16, 1>(h, P, max_n, stream);
+    case 4: return launch_match_w<4, 1>(h, P, max_n, stream, exact);
+    case 8: return launch_match_w<8, 1>(h, P, max_n, stream, exact);
+    default: return launch_match_w<16, 1>(h, P, max_n, stream, exact);
   }
 }
 
@@ -531,6 +540,20 @@ struct LevelPrep {
   bool derivable = false;  // set by level_bbox(): coarser levels of the same container may derive their box from this one
 };
 
+// The marks of an update -- mark bytes (dense scans), end-cell bitmap bits (keyed form) -- are cleared by the apply pass of the
+// SAME update and carry no generation tag.  If that pass never ran over them (a HIP error between the two launches, or a box
+// the host found empty) they would be applied by a later scan as spurious free / occupied updates.  The level remembers that
+// a mark pass is outstanding; the next update on it then clears both mark planes first and widens the rows the key-wrap
+// clear covers to the whole level (the failed update's keys carry an older generation and are ignored as such).
+int scrub_marks(hsm_ctx* h, Level& L) {
+  HIP_TRY(hipMemsetAsync(L.d_free_bytes, 0, key_free_cells(L.sx, L.sy) + 256, h->stream));
+  HIP_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((L.cells() + 31) / 32 + 1) * sizeof(unsigned int), h->stream));
+  L.key_rows[0] = 0;
+  L.key_rows[1] = L.sy - 1;
+  L.marks_pending = false;
+  return HSM_OK;
+}
+
 int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, const float pose_world[3],
                   const float2* d_pts, const float* h_pts, int n, float pt_scale, const float origo_level[2]) {
   Level& L = h->levels[level];
@@ -558,6 +581,8 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
   L.bbox[2] = L.bbox[3] = -1;
   if (n > 0) {
     if (n > HSM_MAX_UPDATE_BEAMS) return fail(HSM_ERR_TOO_LARGE, "update_by_scan: more than HSM_MAX_UPDATE_BEAMS beams");
+    if (L.marks_pending)
+      if (int rc = scrub_marks(h, L)) return rc;
     if (++L.serial > kSerialMax) {
       // key generation wrapped (every 4095 updates of a level): clear the rows that carry keys -- the union of the update
       // boxes since the last clear, not the whole planes (an 8192^2 level would be a 512 MB memset in the middle of a
@@ -593,6 +618,7 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
     P.x1 = P.y1 = -1;  // empty box until level_bbox(): the dense passes skip the level
     prep.slot = batch.nlev;
     batch.lv[batch.nlev++] = P;
+    L.marks_pending = true;  // until the apply pass over this level's box is queued (update_applied)
   }
   L.last_update_index++;     // setUpdated(), GridMapBase.h:343
   L.curr_update_index += 3;  // OccGridMapBase.h:167
@@ -752,6 +778,16 @@ int launch_update_apply(hsm_ctx* h, const UpdateBatch& batch) {
   return HSM_OK;
 }
 
+// the apply pass of this level is queued behind its mark pass: its marks will be cleared.  A level whose box the host found
+// empty has no apply pass; by construction the device marked nothing there either (beam_line and level_bbox evaluate the
+// same fp32 expressions), but nothing checks that on the device, so such a level stays "pending" and is scrubbed before
+// its next update (two memsets, only after a scan that had no end point inside the map)
+void update_applied(hsm_ctx* h, const UpdateBatch& batch, const LevelPrep& prep) {
+  if (prep.slot < 0) return;
+  const UpdateParams& P = batch.lv[prep.slot];
+  if (P.x1 >= P.x0) h->levels[prep.level].marks_pending = false;
+}
+
 int select_device(const hsm_ctx* h) {
   HIP_TRY(hipSetDevice(h->device));
   return HSM_OK;
@@ -828,14 +864,22 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   h->wps_override = wps;
   if (const char* env = getenv("HSM_BPL")) h->bpl_override = atoi(env) == 0 ? 0 : -1;
   if (const char* env = getenv("HSM_COOP_MIN")) h->coop_min_beams = atoi(env);
+  if (const char* env = getenv("HSM_COOP_TAGGED")) h->coop_tagged = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPIN_WAIT")) h->spin_wait = atoi(env) != 0;
   if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
   if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
   if (const char* env = getenv("HSM_PARITY")) {
-    h->exact = strcmp(env, "exact") == 0;
-    h->relaxed = strcmp(env, "relaxed") == 0;
-    h->auto_parity = strcmp(env, "auto") == 0;
+    // only the four documented words change the mode; anything else ("Exact", "1", a typo) must not silently select the
+    // fast tree: the context is refused
+    const bool is_exact = strcmp(env, "exact") == 0, is_relaxed = strcmp(env, "relaxed") == 0, is_auto = strcmp(env, "auto") == 0;
+    if (!is_exact && !is_relaxed && !is_auto && strcmp(env, "fast") != 0) {
+      delete h;
+      return fail(HSM_ERR_INVALID, "hsm_create: HSM_PARITY must be one of auto, fast, exact, relaxed");
+    }
+    h->exact = is_exact;
+    h->relaxed = is_relaxed;
+    h->auto_parity = is_auto;
   }
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
@@ -992,6 +1036,8 @@ int hsm_parity(const hsm_ctx* h) {
   if (!h) return HSM_PARITY_FAST;
   return h->exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : (h->auto_parity ? HSM_PARITY_AUTO : HSM_PARITY_FAST));
 }
+
+int hsm_last_launch_parity(const hsm_ctx* h) { return h ? h->last_parity : HSM_PARITY_FAST; }
 
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
@@ -1183,6 +1229,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   const unsigned seq = ++h->done_seq;
   P.done_flag = h->spin_wait ? reinterpret_cast<unsigned*>(hs_dev + kDoneFlagOff) : nullptr;
   P.done_seq = seq;
+  P.err_flag = reinterpret_cast<unsigned*>(hs_dev + kErrFlagOff);
   if (n >= h->coop_min_beams && h->wps_override == 0 && !h->exact) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
@@ -1196,8 +1243,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     unsigned* bar_counter = reinterpret_cast<unsigned*>(h->d_partials + 2 * 64 * 12);
     unsigned bar_base = h->coop_bar_base;
     void* args[] = {(void*)&P, (void*)&partials, (void*)&bar_counter, (void*)&bar_base};
-    const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane>
-                                                : (const void*)gn_match_coop_kernel<kLayoutQuad>;
+    const void* fn = h->layout == kLayoutPlane
+                         ? (h->coop_tagged ? (const void*)gn_match_coop_kernel<kLayoutPlane, true> : (const void*)gn_match_coop_kernel<kLayoutPlane, false>)
+                         : (h->coop_tagged ? (const void*)gn_match_coop_kernel<kLayoutQuad, true> : (const void*)gn_match_coop_kernel<kLayoutQuad, false>);
     if (hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream) == hipSuccess) {
       unsigned steps = 0;
       for (int l = P.first_level; l >= P.last_level; --l) steps += (unsigned)P.lv[l].gn_steps;
@@ -1207,6 +1255,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
       h->last_cfg[2] = 256;
       h->last_cfg[3] = K;
       h->last_cfg[4] = 0;
+      h->last_parity = HSM_PARITY_FAST;
     } else {
       // the runtime could not guarantee co-residency (device busy with other work): the one-workgroup
       // matcher computes the same thing on one CU
@@ -1217,6 +1266,8 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     return rc;
   }
   if (int rc = wait_single_scan(h, seq)) return rc;
+  if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq)
+    return fail(HSM_ERR_HIP, "hsm_match: the cooperative matcher's inter-workgroup exchange timed out (a workgroup never published its partial sums); no pose");
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
   out_pose_world[1] = hs[4];
@@ -1422,6 +1473,7 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
     level_bbox(h, batch, prep[l], derive ? &batch.lv[prep[0].slot] : nullptr, (int)l);
   }
   if (int rc = launch_update_apply(h, batch)) return rc;
+  for (size_t l = 0; l < h->levels.size(); ++l) update_applied(h, batch, prep[l]);
   if (slot >= 0) {
     HIP_TRY(hipEventRecord(h->upd_evt[slot], h->stream));
     h->upd_busy[slot] = true;
@@ -1460,6 +1512,7 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3], c
   if (int rc = launch_update_mark(h, batch)) return rc;
   level_bbox(h, batch, prep, nullptr, 0);
   if (int rc = launch_update_apply(h, batch)) return rc;
+  update_applied(h, batch, prep);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return HSM_OK;
 }
@@ -2218,6 +2271,29 @@ int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->d_partials + 2 * 64 * 12, &value, sizeof value, hipMemcpyHostToDevice));
   h->coop_bar_base = value;
+  return HSM_OK;
+}
+
+int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]) {
+  if (int rc = valid_level(h, level)) return rc;
+  if (!out) return fail(HSM_ERR_INVALID, "hsm_debug_marks_nonzero: out is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  Level& L = h->levels[level];
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), h->stream);
+  if (e == hipSuccess) {
+    const size_t nb = (key_free_cells(L.sx, L.sy) + 256) / 4, nw = (L.cells() + 31) / 32 + 1;
+    hipLaunchKernelGGL(count_nonzero_words_kernel, dim3(grid_for(nb)), dim3(256), 0, h->stream,
+                       reinterpret_cast<const unsigned int*>(L.d_free_bytes), nb, d);
+    hipLaunchKernelGGL(count_nonzero_words_kernel, dim3(grid_for(nw)), dim3(256), 0, h->stream, L.d_occ_bits, nw, d + 1);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(HSM_ERR_HIP, "hsm_debug_marks_nonzero", e);
   return HSM_OK;
 }
 

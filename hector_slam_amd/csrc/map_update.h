@@ -683,6 +683,20 @@ __global__ void __launch_bounds__(256) update_texels_kernel(const UpdateBatch B)
   }
 }
 
+// test hook (hsm_debug_marks_nonzero): the dense update's byte map and the keyed update's end-cell bitmap must be ALL ZERO
+// between updates (each apply pass clears what its mark passes set; map_update.h "dense scans"): count the non-zero words
+__global__ void __launch_bounds__(256) count_nonzero_words_kernel(const unsigned int* __restrict__ words, size_t n,
+                                                                  unsigned long long* __restrict__ out) {
+  unsigned int local = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    local += words[i] != 0u ? 1u : 0u;
+  const unsigned long long m = __ballot(local != 0u);
+  if (m == 0ull) return;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local += (unsigned int)__shfl_down((int)local, d);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)local);
+}
+
 // ---- whole-plane maintenance (create / reset / upload) ------------------------------
 __global__ void fill_level_kernel(LevelRW L, float logodds, int update_index) {
   const size_t n = (size_t)L.sx * L.sy;

@@ -96,6 +96,9 @@ int hsm_on_map_updated(hsm_ctx* h);
 /* no reference counterpart: selects HSM_PARITY_FAST / _EXACT / _RELAXED / _AUTO for all later matches of the context */
 int hsm_set_parity(hsm_ctx* h, int mode);
 int hsm_parity(const hsm_ctx* h);
+/* the mode the LAST match launch of this context actually ran in (HSM_PARITY_FAST / EXACT / RELAXED): under
+ * HSM_PARITY_AUTO the library picks per launch */
+int hsm_last_launch_parity(const hsm_ctx* h);
 
 /* ---- the hot path -----------------------------------------------------------
  * replaces: MapRepMultiMap::matchData(beginEstimateWorld, dataContainer, covMatrix)
@@ -298,6 +301,10 @@ int hsm_match_level(hsm_ctx* h, int level, const float begin_world[3], const flo
 /* test hook: set the 12-bit per-scan generation counter of `level`'s key planes (it wraps every 4095
  * updates -- 27 minutes at 40 Hz -- and the wrap path has to be exercised without running that long) */
 int hsm_debug_set_update_serial(hsm_ctx* h, int level, unsigned serial);
+/* test hook: out[0] = non-zero 32-bit words of `level`'s crossed-cell byte map (dense scans), out[1] = non-zero words of its
+ * end-cell bitmap (scans below 4096 beams).  Both planes carry no generation tag: every update's apply pass clears exactly
+ * what its mark passes set, so BETWEEN updates both counts must be 0 (waits for the queued updates first) */
+int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]);
 /* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by
  * workgroups x GN steps per dense match and wraps at 2^32) */
 int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value);

@@ -208,6 +208,36 @@ def test_randomised_geometries_restatement_equals_reference(oracle_mod):
             assert np.array_equal(o["ho"].occupancy_grid(lvl), o["hr"].occupancy_grid(lvl))
 
 
+def test_dense_fans_on_and_beyond_the_map_borders_restatement_equals_reference(oracle_mod):
+    """the inputs of tests/test_gpu_dense_edges.py (>= 4096-beam fans ending on and 0.5 .. 6 cells outside the four borders,
+    begin cells next to / off every border, widths 64 .. 512, heights with sy % 4 != 0): restatement == reference headers on
+    every level after every update, and the fans do reach all four borders -- the CPU pin of what the GPU box then runs"""
+    if not oracle_mod.available("hr"):
+        pytest.skip("oracle/_ref not built")
+    from edge_cases import GEOMETRIES, begin_cells, border_fan, world_pose_of_cell
+    for sx, sy, levels, n in GEOMETRIES:
+        res = 0.05
+        o = [oracle_mod.Oracle(k, res, sx, sy, levels) for k in ("ho", "hr")]
+        for x in o:
+            x.set_update_factor_free(0.4)
+            x.set_update_factor_occupied(0.9)
+        rng = np.random.default_rng(sx * 1000 + sy)
+        for k, (cx, cy) in enumerate(begin_cells(sx, sy)):
+            th = float(rng.uniform(-np.pi, np.pi)) if k % 3 else 0.0
+            pose = world_pose_of_cell(res, sx, sy, cx, cy, th)
+            pts = border_fan(rng, sx, sy, cx, cy, th, n)
+            og = np.zeros(2, np.float32) if k % 4 else np.array([0.3, -0.2], np.float32)
+            for x in o:
+                x.match(pose, pts, og)
+                x.update_by_scan(pose, pts, og)
+                x.on_map_updated()
+            for lvl in range(levels):
+                a, b = o[0].download_level(lvl), o[1].download_level(lvl)
+                assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), (sx, sy, k, lvl)
+        _, ui = o[0].download_level(0)
+        assert (ui[0] >= 0).any() and (ui[-1] >= 0).any() and (ui[:, 0] >= 0).any() and (ui[:, -1] >= 0).any(), (sx, sy)
+
+
 def test_reference_shim_is_thread_safe_about_stdout(oracle_mod, small_scene):
     """the bench's all-cores CPU leg drives the reference from many threads; the shim silences the reference's
     std::cout chatter process-wide (a per-call save/restore once left std::cout on a dead buffer: exit crash)"""

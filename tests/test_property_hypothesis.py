@@ -9,7 +9,7 @@ Every example is a whole match/update loop, so the number of examples is kept sm
 structure (sizes, levels, seeds), the worlds and scans come from hector_slam_amd.synth."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, given, seed, settings
 from hypothesis import strategies as st
 
 from conftest import bits, oracle_kinds
@@ -56,11 +56,34 @@ def run_loop(g, make_a, make_b, steps=8):
         cond = float(np.linalg.cond(H)) if np.abs(H).max() > 0 else float("inf")
         a["update"](pa, scans[t], origo)
         b["update"](pa, scans[t], origo)
+        for impl in (a, b):
+            if "check" in impl:
+                impl["check"](g, t)
         pose = pa
     for lvl in range(levels):
         la, lb = a["level"](lvl), b["level"](lvl)
         assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1]), (g, lvl)
     return cond
+
+
+# Round 4: the DENSE form of updateByScan (>= 4096 beams on maps whose rows are a multiple of 64 cells: byte marks +
+# block-owned apply pass, map_update.h) under the same property -- with the map's start coordinates drawn from [-0.04, 1.04],
+# so the robot's loop runs along, across and outside the map's borders (start < 0 or > 1 puts the world origin off the map).
+# Both tests below draw from the SAME seeded strategy (hypothesis' @seed, no example database), so the examples the GPU box
+# runs are exactly the ones the CPU pin (restatement == reference headers) ran here first.
+dense_geometry = st.fixed_dictionaries({
+    "size": st.sampled_from([64, 128, 192, 256, 320]),
+    "levels": st.integers(1, 3),
+    "res": st.sampled_from([0.05, 0.1]),
+    "start": st.tuples(st.floats(-0.04, 1.04), st.floats(-0.04, 1.04)),
+    "free": st.floats(0.3, 0.49),
+    "occ": st.floats(0.55, 0.95),
+    "beams": st.sampled_from([4096, 6000, 16384]),
+    "grow": st.sampled_from([0.6, 0.9, 1.15]),
+    "seed": st.integers(0, 2 ** 20),
+    "origo": st.tuples(st.floats(-2, 2), st.floats(-2, 2)),
+})
+DENSE_SEED = 20260924
 
 
 def oracle_impl(pyoracle, kind):
@@ -98,3 +121,33 @@ def test_gpu_exact_mode_equals_reference_for_random_geometries(oracle_mod, g):
                 "level": m.download_level, "keep": m}
     cond = run_loop(g, make_gpu, oracle_impl(oracle_mod, oracle_kinds()[-1]))
     print(f"cond(H) of the last step: {cond}")
+
+
+@pytest.mark.skipif("hr" not in oracle_kinds(), reason="oracle/_ref/libhector_ref.so not built (needs /root/reference)")
+@seed(DENSE_SEED)
+@settings(max_examples=10, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@given(g=dense_geometry)
+def test_restatement_equals_reference_for_dense_scans_at_the_borders(oracle_mod, g):
+    run_loop(g, oracle_impl(oracle_mod, "ho"), oracle_impl(oracle_mod, "hr"), steps=6)
+
+
+@pytest.mark.gpu
+@seed(DENSE_SEED)
+@settings(max_examples=10, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@given(g=dense_geometry)
+def test_gpu_dense_update_equals_reference_at_the_borders(oracle_mod, g):
+    """exact mode: every pose, covariance and map of the loop bit-identical to the reference, and after every update the
+    dense path's byte map and the keyed path's end-cell bitmap are all zero again"""
+    from hector_slam_amd import capi
+
+    def make_gpu(res, size, levels, start, free, occ):
+        m = capi.MapRepMultiMap(res, size, size, levels, start, parity=capi.PARITY_EXACT)
+        m.setUpdateFactorFree(free)
+        m.setUpdateFactorOccupied(occ)
+
+        def check(gg, t):
+            for lvl in range(m.getMapLevels()):
+                assert m.debug_marks_nonzero(lvl) == (0, 0), (gg, t, lvl)
+        return {"match": lambda h, sc, og: m.matchData(h, sc, None, og), "update": lambda p, sc, og: m.updateByScan(sc, p, og),
+                "level": m.download_level, "keep": m, "check": check}
+    run_loop(g, make_gpu, oracle_impl(oracle_mod, oracle_kinds()[-1]), steps=6)
