@@ -28,6 +28,7 @@ from . import build as _build
 HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
 PARITY_FAST, PARITY_EXACT, PARITY_RELAXED, PARITY_AUTO = 0, 1, 2, 3
+GATHER_AUTO, GATHER_PEER, GATHER_RCCL = 0, 1, 2
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -82,6 +83,10 @@ SIGNATURES = {
     "hsm_group_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
     "hsm_group_match_batch_device": (_i, [_vp, _i32p, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hsm_group_synchronize": (_i, [_vp]),
+    "hsm_group_set_gather": (_i, [_vp, _i]),
+    "hsm_group_gather_mode": (_i, [_vp]),
+    "hsm_group_gather_note": (C.c_char_p, [_vp]),
+    "hsm_group_gathered": (_vp, [_vp, _i, _i]),
     "hsm_retain_scan": (_i, [_vp, _vp, _i, _f32p]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -607,6 +612,19 @@ class MapRepGroup:
 
     def synchronize(self):
         _check(self._lib.hsm_group_synchronize(self._g), "hsm_group_synchronize")
+
+    def set_gather(self, mode: int):
+        """GATHER_AUTO / GATHER_PEER / GATHER_RCCL for match_batch_device (RCCL asked for explicitly raises if unavailable)"""
+        _check(self._lib.hsm_group_set_gather(self._g, mode), "hsm_group_set_gather")
+
+    def gather_mode(self):
+        """("rccl" | "peer", note): what match_batch_device gathers with (initialises the RCCL communicators if still open)"""
+        m = self._lib.hsm_group_gather_mode(self._g)
+        return {GATHER_PEER: "peer", GATHER_RCCL: "rccl"}.get(m, "undecided"), self._lib.hsm_group_gather_note(self._g).decode()
+
+    def gathered(self, replica, want_cov=False):
+        """device pointer (int, 0 = none) of the all-gathered poses / Hessians replica `replica` holds after an RCCL gather"""
+        return int(self._lib.hsm_group_gathered(self._g, replica, 1 if want_cov else 0) or 0)
 
     def match_batch(self, begin_world, pts, offsets=None, want_cov=True):
         b = np.ascontiguousarray(begin_world, np.float32).reshape(-1, 3)

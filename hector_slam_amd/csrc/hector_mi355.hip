@@ -8,8 +8,10 @@
 // host keeps only scalars.  There is no CPU compute path.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <rccl/rccl.h>  // declarations only: librccl is dlopen'ed by the group entry points (rccl_api), never linked
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1871,6 +1873,62 @@ struct GroupWorker {
   std::string err;
 };
 
+// RCCL, loaded on first use: the single-GPU library keeps its dependency set (HIP / HSA / libc), and a process that never
+// gathers across devices never maps the 570 MB librccl.  In a process that has PyTorch-ROCm loaded the SONAME resolves to
+// the librccl torch already brought in (one RCCL, one HIP runtime); elsewhere to /opt/rocm/lib.
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string error;
+};
+
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) {
+      const char* e = dlerror();
+      api.error = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found");
+      return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) -> void* {
+      void* p = dlsym(api.lib, n);
+      if (!p) {
+        ok = false;
+        api.error = std::string("librccl: missing symbol ") + n;
+      }
+      return p;
+    };
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+    if (!ok) {
+      dlclose(api.lib);
+      api.lib = nullptr;
+    }
+  });
+  return &api;
+}
+
 struct hsm_group {
   std::vector<hsm_ctx*> members;
   std::vector<std::unique_ptr<GroupWorker>> workers;  // workers[r - 1] serves replica r
@@ -1878,8 +1936,59 @@ struct hsm_group {
   std::vector<float*> d_pose, d_cov;
   std::vector<size_t> d_cap;  // scans
   std::vector<hipEvent_t> evt;
+  // the gather itself: RCCL over the group's devices (one communicator per replica, ncclCommInitAll on first use), or
+  // peer copies.  gather_pref = what was asked for (hsm_group_set_gather / env HSM_GROUP_GATHER), gather_mode = what runs.
+  int gather_pref = HSM_GATHER_AUTO, gather_mode = HSM_GATHER_AUTO;
+  std::vector<ncclComm_t> comms;
+  std::vector<float*> d_all_pose, d_all_cov;  // all-gather receive blocks of the replicas other than the root
+  std::vector<size_t> d_all_cap;              // floats of pose block (cov block: 3x)
+  std::string gather_note;                    // why AUTO settled on peer copies, if it did
   std::mutex mu;  // one group call at a time
 };
+
+#define NCCL_TRY(api, expr)                                                                     \
+  do {                                                                                          \
+    ncclResult_t r__ = (expr);                                                                  \
+    if (r__ != ncclSuccess) {                                                                   \
+      char b__[384];                                                                            \
+      snprintf(b__, sizeof b__, "%s: %s", #expr, (api)->GetErrorString ? (api)->GetErrorString(r__) : "rccl error"); \
+      return fail(HSM_ERR_HIP, b__);                                                            \
+    }                                                                                           \
+  } while (0)
+
+// decide (once) how the group gathers: RCCL needs the library, distinct devices and a communicator per replica
+static int group_ensure_gather(hsm_group* g) {
+  if (g->gather_mode != HSM_GATHER_AUTO) return HSM_OK;
+  const int R = (int)g->members.size();
+  auto settle_peer = [&](const std::string& why) -> int {
+    if (g->gather_pref == HSM_GATHER_RCCL) return fail(HSM_ERR_HIP, ("hsm_group: RCCL gather requested but unavailable: " + why).c_str());
+    g->gather_note = why;
+    g->gather_mode = HSM_GATHER_PEER;
+    return HSM_OK;
+  };
+  if (g->gather_pref == HSM_GATHER_PEER) {
+    g->gather_mode = HSM_GATHER_PEER;
+    return HSM_OK;
+  }
+  std::vector<int> devs;
+  for (hsm_ctx* h : g->members) devs.push_back(h->device);
+  for (int a = 0; a < R; ++a)
+    for (int b = a + 1; b < R; ++b)
+      if (devs[a] == devs[b]) return settle_peer("a device is listed more than once (one RCCL rank per device)");
+  RcclApi* api = rccl_api();
+  if (!api->lib) return settle_peer(api->error);
+  g->comms.assign((size_t)R, nullptr);
+  const ncclResult_t r = api->CommInitAll(g->comms.data(), R, devs.data());
+  if (r != ncclSuccess) {
+    g->comms.clear();
+    return settle_peer(std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+  }
+  g->d_all_pose.assign((size_t)R, nullptr);
+  g->d_all_cov.assign((size_t)R, nullptr);
+  g->d_all_cap.assign((size_t)R, 0);
+  g->gather_mode = HSM_GATHER_RCCL;
+  return HSM_OK;
+}
 
 static void group_worker_main(GroupWorker* w) {
   std::unique_lock<std::mutex> lk(w->m);
@@ -1956,9 +2065,40 @@ int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned leve
   g->d_cov.assign((size_t)n_devices, nullptr);
   g->d_cap.assign((size_t)n_devices, 0);
   g->evt.assign((size_t)n_devices, nullptr);
+  if (const char* env = getenv("HSM_GROUP_GATHER")) {
+    if (strcmp(env, "rccl") == 0) g->gather_pref = HSM_GATHER_RCCL;
+    else if (strcmp(env, "peer") == 0) g->gather_pref = HSM_GATHER_PEER;
+    else if (strcmp(env, "auto") != 0) {
+      hsm_group_destroy(g);
+      return fail(HSM_ERR_INVALID, "hsm_group_create: HSM_GROUP_GATHER must be one of auto, rccl, peer");
+    }
+  }
   *out = g;
   return HSM_OK;
 }
+
+int hsm_group_set_gather(hsm_group* g, int mode) {
+  if (!g) return fail(HSM_ERR_INVALID, "null group");
+  if (mode != HSM_GATHER_AUTO && mode != HSM_GATHER_PEER && mode != HSM_GATHER_RCCL)
+    return fail(HSM_ERR_INVALID, "hsm_group_set_gather: unknown mode");
+  std::lock_guard<std::mutex> glk(g->mu);
+  g->gather_pref = mode;
+  if (mode == HSM_GATHER_PEER || (mode == HSM_GATHER_RCCL && g->gather_mode == HSM_GATHER_PEER) ||
+      (mode == HSM_GATHER_AUTO && g->comms.empty()))
+    g->gather_mode = mode == HSM_GATHER_PEER ? HSM_GATHER_PEER : HSM_GATHER_AUTO;  // (communicators, once made, are kept)
+  else if (!g->comms.empty())
+    g->gather_mode = HSM_GATHER_RCCL;
+  return mode == HSM_GATHER_RCCL ? group_ensure_gather(g) : HSM_OK;
+}
+
+int hsm_group_gather_mode(hsm_group* g) {
+  if (!g) return HSM_GATHER_AUTO;
+  std::lock_guard<std::mutex> glk(g->mu);
+  if (group_ensure_gather(g) != HSM_OK) return HSM_GATHER_AUTO;
+  return g->gather_mode;
+}
+
+const char* hsm_group_gather_note(const hsm_group* g) { return g ? g->gather_note.c_str() : ""; }
 
 void hsm_group_destroy(hsm_group* g) {
   if (!g) return;
@@ -1970,8 +2110,18 @@ void hsm_group_destroy(hsm_group* g) {
     }
     if (w->th.joinable()) w->th.join();
   }
+  if (!g->comms.empty()) {
+    for (hsm_ctx* h : g->members) (void)hsm_synchronize(h);
+    RcclApi* api = rccl_api();
+    for (ncclComm_t c : g->comms)
+      if (c && api->CommDestroy) (void)api->CommDestroy(c);
+  }
   for (size_t r = 0; r < g->members.size(); ++r) {
     if (g->members[r]) (void)hipSetDevice(g->members[r]->device);
+    if (r < g->d_all_pose.size()) {
+      (void)hipFree(g->d_all_pose[r]);
+      (void)hipFree(g->d_all_cov[r]);
+    }
     if (r < g->d_pose.size()) {
       (void)hipFree(g->d_pose[r]);
       (void)hipFree(g->d_cov[r]);
@@ -2026,14 +2176,29 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
     first[(size_t)r + 1] = first[(size_t)r] + (size_t)counts[r];
   }
   const int root_dev = g->members[(size_t)root]->device;
-  // every replica: match its shard on its own stream, then push the poses (and H) to the root's device with a peer
-  // copy on the same stream -- 12 (+36) bytes per scan over xGMI, no host staging, no host wait
+  if (int rc = group_ensure_gather(g)) return rc;
+  const bool rccl = g->gather_mode == HSM_GATHER_RCCL;
+  const size_t total = first[(size_t)R];
+  bool equal = counts[0] > 0;  // ncclAllGather wants the same count from every rank
+  for (int r = 1; r < R; ++r) equal = equal && counts[r] == counts[0];
+  // every replica: match its shard on its own stream.  Peer gather: push the poses (and H) to the root's device with a peer
+  // copy on the same stream -- 12 (+36) bytes per scan over xGMI, no host staging, no host wait.  RCCL gather: the
+  // collective is queued below, behind the match, on the same streams.
   int rc = group_parallel(g, [&](int r) -> int {
     hsm_ctx* h = g->members[(size_t)r];
     const size_t n = (size_t)counts[r];
     std::lock_guard<std::mutex> lk(h->mu);
     if (int rc2 = select_device(h)) return rc2;
     if (!g->evt[(size_t)r]) HIP_TRY(hipEventCreateWithFlags(&g->evt[(size_t)r], hipEventDisableTiming));
+    if (rccl && equal && r != root && total * 3 > g->d_all_cap[(size_t)r]) {  // all-gather receive blocks of a non-root replica
+      (void)hipFree(g->d_all_pose[(size_t)r]);
+      (void)hipFree(g->d_all_cov[(size_t)r]);
+      g->d_all_pose[(size_t)r] = g->d_all_cov[(size_t)r] = nullptr;
+      g->d_all_cap[(size_t)r] = 0;
+      HIP_TRY(hipMalloc((void**)&g->d_all_pose[(size_t)r], total * 3 * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&g->d_all_cov[(size_t)r], total * 9 * sizeof(float)));
+      g->d_all_cap[(size_t)r] = total * 3;
+    }
     if (n > 0) {
       if (n > g->d_cap[(size_t)r]) {
         (void)hipFree(g->d_pose[(size_t)r]);
@@ -2048,16 +2213,53 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
                                               d_scan_offsets ? d_scan_offsets[r] : nullptr, shared_n, g->d_pose[(size_t)r],
                                               d_out_cov_all ? g->d_cov[(size_t)r] : nullptr, h->stream))
         return rc2;
-      HIP_TRY(hipMemcpyPeerAsync(d_out_pose_all + 3 * first[(size_t)r], root_dev, g->d_pose[(size_t)r], h->device,
-                                 n * 3 * sizeof(float), h->stream));
-      if (d_out_cov_all)
-        HIP_TRY(hipMemcpyPeerAsync(d_out_cov_all + 9 * first[(size_t)r], root_dev, g->d_cov[(size_t)r], h->device,
-                                   n * 9 * sizeof(float), h->stream));
+      if (!rccl || (r == root && !equal)) {  // (RCCL send/recv gather: the root's own shard is a local copy)
+        HIP_TRY(hipMemcpyPeerAsync(d_out_pose_all + 3 * first[(size_t)r], root_dev, g->d_pose[(size_t)r], h->device,
+                                   n * 3 * sizeof(float), h->stream));
+        if (d_out_cov_all)
+          HIP_TRY(hipMemcpyPeerAsync(d_out_cov_all + 9 * first[(size_t)r], root_dev, g->d_cov[(size_t)r], h->device,
+                                     n * 9 * sizeof(float), h->stream));
+      }
     }
-    HIP_TRY(hipEventRecord(g->evt[(size_t)r], h->stream));
+    if (!rccl) HIP_TRY(hipEventRecord(g->evt[(size_t)r], h->stream));
     return HSM_OK;
   });
   if (rc != HSM_OK) return rc;
+  if (rccl) {
+    // ONE grouped collective over the group's communicators, each rank's part on its replica's stream (behind its match):
+    // equal shards -> ncclAllGather of [B/G, 3] (+ [B/G, 9]); the root receives straight into the caller's arrays, the
+    // other replicas into blocks the group keeps (every replica then holds all poses: hsm_group_gathered).  Unequal
+    // shards -> the same gather as grouped ncclSend / ncclRecv to the root.  The collective itself orders the root's
+    // stream behind every shard.
+    RcclApi* api = rccl_api();
+    NCCL_TRY(api, api->GroupStart());
+    ncclResult_t nr = ncclSuccess;
+    for (int r = 0; r < R && nr == ncclSuccess; ++r) {
+      hsm_ctx* h = g->members[(size_t)r];
+      const size_t n = (size_t)counts[r];
+      if (equal) {
+        nr = api->AllGather(g->d_pose[(size_t)r], r == root ? d_out_pose_all : g->d_all_pose[(size_t)r], n * 3, ncclFloat,
+                            g->comms[(size_t)r], h->stream);
+        if (nr == ncclSuccess && d_out_cov_all)
+          nr = api->AllGather(g->d_cov[(size_t)r], r == root ? d_out_cov_all : g->d_all_cov[(size_t)r], n * 9, ncclFloat,
+                              g->comms[(size_t)r], h->stream);
+      } else if (r != root && n > 0) {
+        hsm_ctx* hr = g->members[(size_t)root];
+        nr = api->Send(g->d_pose[(size_t)r], n * 3, ncclFloat, root, g->comms[(size_t)r], h->stream);
+        if (nr == ncclSuccess)
+          nr = api->Recv(d_out_pose_all + 3 * first[(size_t)r], n * 3, ncclFloat, r, g->comms[(size_t)root], hr->stream);
+        if (nr == ncclSuccess && d_out_cov_all) {
+          nr = api->Send(g->d_cov[(size_t)r], n * 9, ncclFloat, root, g->comms[(size_t)r], h->stream);
+          if (nr == ncclSuccess)
+            nr = api->Recv(d_out_cov_all + 9 * first[(size_t)r], n * 9, ncclFloat, r, g->comms[(size_t)root], hr->stream);
+        }
+      }
+    }
+    const ncclResult_t ne = api->GroupEnd();
+    if (nr != ncclSuccess) NCCL_TRY(api, nr);
+    NCCL_TRY(api, ne);
+    return HSM_OK;
+  }
   // the root's stream waits for every shard: work queued on it afterwards (and hsm_synchronize on the root member) sees
   // the complete gather
   hsm_ctx* hr = g->members[(size_t)root];
@@ -2066,6 +2268,11 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
   for (int r = 0; r < R; ++r)
     if (r != root) HIP_TRY(hipStreamWaitEvent(hr->stream, g->evt[(size_t)r], 0));
   return HSM_OK;
+}
+
+const float* hsm_group_gathered(hsm_group* g, int replica, int want_cov) {
+  if (!g || replica < 0 || replica >= (int)g->d_all_pose.size()) return nullptr;
+  return want_cov ? g->d_all_cov[(size_t)replica] : g->d_all_pose[(size_t)replica];
 }
 
 int hsm_group_synchronize(hsm_group* g) {

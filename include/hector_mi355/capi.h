@@ -161,10 +161,24 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
  * sharded contiguously over the replicas, one PERSISTENT host thread per replica (created with the group), each
  * replica on its own stream.  Two forms: host arrays in/out (hsm_group_match_batch: the "gather" of the poses is the
  * D2H copy of each shard into the caller's arrays) and device-resident shards (hsm_group_match_batch_device: the
- * gather is a peer copy of each shard's [n,3] poses over xGMI to the root replica's device, no host staging).  Map
- * updates are replayed on every replica -- updateByScan is deterministic, so the replicas stay bit-identical.
- * (bench.py uses the other deployment shape: one process per GPU and an RCCL all-gather of device-resident poses.) */
+ * gather of each shard's [n,3] poses to the root replica's device runs over xGMI, no host staging -- as ONE grouped RCCL
+ * collective over the group's communicators (ncclCommInitAll on first use; librccl is dlopen'ed then, the library does
+ * not link it), or as peer copies; see hsm_group_set_gather).  Map updates are replayed on every replica -- updateByScan
+ * is deterministic, so the replicas stay bit-identical.
+ * (bench.py's --gpus N uses the other deployment shape: one process per GPU and an RCCL all-gather of device-resident
+ * poses through torch.distributed; bench.py --group N drives this one.) */
 typedef struct hsm_group hsm_group;
+/* how hsm_group_match_batch_device gathers.  AUTO (default; env HSM_GROUP_GATHER=auto|rccl|peer at hsm_group_create):
+ * RCCL when librccl loads, every replica sits on its own device and ncclCommInitAll succeeds, else peer copies
+ * (hsm_group_gather_note says why).  RCCL asked for explicitly fails instead of falling back. */
+enum { HSM_GATHER_AUTO = 0, HSM_GATHER_PEER = 1, HSM_GATHER_RCCL = 2 };
+int hsm_group_set_gather(hsm_group* g, int mode);
+/* the mode in effect (initialises the communicators if that is still open): HSM_GATHER_PEER or HSM_GATHER_RCCL */
+int hsm_group_gather_mode(hsm_group* g);
+const char* hsm_group_gather_note(const hsm_group* g);
+/* RCCL gather with equal shards is an all-gather: replica i (other than the root, which received into the caller's arrays)
+ * holds all poses [sum(counts) * 3] (want_cov: all Hessians [sum * 9]) in a block the group owns; NULL otherwise */
+const float* hsm_group_gathered(hsm_group* g, int replica, int want_cov);
 int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
                      const int* devices, int n_devices, hsm_group** out);
 void hsm_group_destroy(hsm_group* g);
@@ -179,8 +193,9 @@ int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float*
  * d_pts_xy[r], d_scan_offsets[r]: CSR offsets relative to the shard, or d_scan_offsets == NULL / entries NULL for
  * pose hypotheses of one shared scan of shared_n beams per replica).  The poses of all shards are gathered, in replica
  * order, into d_out_pose_all [sum(counts) * 3] on replica `root`'s device (and the Hessians into d_out_cov_all
- * [sum * 9] unless NULL) by hipMemcpyPeerAsync on each replica's own stream.  Asynchronous: returns when everything
- * is queued; root's context stream is ordered behind the gather (hsm_synchronize(hsm_group_member(g, root)) or
+ * [sum * 9] unless NULL): by a grouped ncclAllGather (equal counts) / ncclSend + ncclRecv (ragged counts) on the replicas'
+ * own streams, or by hipMemcpyPeerAsync on each replica's own stream (hsm_group_set_gather).  Asynchronous: returns when
+ * everything is queued; root's context stream is ordered behind the gather (hsm_synchronize(hsm_group_member(g, root)) or
  * hsm_group_synchronize wait for it). */
 int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* const* d_begin_world,
                                  const float* const* d_pts_xy, const int* const* d_scan_offsets, int shared_n, int root,

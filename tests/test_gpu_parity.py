@@ -750,6 +750,71 @@ def test_update_with_more_than_65535_beams_is_bit_exact(capi, oracle_mod, kind):
     assert np.array_equal(bits(px), bits(po)) and np.array_equal(bits(cx), bits(co))
 
 
+def test_group_gathers_with_rccl(capi, pyramid_scene, monkeypatch):
+    """hsm_group_match_batch_device through RCCL (ncclCommInitAll over the group's devices, ONE grouped ncclAllGather of the
+    [n,3] poses and the [n,9] Hessians on the replicas' own streams; ragged shards: grouped ncclSend / ncclRecv to the root):
+    one replica per device the box has -- a single-rank communicator on the 1-GPU box --, bit-identical to one context and to
+    the peer-copy gather.  A device listed twice cannot have two RCCL ranks: AUTO settles on peer copies and says why,
+    RCCL asked for explicitly is refused."""
+    import torch
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev))
+    one = make_gpu(capi, sc)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    want_p, want_c = one.match_batch(sc.query_init, pts, offs)
+    B = len(sc.query_scans)
+    for ragged in (False, True):
+        per = B // ndev
+        bounds = [(r * per, (r + 1) * per if r + 1 < ndev else (B if not ragged else B - 1)) for r in range(ndev)]
+        if ragged and ndev > 1:
+            bounds[0] = (0, per - 1)
+            bounds[1] = (per - 1, bounds[1][1])
+        nb = bounds[-1][1]
+        shards = []
+        for r, (b, e) in enumerate(bounds):
+            dev = torch.device("cuda", devices[r])
+            sp, so = synth.pack_scans(sc.query_scans[b:e])
+            shards.append([torch.from_numpy(np.ascontiguousarray(sc.query_init[b:e])).to(dev), torch.from_numpy(sp).to(dev), torch.from_numpy(so).to(dev)])
+        got = {}
+        for mode in (capi.GATHER_RCCL, capi.GATHER_PEER):
+            grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, devices)
+            grp.set_update_factors(0.4, 0.9)
+            for r in range(ndev):
+                grp.member(r).build_map(sc.build_poses, sc.build_scans)
+            grp.set_gather(mode)
+            assert grp.gather_mode()[0] == ("rccl" if mode == capi.GATHER_RCCL else "peer")
+            root = ndev - 1
+            rdev = torch.device("cuda", devices[root])
+            for rep in range(3):
+                d_all = torch.zeros((nb, 3), dtype=torch.float32, device=rdev)
+                d_cov = torch.zeros((nb, 9), dtype=torch.float32, device=rdev)
+                torch.cuda.synchronize()
+                grp.match_batch_device([e - b for b, e in bounds], [s_[0].data_ptr() for s_ in shards], [s_[1].data_ptr() for s_ in shards],
+                                       [s_[2].data_ptr() for s_ in shards], 0, root, d_all.data_ptr(), d_cov.data_ptr())
+                grp.synchronize()
+                assert np.array_equal(bits(d_all.cpu().numpy()), bits(want_p[:nb])), (mode, ragged, rep)
+                assert np.array_equal(bits(d_cov.cpu().numpy()), bits(want_c[:nb])), (mode, ragged, rep)
+            if mode == capi.GATHER_RCCL and not ragged and ndev > 1:  # an all-gather: every other replica holds all poses too
+                ptr = grp.gathered(0)
+                assert ptr != 0
+            got[mode] = d_all.cpu().numpy()
+            grp.close()
+        assert np.array_equal(bits(got[capi.GATHER_RCCL]), bits(got[capi.GATHER_PEER]))
+    # one device listed twice: no second RCCL rank on it
+    grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, [0, 0])
+    mode, note = grp.gather_mode()
+    assert mode == "peer" and "more than once" in note
+    with pytest.raises(capi.HsmError):
+        grp.set_gather(capi.GATHER_RCCL)
+    grp.close()
+    monkeypatch.setenv("HSM_GROUP_GATHER", "Rccl")  # a typo must not silently select something
+    with pytest.raises(capi.HsmError):
+        capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, [0])
+    one.close()
+
+
 def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
     """hsm_group_*: R replicas in one process -- on R DISTINCT devices where the box has them (peer copies, per-device
     contexts and streams), else all on device 0 (the sharding, the persistent worker threads and the replica consistency
