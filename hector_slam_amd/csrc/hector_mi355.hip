@@ -235,7 +235,7 @@ LevelRW level_rw(const Level& L) {
   v.sx = L.sx;
   v.sy = L.sy;
   v.tiles_x = L.tiles_x();
-  v.kf_tiles_x = (L.sx + 7) / 8;
+  v.kf_tiles_x = key_free_tiles_x(L.sx);
   v.quad_texels = L.quad_texels();
   return v;
 }
@@ -376,26 +376,21 @@ template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
   // 36-lane chain job per round behind the round's barrier (gn_match_exact.h).  Measured against round 2's producer /
-  // chain-wavefront form below (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
-  // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  env HSM_EXACT_CACHED=0 keeps round 2's form.
+  // chain-wavefront form (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
+  // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  Scans longer than 17 beams per lane stream their tail rows.
   if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
     const int per_lane = (max_n + 63) / 64;
-    if (per_lane <= 17 + 4) {  // scans of up to 17 beams per lane (up to four rows more stream their tail)
-      if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
-      if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
-      return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
-    }
+    if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
+    if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
+    return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
   }
-  // throughput launches: producer wavefronts + chain wavefronts per workgroup (gn_match.h).  Measured
-  // (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2> and two
-  // gathers in flight; on the 4096^2 pyramid, whose gathers miss the L2, <7,1> lost to the one-wavefront-per-scan form
-  // (334 vs 317 us) but <8,2> wins there too (293 us), so every map takes it
+#if defined(HSM_EXPERIMENTS)
+  // round 2's exact batch form: producer wavefronts + chain wavefronts per workgroup (gn_match.h), env HSM_EXACT_CACHED=0.
+  // Measured (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2>
+  // and two gathers in flight.  Not in the default library since round 4 (the texel-cache form above serves every quad
+  // batch; the plane layout takes the one-wavefront exact form below).
   if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form &&
       (h->exact_batch_form == 2 || h->levels[0].cells() <= ((size_t)1 << 23))) {
-    // workgroup shape: 7 producers + 1 consumer, or 8 + 2.  All workgroups of a launch are resident at once, so the
-    // launch lasts as long as the CU with the most producer wavefronts: pick the shape whose fullest of the 256 CUs
-    // carries fewer (4096 scans: 586 workgroups of 7 = three on 74 CUs = 21 producers, against 512 workgroups of 8 =
-    // two everywhere = 16).  env HSM_EXACT_SHAPE=7|8 pins it.
     const auto worst_cu = [&](int per_wg) { return ((P.batch + per_wg - 1) / per_wg + 255) / 256 * per_wg; };
     int per_wg = worst_cu(8) < worst_cu(kExactScans) ? 8 : kExactScans;
     if (h->exact_shape == 7 || h->exact_shape == 8) per_wg = h->exact_shape;
@@ -419,6 +414,7 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     h->last_cfg[5] = 0;
     return HSM_OK;
   }
+#endif
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
   if (h->layout == kLayoutPlane)
@@ -435,13 +431,17 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   return HSM_OK;
 }
 
-// HSM_PARITY_AUTO (the default): a BATCH on a map of more than 2^23 cells takes the reference's summation order.  Measured
-// (profiles/r03/README.md, tests/test_gpu_full_size.py): on the 2048^2 workloads the fast tree is within 1e-4 m of the
-// reference on 36 864 of 36 864 scans; on the 4096^2 pyramid with its 160 m room -- long beams on coarse far walls, 30 % of
-// the scans not settled in the reference itself -- it misses on 0.7 %.  Map size is the proxy for that regime that the
-// context knows; hsm_set_parity pins either mode.  Single scans keep the fast tree (their cost is latency).
+// HSM_PARITY_AUTO (the default): every BATCHED match takes the reference's summation order.  Round 3's rule -- exact only on
+// maps of more than 2^23 cells -- was fitted to BASELINE's own scenes; the scene sweep of round 4 (tools/parity_scene_sweep.py,
+// profiles/r04/parity_scene_sweep.jsonl: six scene families on maps of up to 2^23 cells, 4096 scans each, three start / level
+// set-ups) finds the fast tree beyond 1e-4 m of the reference in every family for some set-up -- 0.02 % .. 0.3 % of the scans
+// with level-0-only matching from SURVEY 8(d)'s start errors, one scan in 4096 on 0.025 m cells from the headline's starts,
+// half the scans of a corridor (near-singular H) -- wherever the reference's own Gauss-Newton iteration has not settled.
+// No property of the map or the batch that the host knows at launch separates those scans, so the default does not try:
+// exact order for every batch (bit-identical to the reference on 100 % of the scans of every family), HSM_PARITY_FAST /
+// _RELAXED for callers who trade the guarantee for 27 % / 37 % more throughput.  Single scans: see match_single().
 bool auto_wants_exact(const hsm_ctx* h, const MatchParams& P) {
-  return h->auto_parity && !h->relaxed && P.begin_world && !P.trace && P.batch > 1 && h->levels[0].cells() > ((size_t)1 << 23);
+  return h->auto_parity && !h->relaxed && P.begin_world && !P.trace;
 }
 
 template <int WPS, int SPB>
@@ -449,7 +449,10 @@ int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stre
   if (exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
   const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
   if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
-  if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
+  // (two beams per lane: only one-wavefront teams get there by themselves -- choose_wps keeps ~5 beams per lane -- so wider
+  // teams, reachable through an explicit waves_per_scan only, share the three-beam instantiation)
+  if constexpr (WPS == 1)
+    if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
   if (per_lane <= 3) return launch_match_t<WPS, SPB, 3>(h, P, stream);
   if (per_lane <= 5) return launch_match_t<WPS, SPB, 5>(h, P, stream);
   if (per_lane <= 9) return launch_match_t<WPS, SPB, 9>(h, P, stream);
@@ -593,7 +596,7 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
         const size_t y0 = (size_t)L.key_rows[0], y1 = (size_t)L.key_rows[1];
         HIP_TRY(hipMemsetAsync(L.d_key_occ + y0 * L.sx, 0, (y1 - y0 + 1) * L.sx * sizeof(unsigned int), h->stream));
 #if HSM_KEYFREE_TILE
-        const size_t row_words = (size_t)((L.sx + 7) / 8) * 32u;  // one row of 8x4-cell tiles
+        const size_t row_words = (size_t)key_free_tiles_x(L.sx) * 32u;  // one row of 8x4-cell tiles
         HIP_TRY(hipMemsetAsync(L.d_key_free + (y0 >> 2) * row_words, 0, ((y1 >> 2) - (y0 >> 2) + 1) * row_words * sizeof(unsigned int), h->stream));
 #else
         HIP_TRY(hipMemsetAsync(L.d_key_free + y0 * L.sx, 0, (y1 - y0 + 1) * L.sx * sizeof(unsigned int), h->stream));
@@ -704,13 +707,13 @@ void level_bbox(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, const UpdatePar
   }
 }
 
-// dense scans take the bitmap form of the update (map_update.h) when every level of the batch has rows of a multiple of
-// 64 cells (the apply pass owns its bitmap words per 64 x 4-cell block); env HSM_DENSE_BITS=0 keeps the keyed form
+// dense scans (>= merged_mark_max beams) take the byte-map form of the update (map_update.h), on every map width since round 4;
+// env HSM_DENSE_BITS=0 keeps them on the keyed one-launch mark pass of the small scans
 bool use_dense_bits(const hsm_ctx* h, const UpdateBatch& batch, int max_n) {
 #if HSM_KEYFREE_TILE
   if (!h->dense_bits || max_n < h->merged_mark_max) return false;
   for (int i = 0; i < batch.nlev; ++i)
-    if ((batch.lv[i].lv.sx & 63) != 0 || batch.lv[i].lv.free_bytes == nullptr) return false;
+    if (batch.lv[i].lv.free_bytes == nullptr) return false;
   return true;
 #else
   return false;
@@ -727,17 +730,25 @@ int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
   if (use_dense_bits(h, batch, max_n)) {
     hipLaunchKernelGGL(update_mark_occ_dense_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
     // x extent a multiple of 8: workgroup b of every level then runs on XCD b % 8 (the kernel's beam -> XCD mapping)
-    hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3(mark_dense_blocks(max_n), ny), dim3(256), 0, h->stream, batch);
+    hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3(mark_dense_blocks_g(max_n), ny), dim3(256), 0, h->stream, batch);
     HIP_TRY(hipGetLastError());
     return HSM_OK;
   }
-  if (max_n < h->merged_mark_max) {
-    // small scans: end-cell marks and line walks in ONE launch (keyed atomics, map_update.h) -- one dependent launch less
-    const unsigned occ_blocks = (unsigned)(max_n + 255) / 256;
-    hipLaunchKernelGGL(update_mark_kernel, dim3(occ_blocks + (max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch, occ_blocks);
-  } else {
+#if defined(HSM_EXPERIMENTS)
+  if (max_n >= h->merged_mark_max) {
+    // rounds 1-2: dense scans on two launches (end cells, then the line walk with plain tag stores where no beam ends);
+    // superseded by the byte-map form on every map width, kept for A/B builds
     hipLaunchKernelGGL(update_mark_occ_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
     hipLaunchKernelGGL(update_mark_free_kernel, dim3((max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch);  // 4 beams (waves) per block
+    HIP_TRY(hipGetLastError());
+    return HSM_OK;
+  }
+#endif
+  {
+    // small scans (and HSM_DENSE_BITS=0): end-cell marks and line walks in ONE launch (keyed atomics, map_update.h) -- one
+    // dependent launch less
+    const unsigned occ_blocks = (unsigned)(max_n + 255) / 256;
+    hipLaunchKernelGGL(update_mark_kernel, dim3(occ_blocks + (max_n + 3) / 4, ny), dim3(256), 0, h->stream, batch, occ_blocks);
   }
   HIP_TRY(hipGetLastError());
   return HSM_OK;

@@ -52,7 +52,7 @@ struct LevelRW {
                              // update_mark_free_dense_kernel, cleared by update_apply_dense_kernel
   int sx, sy;
   int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
-  int kf_tiles_x;            // free-key tiles per row = ceil(sx / 8)   (key_free_index)
+  int kf_tiles_x;            // free-key tiles per row = key_free_tiles_x(sx): ceil(sx / 64) * 8   (key_free_index)
 };
 
 // The free-key plane is stored in 8x4-cell tiles (= one 128-byte line).  The line walk of update_mark_free_kernel
@@ -62,9 +62,13 @@ struct LevelRW {
 #ifndef HSM_KEYFREE_TILE
 #define HSM_KEYFREE_TILE 1
 #endif
+// tiles per tile row, padded to whole 64-cell BLOCKS (8 tiles): the dense apply pass owns the marks of a 64 x 4-cell block as
+// 256 CONTIGUOUS bytes, so the last block of a row must not run into the next tile row -- with the padding the dense form
+// works for every map width (round 4; until then rows had to be a multiple of 64 cells)
+__host__ __device__ __forceinline__ int key_free_tiles_x(int sx) { return ((sx + 63) / 64) * 8; }
 __host__ __device__ __forceinline__ size_t key_free_cells(int sx, int sy) {
 #if HSM_KEYFREE_TILE
-  return (size_t)((sx + 7) / 8) * (size_t)((sy + 3) / 4) * 32u;
+  return (size_t)key_free_tiles_x(sx) * (size_t)((sy + 3) / 4) * 32u;
 #else
   return (size_t)sx * sy;
 #endif
@@ -206,9 +210,11 @@ __device__ __forceinline__ void mark_occ_block(const UpdateParams& P, unsigned i
   if (head && valid) atomicOr(&P.lv.occ_bits[w], m);
 }
 
+#if defined(HSM_EXPERIMENTS)  // rounds 1-2: dense scans on the keyed planes in two launches (superseded by the byte-map form)
 __global__ void __launch_bounds__(256) update_mark_occ_kernel(const UpdateBatch B) {
   mark_occ_block(B.lv[blockIdx.y], blockIdx.x);
 }
+#endif
 
 // dense scans: "a beam ends here" is bit 1 of the cell's mark byte instead of a bit of the row-major end-cell bitmap
 constexpr unsigned char kMarkCrossed = 1, kMarkEnd = 2;
@@ -310,9 +316,11 @@ __device__ __forceinline__ void mark_free_block(const UpdateParams& P, unsigned 
   }
 }
 
+#if defined(HSM_EXPERIMENTS)
 __global__ void __launch_bounds__(256) update_mark_free_kernel(const UpdateBatch B) {
   mark_free_block<false>(B.lv[blockIdx.y], blockIdx.x);
 }
+#endif
 
 // passes 1a + 1b of a SMALL scan in one launch: the first occ_blocks workgroups of a row mark the end cells, the rest
 // walk the lines with keyed atomics (no dependency between the two, see mark_free_block)
@@ -423,9 +431,6 @@ __global__ void __launch_bounds__(256) update_apply_kernel(const UpdateBatch B) 
 #ifndef HSM_MARK_XCD_CHUNK  // workgroups of consecutive beams per XCD turn (xcd_block); < 0: the hardware's round robin
 #define HSM_MARK_XCD_CHUNK 16
 #endif
-__host__ __device__ __forceinline__ int mark_dense_blocks(int n) {  // workgroups of 4 wavefronts, a multiple of 8 (see the kernel)
-  return ((n + 3) / 4 + 7) / 8 * 8;
-}
 
 // a wave-uniform kernel argument pinned in SGPRs before a loop (left alone, the compiler re-loads it from the kernarg segment
 // -- s_load + s_waitcnt -- inside every conditional block of every iteration)
@@ -453,27 +458,44 @@ __device__ __forceinline__ unsigned int div_small(unsigned int num, unsigned int
   return q;
 }
 
+// HSM_MARK_GROUP = G beams per wavefront (1, 2 or 4): 64 / G lanes walk one beam (lane k of the sub-group owns steps k, k + 64/G,
+// ...).  The per-beam set-up (two beam_line evaluations -- the beam's own and its predecessor's for the duplicate suppression --
+// and four divisions) is wave-uniform work at G = 1: every lane computes the same thing, and with ~12 loop iterations per level-0
+// beam (3 on level 2) it is HALF of the kernel's 30 M VALU instructions (ISA: ~300 set-up + ~45 per iteration).  With G beams
+// side by side the same instructions set up G beams; the loop runs G times as many iterations per wavefront on G times fewer
+// wavefronts.  Same cells, same values: bit-identical.
+#ifndef HSM_MARK_GROUP
+#define HSM_MARK_GROUP 1
+#endif
+__host__ __device__ __forceinline__ int mark_dense_blocks_g(int n) {  // workgroups of 4 wavefronts x G beams, a multiple of 8
+  return ((n + 4 * HSM_MARK_GROUP - 1) / (4 * HSM_MARK_GROUP) + 7) / 8 * 8;
+}
+
 __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
+  constexpr int G = HSM_MARK_GROUP, LPB = 64 / G;  // beams per wavefront, lanes per beam
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8, "beams per wavefront");
   const int lane = threadIdx.x & 63;
+  const int sub = lane / LPB, sl = lane % LPB;
   // Neighbouring beams cross the same cells for most of their length, and a mark byte read from another XCD's L2 is stale
   // (this kernel's stores stay in the writer's L2 until they are evicted): with the hardware's round robin of workgroups
   // over the XCDs every XCD walks every part of the fan.  Chunks of consecutive workgroups per XCD (the grid's x extent is
   // a multiple of 8, so workgroup b of any level runs on XCD b % 8) keep a sector's lines in ONE L2, where the walk sees
   // its neighbours' marks and skips the stores.
-  const int wg = HSM_MARK_XCD_CHUNK >= 0 ? xcd_block((int)blockIdx.x, (int)gridDim.x, HSM_MARK_XCD_CHUNK) : (int)blockIdx.x;
-  const int beam = wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  constexpr int kChunk = HSM_MARK_XCD_CHUNK >= G ? HSM_MARK_XCD_CHUNK / G : (HSM_MARK_XCD_CHUNK >= 0 ? 1 : -1);  // the same 64 beams per chunk
+  const int wg = kChunk >= 0 ? xcd_block((int)blockIdx.x, (int)gridDim.x, kChunk) : (int)blockIdx.x;
+  const int beam = (wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * G + sub;
   if (beam >= P.n) return;
   const BeamLine b = beam_line(P, beam);
   if (!b.valid) return;
   const unsigned int key = (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam);
-  if ((unsigned int)lane >= b.abs_da) return;
-  // lane k visits steps k, k + 64, ...: quotient / remainder of (e0 + i*db) / da carried forward by the per-64-steps increment
+  if ((unsigned int)sl >= b.abs_da) return;
+  // lane k visits steps k, k + LPB, ...: quotient / remainder of (e0 + i*db) / da carried forward by the per-LPB-steps increment
   const bool small = b.abs_da < (1u << 17);  // (e0 + 63 db, 64 db < 2^24: always, for maps below 131072 cells a side)
-  const unsigned int num0 = b.e0 + (unsigned int)lane * b.abs_db;
+  const unsigned int num0 = b.e0 + (unsigned int)sl * b.abs_db;
   unsigned int q = small ? div_small(num0, b.abs_da) : num0 / b.abs_da;
   unsigned int r = num0 - q * b.abs_da;
-  const unsigned int inc = 64u * b.abs_db;
+  const unsigned int inc = (unsigned int)LPB * b.abs_db;
   const unsigned int q64 = small ? div_small(inc, b.abs_da) : inc / b.abs_da, r64 = inc - q64 * b.abs_da;
   // duplicate suppression against the previous beam (mark_free_block)
 #ifndef HSM_MARK_DEDUP
@@ -483,21 +505,21 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   const bool dedup = HSM_MARK_DEDUP && beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
   const bool psmall = pb.abs_da < (1u << 17);
   const unsigned int pden = dedup ? pb.abs_da : 1u;
-  const unsigned int pnum0 = pb.e0 + (unsigned int)lane * pb.abs_db;
+  const unsigned int pnum0 = pb.e0 + (unsigned int)sl * pb.abs_db;
   unsigned int pq = dedup ? (psmall ? div_small(pnum0, pden) : pnum0 / pden) : 0u, pr = dedup ? pnum0 - pq * pden : 0u;
-  const unsigned int pinc = 64u * pb.abs_db;
+  const unsigned int pinc = (unsigned int)LPB * pb.abs_db;
   const unsigned int pq64 = dedup ? (psmall ? div_small(pinc, pden) : pinc / pden) : 0u, pr64 = dedup ? pinc - pq64 * pden : 0u;
   const unsigned int pda = dedup ? pb.abs_da : 0u;  // no step is "also the previous beam's" without dedup
   // the walk in (x, y): i steps along the major axis, q along the minor one; both advance by additions
   const int sgn_a = b.offset_a > 0 ? 1 : -1, sgn_b = b.offset_b > 0 ? 1 : -1;
   const int ax = b.x_major ? sgn_a : 0, ay = b.x_major ? 0 : sgn_a, mx = b.x_major ? 0 : sgn_b, my = b.x_major ? sgn_b : 0;
-  int cx = P.bx + ax * lane + mx * (int)q, cy = P.by + ay * lane + my * (int)q;
-  const int dx64 = 64 * ax + mx * (int)q64, dy64 = 64 * ay + my * (int)q64;  // per iteration, before the remainder's carry
+  int cx = P.bx + ax * sl + mx * (int)q, cy = P.by + ay * sl + my * (int)q;
+  const int dx64 = LPB * ax + mx * (int)q64, dy64 = LPB * ay + my * (int)q64;  // per iteration, before the remainder's carry
   const unsigned int tiles_x = pinned_sgpr((unsigned int)P.lv.kf_tiles_x);
   unsigned char* const marks = pinned_sgpr(P.lv.free_bytes);
   unsigned int* const keys = pinned_sgpr(P.lv.key_free);
   const unsigned int da = b.abs_da;
-  for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
+  for (unsigned int i = sl; i < da; i += LPB) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
 #if HSM_KEYFREE_TILE
       const unsigned int kc = ((__umul24((unsigned int)cy >> 2, tiles_x) + ((unsigned int)cx >> 3)) << 5) | (((unsigned int)cy & 3u) << 3) |
@@ -532,7 +554,8 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   }
 }
 
-// requires sx % 64 == 0 and HSM_KEYFREE_TILE (the host checks): the box is widened to 64-column / 4-row boundaries
+// requires HSM_KEYFREE_TILE (the host checks): the box is widened to 64-column / 4-row boundaries; any map width (the tile
+// rows are padded to whole blocks, key_free_tiles_x)
 #ifndef HSM_APPLY_NT  // 1: the dense apply pass writes its three planes with non-temporal stores -- 12 bytes per touched cell that
                       // nothing reads again before the next update; kept out of the L2 they leave it to the marks and the log-odds
                       // rows (update 0.198 -> 0.178 ms on configs[4]; non-temporal LOADS of the rows or stores of the cleared marks
@@ -594,8 +617,8 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
         // the byte of cell (x, Y0 + dy): tile lane / 8, byte dy * 8 + lane % 8 = dword (lane & ~7) + 2 dy + (lane & 7) / 4, byte lane & 3
         const unsigned int fwd = (unsigned int)__shfl((int)fw[j], (lane & ~7) + 2 * dy + ((lane & 7) >> 2));
         const unsigned int mark = (fwd >> ((lane & 3) << 3)) & 0xffu;
-        occ[j][dy] = (mark & kMarkEnd) != 0u && y < sy;
-        fre[j][dy] = (mark & kMarkCrossed) != 0u && y < sy;
+        occ[j][dy] = (mark & kMarkEnd) != 0u && y < sy && x < sx;  // (the widened box may reach past the map's last row / column:
+        fre[j][dy] = (mark & kMarkCrossed) != 0u && y < sy && x < sx;  //  no mark can sit there, cheap to insist)
         l[j][dy] = 0.0f;
         ko[j][dy] = kf[j][dy] = 0u;
         if (fre[j][dy] || occ[j][dy]) l[j][dy] = P.lv.logodds[c];

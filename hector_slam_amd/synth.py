@@ -67,7 +67,13 @@ class World:
         return t.min(axis=1)
 
 
+_ANGLE_CACHE: dict = {}
+
+
 def beam_angles(n_beams: int) -> np.ndarray:
+    """the fan's beam angles (cached per fan: every scan of a bench batch shares them; callers do not modify the array)"""
+    if n_beams in _ANGLE_CACHE:
+        return _ANGLE_CACHE[n_beams]
     a0, inc = SCAN_SHAPES[n_beams] if n_beams in SCAN_SHAPES else (-math.pi, 2.0 * math.pi / n_beams)
     # the node accumulates ``angle += angle_increment`` in fp32 (HectorMappingRos.cpp:491,505)
     out = np.empty(n_beams, dtype=np.float32)
@@ -76,6 +82,8 @@ def beam_angles(n_beams: int) -> np.ndarray:
     for i in range(n_beams):
         out[i] = ang
         ang = np.float32(ang + inc32)
+    out.setflags(write=False)
+    _ANGLE_CACHE[n_beams] = out
     return out
 
 

@@ -121,23 +121,21 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
         assert same(pg, po) and same(cg, co), it
 
 
-@pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "cached-9rows", "cached-5rows", "throughput", "throughput-8+2",
-                                  "throughput-plane", "one-wave-per-scan"])
+@pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "cached-long", "cached-9rows", "cached-5rows", "plane-layout",
+                                  "one-wave-per-scan"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
-    a small batch picks by itself ("auto"), the texel-cache exact form large maps take (gn_match_exact.h: every wavefront a
-    producer, packed rotating chain jobs; 17 scans = two full workgroups and a partial one; "cached-tail": scans up to four
-    rows longer than the 17 cached ones stream their tail), round 2's wave-specialised forms (seven producer wavefronts +
-    one chain wavefront per workgroup, or eight + two), and the one-wavefront-per-scan form"""
+    a small batch picks by itself ("auto"), the texel-cache exact form every quad-layout batch takes (gn_match_exact.h: every
+    wavefront a producer, packed rotating chain jobs; 17 scans = two full workgroups and a partial one; "cached-tail" /
+    "cached-long": scans four / nine rows longer than the 17 cached ones stream their tail rows), the plane layout (which has
+    no texel-cache exact form) and the one-wavefront-per-scan form (HSM_EXACT_CACHED=0).  Round 2's producer / chain-wavefront
+    form left the default library in round 4 (-DHSM_EXPERIMENTS)"""
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
-    if form == "one-wave-per-scan":
-        monkeypatch.setenv("HSM_EXACT_BATCH", "0")
-    monkeypatch.setenv("HSM_EXACT_CACHED", "1" if form.startswith("cached") or form == "auto" else "0")
-    monkeypatch.setenv("HSM_EXACT_SHAPE", "8" if form == "throughput-8+2" else "7")
+    monkeypatch.setenv("HSM_EXACT_CACHED", "0" if form == "one-wave-per-scan" else "1")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
-    if form == "throughput-plane":
+    if form == "plane-layout":
         kw["layout"] = capi.LAYOUT_PLANE
     g = exact_gpu(capi, sc, o, **kw)
     rng = np.random.default_rng(5)
@@ -150,8 +148,8 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         init.append(sc.query_init[q])
     long_scan = np.concatenate([sc.query_scans[3], sc.query_scans[3][::2] + np.float32(0.01)])  # 1622 beams > 64 * 17
     if form.endswith("-tail"):
-        long_scan = long_scan[:1300]  # 21 rows: the texel-cache form takes it and streams rows 17..20
-    elif form.startswith("cached"):
+        long_scan = long_scan[:1300]  # 21 rows: the texel-cache form streams rows 17..20
+    elif form.startswith("cached") and form != "cached-long":  # ("cached-long": all 1622 beams, 26 rows)
         long_scan = long_scan[:1081]
     scans.append(long_scan)
     init.append(sc.query_init[3])
@@ -161,8 +159,8 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
     init = np.stack(init)
     pts, offs = synth.pack_scans(scans)
     pb, cb = g.match_batch(init, pts, offs)
-    if form.startswith("throughput"):
-        assert g.last_launch_config()["block"] == (640 if form == "throughput-8+2" else 512), g.last_launch_config()
+    if form in ("plane-layout", "one-wave-per-scan"):
+        assert not g.last_launch_config()["texel_cache"], g.last_launch_config()
     if form.startswith("cached"):
         cfg = g.last_launch_config()
         assert cfg["texel_cache"] and cfg["block"] == 256, cfg

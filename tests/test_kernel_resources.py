@@ -148,15 +148,24 @@ def test_gather_contract_walker_catches_a_broken_sequence():
     assert gather_contract_violations(text)
 
 
-@pytest.mark.parametrize("kernel", ["_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE",
-                                    "_ZN3hsm22gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1EEEvNS_11MatchParamsE",
-                                    "_ZN3hsm22gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0EEEvNS_11MatchParamsE",
-                                    "_ZN3hsm22gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0EEEvNS_11MatchParamsE",
-                                    "_ZN3hsm28gn_match_exact_cached_kernelILi4ELi17ELi15EEEvNS_11MatchParamsE"])
-def test_no_register_of_an_inflight_gather_is_touched(device_asm, kernel):
-    m = re.search(r"^" + re.escape(kernel) + r":(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
-    assert m, kernel
-    body = m.group(1)
-    assert body.count("global_load_dwordx4") >= 9
-    bad = gather_contract_violations(body)
-    assert not bad, bad[:5]
+def texel_cache_kernels(asm):
+    """every instantiation of the two kernels that issue their gathers from inline asm"""
+    return sorted(set(re.findall(r"^(_ZN3hsm(?:22gn_match_cached_kernel|28gn_match_exact_cached_kernel)\w+):", asm, re.M)))
+
+
+def test_no_register_of_an_inflight_gather_is_touched(device_asm):
+    """EVERY instantiation in the default library (round-3 verdict: two were guarded): the quad and plane layouts, four and
+    eight scans per workgroup, 9 and 17 rows, the relaxed arithmetic, and the three exact-order forms"""
+    names = texel_cache_kernels(device_asm)
+    assert len(names) >= 10, names
+    for need in ("gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1E", "gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0E",
+                 "gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi2ELi1ELb0E",
+                 "gn_match_exact_cached_kernelILi4ELi17ELi15E", "gn_match_exact_cached_kernelILi4ELi9ELi9E", "gn_match_exact_cached_kernelILi4ELi5ELi5E"):
+        assert any(need in n for n in names), (need, names)
+    for kernel in names:
+        m = re.search(r"^" + re.escape(kernel) + r":(.*?)^\.Lfunc_end", device_asm, re.S | re.M)
+        assert m, kernel
+        body = m.group(1)
+        assert len(re.findall(r"global_load_dwordx[24]", body)) >= 5, kernel  # the gathers are there (x4 texels, x2 plane pairs)
+        bad = gather_contract_violations(body)
+        assert not bad, (kernel, bad[:5])

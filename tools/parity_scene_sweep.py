@@ -142,6 +142,25 @@ def main():
                        "fast_vs_reference_sample": stats(pf[:ns], pr),
                        "reference_unsettled_frac_of_sample": float((dm > 1e-4).mean()),
                        "kernels": {"fast": cfg_f, "exact": cfg_x}}
+                if levels == 3 and "--no-single" not in sys.argv:
+                    # the ROS node's path: ONE scan per hsm_match call (the latency kernels: another summation tree than the
+                    # batch form's), fast against exact on the first `ns` scans, with the host-call time of both
+                    single = {}
+                    for mode, nm in ((capi.PARITY_FAST, "fast"), (capi.PARITY_EXACT, "exact"), (capi.PARITY_AUTO, "default")):
+                        m.set_parity(mode)
+                        outp = np.empty((ns, 3), np.float32)
+                        t0 = time.perf_counter()
+                        for q in range(ns):
+                            outp[q] = m.matchData(init[q], scans[q])[0]
+                        single[nm] = (outp, (time.perf_counter() - t0) / ns * 1e6, m.last_launch_config())
+                    rec["single_scan"] = {"fast_vs_exact": stats(single["fast"][0], single["exact"][0]),
+                                          "default_vs_exact": stats(single["default"][0], single["exact"][0]),
+                                          "default_mode": single["default"][2]["parity_effective"],
+                                          "exact_vs_reference": stats(single["exact"][0], pr),
+                                          "host_call_us": {k: round(v[1], 2) for k, v in single.items()}}
+                    print("   single scans: fast within", rec["single_scan"]["fast_vs_exact"]["within_1e-4"], "worst",
+                          rec["single_scan"]["fast_vs_exact"]["worst_dxy_m"], "| exact==ref", rec["single_scan"]["exact_vs_reference"]["bit_identical"],
+                          "| us/call", rec["single_scan"]["host_call_us"], flush=True)
                 fh.write(json.dumps(rec) + "\n")
                 fh.flush()
                 print(fam, levels, iname, "fast within", rec["fast_vs_exact"]["within_1e-4"], "worst", rec["fast_vs_exact"]["worst_dxy_m"],
