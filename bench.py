@@ -373,6 +373,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             names = ["update_mark_occ_dense_kernel", "update_mark_occ_kernel", "update_mark_free_dense_kernel", "update_apply_dense_kernel", "update_mark_free_kernel",
                      "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel"]
             pv, perr = pmc_collect(["--workload", "config5", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=2)
+            pmc_dump(args.pmc_dump, "config5", pv, perr, "configs[4] replica: 16 k-beam scans on the 8192^2 pyramid, match + update per step (plane layout)")
             if pv:
                 ks, tot_ns, tot_hbm = {}, 0.0, 0.0
                 for k, v in pv.items():
@@ -511,6 +512,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             # the node's cycle kernel by kernel: duration, instructions, HBM bytes (counter passes around `--leg pmc`)
             names = ["gn_match_kernel", "update_mark_kernel", "update_apply_kernel", "update_texels_kernel"]
             pv, perr = pmc_collect(["--workload", "config2", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=5)
+            pmc_dump(args.pmc_dump, "config2", pv, perr, "configs[1]: one 1081-beam scan on the 3-level 1024^2 pyramid, match + update cycle")
             if pv:
                 out["roofline"]["kernels"] = {
                     k: {"avg_us": v.get("avg_ns", 0.0) / 1e3, "launches": v.get("avg_ns_launches"),
@@ -617,6 +619,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
     if rank == 0 and nranks == 1 and not args.no_pmc and not under_profiler():
         pv, perr = pmc_collect(["--workload", name, "--leg", "pmc", "--no-cpu", "--no-pmc", "--steps", str(min(args.steps, 10))],
                                ["gn_match_exact_cached_kernel", "gn_match_exact_batch_kernel", "gn_match_cached_kernel", "gn_match_kernel"])
+        pmc_dump(args.pmc_dump, name, pv, perr, f"{name}: batch of {B} x {beams}-beam scans, {levels}-level {size}^2 pyramid; fast-mode launches, then exact-mode launches")
     clock_hz = m.device_info()["clock_khz"] * 1e3
     out["roofline"] = roofline_block(fast_kernel, kern_ms, bytes_per_launch, beams, its, B, (pv or {}).get(fast_kernel), perr, clock_hz)
     default_is_exact = True  # round 4: HSM_PARITY_AUTO takes the reference's summation order for EVERY batch
@@ -1367,7 +1370,8 @@ def main():
         matcher.close()
         del matcher
         torch.cuda.empty_cache()
-        extra = ["--compact"] + (["--no-cpu"] if args.no_cpu else []) + (["--no-pmc"] if args.no_pmc else [])
+        extra = ["--compact"] + (["--no-cpu"] if args.no_cpu else []) + (["--no-pmc"] if args.no_pmc else []) + \
+            (["--pmc-dump", args.pmc_dump] if args.pmc_dump else [])
         cf = {"configs[0]": config1_plumbing(capi) if not args.no_cpu else None}
         for key, wl in (("configs[1]", "config2"), ("configs[3] (one GPU's share)", "config4"), ("configs[4] (one replica)", "config5")):
             cf[key] = run_child(["--workload", wl] + extra, timeout_s=400)

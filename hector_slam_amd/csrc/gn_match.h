@@ -199,7 +199,17 @@ __device__ __forceinline__ void affine_apply(const Affine2& a, float x, float y,
 // PIN: the texel-cache forms pin the binary64 constants to their use (libm_exact.h at_use: they have no register to hoist
 // them into); the latency forms let the optimiser hoist them out of the 14-step chain
 template <bool PIN = false>
-__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) { libm::sincosf_glibc<PIN>(th, s, c); }
+__device__ __forceinline__ void sincos_f32(float th, float& s, float& c) {
+#if defined(HSM_EXPERIMENTS) && defined(HSM_EXP_FAST_SINCOS)
+  // what-if build (NOT parity-safe): the hardware's v_sin_f32 / v_cos_f32 -- two instructions -- instead of glibc's binary64
+  // evaluation.  An upper bound on what any restructuring of the bit-exact sincosf can buy per Gauss-Newton step
+  // (round-3 verdict item 7; profiles/r04/README.md)
+  s = __sinf(th);
+  c = __cosf(th);
+#else
+  libm::sincosf_glibc<PIN>(th, s, c);
+#endif
+}
 
 // util::normalize_angle (HSL/util/UtilFunctions.h:37-49): double fmod, float result
 template <bool PIN = false>

@@ -1256,10 +1256,26 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     unsigned* bar_counter = reinterpret_cast<unsigned*>(h->d_partials + 2 * 64 * 12);
     unsigned bar_base = h->coop_bar_base;
     void* args[] = {(void*)&P, (void*)&partials, (void*)&bar_counter, (void*)&bar_base};
-    const void* fn = h->layout == kLayoutPlane
-                         ? (h->coop_tagged ? (const void*)gn_match_coop_kernel<kLayoutPlane, true> : (const void*)gn_match_coop_kernel<kLayoutPlane, false>)
-                         : (h->coop_tagged ? (const void*)gn_match_coop_kernel<kLayoutQuad, true> : (const void*)gn_match_coop_kernel<kLayoutQuad, false>);
-    if (hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream) == hipSuccess) {
+    const void* fn = h->layout == kLayoutPlane ? (const void*)gn_match_coop_kernel<kLayoutPlane, false>
+                                                : (const void*)gn_match_coop_kernel<kLayoutQuad, false>;
+    // The tagged-record exchange (default) has no grid barrier: a workgroup that is not resident yet only delays the others'
+    // polls, which are bounded (a record that never arrives turns into an error return, err_flag) -- so it is an ORDINARY
+    // launch: K <= 64 workgroups of 256 lanes are co-resident on an idle 256-CU device, and on a busy one they become so as
+    // soon as other kernels retire.  (Round 3 launched it through hipLaunchCooperativeKernel: that goes through the
+    // device's cooperative queue -- a slower launch, and a process that has used it segfaults in the runtime's exit
+    // handlers when it runs under rocprofv3, profiles/r04/README.md.)  The counter-barrier form (HSM_COOP_TAGGED=0) spins
+    // without a bound and keeps the cooperative launch's co-residency guarantee.
+    hipError_t le;
+    if (h->coop_tagged) {
+      if (h->layout == kLayoutPlane)
+        hipLaunchKernelGGL((gn_match_coop_kernel<kLayoutPlane, true>), dim3(K), dim3(256), 0, h->stream, P, partials, bar_counter, bar_base);
+      else
+        hipLaunchKernelGGL((gn_match_coop_kernel<kLayoutQuad, true>), dim3(K), dim3(256), 0, h->stream, P, partials, bar_counter, bar_base);
+      le = hipGetLastError();
+    } else {
+      le = hipLaunchCooperativeKernel(fn, dim3(K), dim3(256), args, 0, h->stream);
+    }
+    if (le == hipSuccess) {
       unsigned steps = 0;
       for (int l = P.first_level; l >= P.last_level; --l) steps += (unsigned)P.lv[l].gn_steps;
       h->coop_bar_base += (unsigned)K * steps;  // one arrival per workgroup per GN step

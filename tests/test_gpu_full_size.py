@@ -81,9 +81,10 @@ def batch_properties(capi, oracle_mod, sc, g, init, scans, rng, fast_within_tol,
     from hector_slam_amd import synth
     B = len(scans)
     pts, offs = synth.pack_scans(scans)
-    # ---- the default (HSM_PARITY_AUTO): exact summation for batches on maps above 2^23 cells, the fast tree below
+    # ---- the default (HSM_PARITY_AUTO): the reference's summation order for EVERY batch (round 4; profiles/r04 scene sweep)
     assert g.parity() == capi.PARITY_AUTO
     pose_auto, _ = g.match_batch(init, pts, offs)
+    assert g.last_launch_config()["parity_effective"] == "exact"
     # ---- exact mode: the WHOLE batch against the reference, bit for bit, no predicate
     g.set_parity(capi.PARITY_EXACT)
     pose_x, cov_x = g.match_batch(init, pts, offs)
@@ -93,8 +94,8 @@ def batch_properties(capi, oracle_mod, sc, g, init, scans, rng, fast_within_tol,
     # ---- fast mode, measured against the exact mode
     g.set_parity(capi.PARITY_FAST)
     pose, cov = g.match_batch(init, pts, offs)
-    big = sc.map_size * sc.map_size > (1 << 23)
-    assert np.array_equal(bits(pose_auto), bits(pose_x if big else pose)), "HSM_PARITY_AUTO: exact above 2^23 cells, fast below"
+    assert g.last_launch_config()["parity_effective"] == "fast"
+    assert np.array_equal(bits(pose_auto), bits(pose_x)), "HSM_PARITY_AUTO: the default batch result is the exact mode's"
     assert np.isfinite(pose).all() and np.isfinite(cov).all()
     d = np.abs(pose.astype(np.float64) - pose_x)
     dxy, dth = d[:, :2].max(1), ang_diff(pose[:, 2], pose_x[:, 2])
@@ -200,12 +201,19 @@ def test_config5_dense_scan_8192map_interleaved(capi, oracle_mod):
         hint_o, hint_g = po + step, pg + step
     cfg = p.mapRep.last_launch_config()
     assert cfg["waves_per_scan"] == -cfg["grid"] and 56 <= cfg["grid"] <= 64  # ~n / 256 cooperating workgroups (multi-CU dense matcher)
+    differ = []
     for lvl in range(sc.levels):
         lo_g, _ = p.mapRep.download_level(lvl)
         lo_o, _ = o.download_level(lvl)
         touched = (lo_o != 0).sum()
         assert touched > 100000
-        assert (bits(lo_g) != bits(lo_o)).sum() <= 0.002 * touched
+        nd = int((bits(lo_g) != bits(lo_o)).sum())
+        differ.append({"level": lvl, "touched": int(touched), "cells_differ": nd, "frac": nd / float(touched)})
+        # fast-mode poses differ from the reference's in the last bits -> a handful of Bresenham end cells may flip; the
+        # bound is 4x what MI355X measures (recorded below; exact mode: 0, next test)
+        assert nd <= 0.002 * touched, differ
+    record(test="config5_fast_mode_free_running_maps", steps=steps, checker=KIND, cells_differing_from_reference=differ,
+           bound_frac=0.002)
     # identical poses in -> bit-identical maps out (pure index work), at full size
     g2 = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
     g2.setUpdateFactorFree(0.4)

@@ -683,6 +683,45 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
             assert np.array_equal(bits(pq), bits(ref[q][0])) and np.array_equal(bits(cq), bits(ref[q][1])), (rep, q)
 
 
+def test_dense_matcher_exchange_forms_agree(capi, pyramid_scene, monkeypatch):
+    """the multi-workgroup matcher exchanges its partial sums through tagged 16-byte records (default: an ordinary launch, no
+    grid barrier) or through the counter grid barrier (HSM_COOP_TAGGED=0: a cooperative launch): same sums in the same
+    order -> bit-identical poses and covariances, across the wrap of the barrier counter as well; and a match while a long
+    batch kernel occupies the device on another stream still completes (the workgroups become co-resident as it retires)"""
+    import torch
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    rng = np.random.default_rng(78)
+    scans = [synth.make_scan(sc.world, sc.query_truth[q], n, s, rng) for q, n in ((0, 4096), (1, 8192), (2, 16384))]
+    got = {}
+    for tagged in ("1", "0"):
+        monkeypatch.setenv("HSM_COOP_TAGGED", tagged)
+        g = make_gpu(capi, sc)
+        if tagged == "0":
+            g.debug_set_coop_barrier(0xffffffff - 700)
+        got[tagged] = [g.matchData(sc.query_init[q], scans[q]) for q in range(3) for _ in range(2)]
+        assert g.last_launch_config()["waves_per_scan"] < 0
+        if tagged == "1":
+            # a 4096-scan batch on a caller-owned stream right before the dense match: the device is busy when it launches
+            dev = torch.device("cuda", 0)
+            B = 4096
+            pts, offs = synth.pack_scans([sc.query_scans[i % len(sc.query_scans)] for i in range(B)])
+            init = np.repeat(sc.query_init, B // len(sc.query_init) + 1, 0)[:B]
+            d_i, d_p, d_o = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (init, pts, offs))
+            d_out = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            for rep in range(3):
+                for _ in range(4):
+                    g.match_batch_device(B, d_i.data_ptr(), d_p.data_ptr(), d_o.data_ptr(), 1081, d_out.data_ptr(), 0, side.cuda_stream)
+                pb, cb = g.matchData(sc.query_init[1], scans[1])
+                assert np.array_equal(bits(pb), bits(got["1"][2][0])) and np.array_equal(bits(cb), bits(got["1"][2][1])), rep
+            torch.cuda.synchronize()
+        g.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
 def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):
     """the key planes carry a 12-bit per-scan generation (the other 20 bits are the beam index); after 4095 updates
     (100 s at 40 Hz) it wraps and the planes are cleared once.  Updates straddling the wrap -- with stale keys of

@@ -129,7 +129,9 @@ def main():
                 px, cfg_x = match(capi.PARITY_EXACT, init)
                 pa, cfg_a = match(capi.PARITY_AUTO, init)
                 # the reference on a sample, and whether IT has settled (restart from its own result)
-                ns = min(S, B)
+                # (the corridor: the reference itself flies off along the corridor on some scans and, once its estimate is NaN,
+                # indexes the map with (int)NaN and segfaults -- OccGridMapUtil.h:295,302; its first 256 scans are known to survive)
+                ns = min(S, B, 256) if fam.startswith("corridor") else min(S, B)
                 pr = o.match_many(init[:ns], pts, offs[:ns + 1])
                 pr2 = o.match_many(pr, pts, offs[:ns + 1])
                 dm = np.abs(pr2.astype(np.float64) - pr)[:, :2].max(1)
