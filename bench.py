@@ -87,6 +87,14 @@ def multi_rank_record(dt_local: float, kern_ms_local: float, dev, gathered=None)
     return rec
 
 
+def pose_stats(a, b):
+    """how two sets of poses of the same scans compare: bit-identical fraction, fraction within 1e-4 m / 1e-4 rad, worst"""
+    dd = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    dd[:, 2] = np.abs((dd[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+    return {"scans": int(a.shape[0]), "bit_identical": float((a.view(np.uint32) == b.view(np.uint32)).all(1).mean()),
+            "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()), "max_abs_dxy_m": float(dd[:, :2].max())}
+
+
 def algorithmic_bytes_per_iteration(n_beams: int) -> int:
     return 24 * n_beams + 60  # 8 B endpoint + 4 x 4 B samples per beam; 12 B pose in + 48 B H,dTr out
 
@@ -1010,9 +1018,11 @@ def main():
                     help="extra workloads: the short form the default run embeds (fewer steps, smaller CPU samples)")
     ap.add_argument("--no-configs", action="store_true", help="skip the legs for the other BASELINE configs")
     ap.add_argument("--no-relaxed", action="store_true", help="skip the HSM_PARITY_RELAXED leg")
-    ap.add_argument("--leg", default=None, choices=["pmc", "pyramid", "pipelined"],
+    ap.add_argument("--leg", default=None, choices=["pmc", "pyramid", "pipelined", "8d"],
                     help="internal: a leg of the default run executed in a child process")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps launches each; the median one is reported (timed_regions keeps all)")
+    ap.add_argument("--prewarm-ms", type=float, default=40.0,
+                    help="untimed launches for this long before the warm-up steps of every timed run (engine clock settling)")
     ap.add_argument("--starts", default="headline", choices=["headline", "8d"], help="internal (--leg pmc): start errors of the counter pass")
     ap.add_argument("--pmc-dump", default=None, help="directory for pmc_<leg>.txt files with the raw counter values of this run")
     ap.add_argument("--group", type=int, default=0,
@@ -1115,6 +1125,14 @@ def main():
         # first GN step and at its end; read after the timed loop = the clock the LAST timed launch ran at
         probe = torch.zeros(4, dtype=torch.int64, device=dev)
         matcher.set_clock_probe(probe.data_ptr())
+        # the engine clock needs ~25 ms of load to settle (first 200-launch region of a cold run: 65 us per launch, second 61,
+        # then 58.5 -- profiles/r04/README.md): untimed launches until it has, then the W warm-up steps of the contract
+        if args.prewarm_ms > 0:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         regions = []
@@ -1145,7 +1163,7 @@ def main():
             regions.append((dt, ev0.elapsed_time(ev1) / steps))
         order = sorted(range(len(regions)), key=lambda i: regions[i][0])
         dt, kern_ms = regions[order[len(order) // 2]]
-        run.regions = {"repeats": len(regions), "steps_each": steps, "ms_per_step": [r[0] / steps * 1e3 for r in regions],
+        run.regions = {"repeats": len(regions), "steps_each": steps, "prewarm_ms": args.prewarm_ms, "ms_per_step": [r[0] / steps * 1e3 for r in regions],
                        "kernel_ms": [r[1] for r in regions], "reported": "median region",
                        "min_ms_per_step": min(r[0] for r in regions) / steps * 1e3, "max_ms_per_step": max(r[0] for r in regions) / steps * 1e3}
         st = probe.cpu().numpy().astype(np.uint64)
@@ -1167,6 +1185,26 @@ def main():
         run(matcher, d_in, args.steps, args.warmup)
         matcher.set_parity(capi.PARITY_FAST)
         run(matcher, d_in, args.steps, args.warmup)
+        return
+    if args.leg == "8d":
+        # SURVEY 8(d)'s start errors on the level-0 headline batch (round-3 verdict: the texel cache re-gathers only lanes whose
+        # cell changed, so the headline's sub-cell starts are the gentler input): same scans, +-0.15 m / +-0.05 rad.  A child
+        # process, so that a kernel trace of the parent holds the headline's launches only.
+        matcher = build_matcher(1)
+        i8 = init_8d_level0(truth, rank)
+        d_i8 = torch.from_numpy(i8).to(dev)
+        leg = {"start_error": "+-0.15 m, +-0.05 rad (SURVEY.md 8(d)), level 0 only, same 4096 scans"}
+        poses8 = {}
+        for mode, nm in ((capi.PARITY_AUTO, "default"), (capi.PARITY_FAST, "fast")):
+            matcher.set_parity(mode)
+            dt8, k8, its8 = run(matcher, d_i8, args.steps, 3, repeats=min(args.repeats, 3))
+            poses8[nm] = d_pose.cpu().numpy().copy()
+            leg[nm] = {"value": B * its8 * args.steps / dt8, "kernel_ms": k8, "kernel": kernel_of(matcher.last_launch_config()),
+                       "timed_regions": getattr(run, "regions", None)}
+        leg["fast_vs_default_all_scans"] = pose_stats(poses8["fast"], poses8["default"])
+        if not args.no_cpu:
+            leg["default"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, i8, pts, offs, poses8["default"], 1, budget_s=0.0, n_par=512)
+        print(json.dumps(leg))
         return
     if args.leg == "pipelined":
         # Independent batches issued round-robin on S caller-owned streams (hsm_match_batch_device is asynchronous on the
@@ -1289,12 +1327,6 @@ def main():
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
                           "median_abs_err_theta_rad": float(np.median(conv[:, 2]))}
 
-    def pose_stats(a, b):
-        dd = np.abs(a.astype(np.float64) - b.astype(np.float64))
-        dd[:, 2] = np.abs((dd[:, 2] + np.pi) % (2 * np.pi) - np.pi)
-        return {"scans": int(a.shape[0]), "bit_identical": float((a.view(np.uint32) == b.view(np.uint32)).all(1).mean()),
-                "within_1e-4": float(((dd[:, :2].max(1) <= 1e-4) & (dd[:, 2] <= 1e-4)).mean()), "max_abs_dxy_m": float(dd[:, :2].max())}
-
     single = rank == 0 and world == 1
     exact_pose = gpu_pose if cfg.get("parity_effective") == "exact" else None
     if single and not args.no_exact:
@@ -1314,20 +1346,10 @@ def main():
             out["fast_mode"]["fast_vs_default_all_scans"] = pose_stats(fast_pose, exact_pose)
         matcher.set_parity(capi.PARITY_AUTO)
     if single and not args.no_exact and args.levels == 1 and B == BATCH_PER_GPU:
-        # SURVEY 8(d)'s start errors on the level-0 headline batch (round-3 verdict: the texel cache re-gathers only lanes whose
-        # cell changed, so the headline's sub-cell starts are the gentler input): same scans, +-0.15 m / +-0.05 rad
-        i8 = init_8d_level0(truth, rank)
-        d_i8 = torch.from_numpy(i8).to(dev)
-        leg = {"start_error": "+-0.15 m, +-0.05 rad (SURVEY.md 8(d)), level 0 only, same 4096 scans"}
-        poses8 = {}
-        for mode, nm in ((capi.PARITY_AUTO, "default"), (capi.PARITY_FAST, "fast")):
-            matcher.set_parity(mode)
-            dt8, k8, _ = run(matcher, d_i8, max(10, args.steps // 2), 3, repeats=min(args.repeats, 3))
-            poses8[nm] = d_pose.cpu().numpy().copy()
-            leg[nm] = {"value": B * its * max(10, args.steps // 2) / dt8, "kernel_ms": k8, "kernel": kernel_of(matcher.last_launch_config())}
-        matcher.set_parity(capi.PARITY_AUTO)
-        leg["fast_vs_default_all_scans"] = pose_stats(poses8["fast"], poses8["default"])
-        if want_pmc and not under_profiler():
+        # the same batch from SURVEY 8(d)'s start errors (child process: `--leg 8d`), with the counters of its launches
+        leg = run_child(["--leg", "8d", "--steps", str(max(10, args.steps // 2)), "--batch", str(B), "--repeats", str(args.repeats)] +
+                        (["--no-cpu"] if args.no_cpu else []))
+        if want_pmc and not under_profiler() and "error" not in leg:
             p8, e8 = pmc_leg(["gn_match_exact_cached_kernel", fast_name], extra=("--starts", "8d"))
             pmc_dump(args.pmc_dump, "headline_8d_starts", p8, e8, "the headline batch from SURVEY 8(d)'s start errors (+-0.15 m / +-0.05 rad)")
             for nm in ("default", "fast"):
@@ -1337,8 +1359,6 @@ def main():
                 leg[nm]["same_counters_headline_starts"] = {k: h.get(k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "TCP_TCC_READ_REQ_sum", "avg_ns")}
             if e8:
                 leg["pmc_errors"] = e8
-        if not args.no_cpu:
-            leg["default"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, i8, pts, offs, poses8["default"], 1, budget_s=0.0, n_par=512)
         out["headline_8d_starts"] = leg
     if single and not args.no_relaxed and args.levels == 1:
         # HSM_PARITY_RELAXED (opt-in): multiply-add pairs of the per-beam arithmetic contracted; bar = 1e-4 m / 1e-4 rad

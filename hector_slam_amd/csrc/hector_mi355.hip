@@ -119,6 +119,8 @@ struct hsm_ctx {
   int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
   int merged_mark_max = 4096;       // scans below this take the one-launch mark pass (env HSM_MERGED_MARK_MAX, 0 = never)
   int scatter_texels_max = 1 << 30; // quad layout: scans below this write the texels from the apply pass (env HSM_SCATTER_TEXELS_MAX, 0 = never)
+  BeamRec* d_beam_recs = nullptr;   // dense scans: per-beam records of all levels (map_update.h BeamRec), [levels][cap]
+  size_t beam_recs_cap = 0;         // beams per level
   float2* h_upd_pinned[2] = {nullptr, nullptr};
   size_t h_upd_cap[2] = {0, 0};
   hipEvent_t upd_evt[2] = {nullptr, nullptr};
@@ -621,6 +623,7 @@ int prepare_level(hsm_ctx* h, UpdateBatch& batch, LevelPrep& prep, int level, co
     P.mark_occ = L.curr_mark_occ;
     P.x0 = P.y0 = 0;
     P.x1 = P.y1 = -1;  // empty box until level_bbox(): the dense passes skip the level
+    P.recs = nullptr;  // dense scans: set by launch_update_mark()
     prep.slot = batch.nlev;
     batch.lv[batch.nlev++] = P;
     L.marks_pending = true;  // until the apply pass over this level's box is queued (update_applied)
@@ -721,16 +724,26 @@ bool use_dense_bits(const hsm_ctx* h, const UpdateBatch& batch, int max_n) {
 }
 
 // pass 1 of map_update.h for all levels of the batch (grid.y = level): needs no box
-int launch_update_mark(hsm_ctx* h, const UpdateBatch& batch) {
+int launch_update_mark(hsm_ctx* h, UpdateBatch& batch) {
   if (batch.nlev == 0) return HSM_OK;
   int max_n = 0;
   for (int i = 0; i < batch.nlev; ++i)
     if (batch.lv[i].n > max_n) max_n = batch.lv[i].n;
   const unsigned ny = (unsigned)batch.nlev;
   if (use_dense_bits(h, batch, max_n)) {
+    // per-beam records: written by the end-cell pass, read by the line walk (one block of max_n records per level)
+    if ((size_t)max_n > h->beam_recs_cap) {
+      if (h->d_beam_recs) HIP_TRY(hipFree(h->d_beam_recs));  // (frees wait for the queued work that still reads the old block)
+      h->d_beam_recs = nullptr;
+      h->beam_recs_cap = 0;
+      const size_t want = (size_t)max_n + (size_t)max_n / 2;
+      HIP_TRY(hipMalloc((void**)&h->d_beam_recs, want * HSM_MAX_LEVELS * sizeof(BeamRec)));
+      h->beam_recs_cap = want;
+    }
+    for (int i = 0; i < batch.nlev; ++i) batch.lv[i].recs = h->d_beam_recs + (size_t)i * h->beam_recs_cap;
     hipLaunchKernelGGL(update_mark_occ_dense_kernel, dim3((max_n + 255) / 256, ny), dim3(256), 0, h->stream, batch);
     // x extent a multiple of 8: workgroup b of every level then runs on XCD b % 8 (the kernel's beam -> XCD mapping)
-    hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3(mark_dense_blocks_g(max_n), ny), dim3(256), 0, h->stream, batch);
+    hipLaunchKernelGGL(update_mark_free_dense_kernel, dim3(mark_dense_blocks(max_n), ny), dim3(256), 0, h->stream, batch);
     HIP_TRY(hipGetLastError());
     return HSM_OK;
   }
@@ -982,6 +995,7 @@ void hsm_destroy(hsm_ctx* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (Level& L : h->levels) free_level(L);
   (void)hipFree(h->d_scan);
+  (void)hipFree(h->d_beam_recs);
   (void)hipFree(h->d_retained);
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);

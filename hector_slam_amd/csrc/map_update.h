@@ -88,6 +88,18 @@ constexpr unsigned int kBeamBits = 20;
 constexpr unsigned int kBeamMask = (1u << kBeamBits) - 1u;
 constexpr unsigned int kSerialMax = (1u << (32 - kBeamBits)) - 1u;
 
+// What the dense line walk needs to know about ONE beam on ONE level -- the result of beam_line() and of the two divisions
+// of its per-64-steps increment.  Round 3's walk derived all of this per WAVEFRONT (one beam each, 64 lanes computing the same
+// numbers: ~300 of the kernel's VALU instructions per beam, twice -- the beam and its predecessor --, half of its 30 M);
+// since round 4 the end-cell pass, which evaluates beam_line() per LANE anyway, stores the record and the walk reads two of
+// them through the scalar cache (wave-uniform address: s_load_dwordx4 into SGPRs).
+struct BeamRec {
+  unsigned int abs_da;  // major-axis steps = free cells of the line; 0 = the beam is skipped (off the map, begin == end, NaN)
+  unsigned int abs_db;
+  unsigned int q64;     // (64 * abs_db) / abs_da: minor steps per 64 major steps ...
+  unsigned int r64_oct; // ... and the remainder, << 3 | octant: bit 0 x is the major axis, bit 1 major step > 0, bit 2 minor step > 0
+};
+
 struct UpdateParams {
   LevelRW lv;
   Affine2 pose;           // Translation(mapPose.xy) * Rotation(mapPose.theta), host sinf/cosf
@@ -99,6 +111,7 @@ struct UpdateParams {
   float log_odds_free, log_odds_occ;
   int mark_free, mark_occ;  // currMarkFreeIndex / currMarkOccIndex (OccGridMapBase.h:123-124)
   int x0, y0, x1, y1;       // inclusive cell bounding box of everything this scan can touch
+  struct BeamRec* recs;     // dense scans: one record per beam of this level (update_mark_occ_dense_kernel -> the line walk)
 };
 
 // GridMapLogOddsFunctions::getGridProbability (GridMapLogOdds.h:163-166): exp(float) is glibc's expf
@@ -232,10 +245,20 @@ __global__ void __launch_bounds__(256) update_mark_occ_dense_kernel(const Update
   if (valid) {
     const BeamLine b = beam_line(P, beam);
     valid = b.valid;
+    BeamRec rec = {0u, 0u, 0u, 0u};
     if (valid) {
       c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
       kc = key_free_index(P.lv, (unsigned int)b.x1, (unsigned int)b.y1);
+      // the walk's per-64-steps increment of (e0 + i * db) / da: quotient and remainder (abs_da >= 1 for a valid beam)
+      const unsigned int inc = 64u * b.abs_db;
+      const unsigned int q64 = inc / b.abs_da;
+      const bool major_pos = b.offset_a > 0, minor_pos = b.offset_b > 0;
+      rec.abs_da = b.abs_da;
+      rec.abs_db = b.abs_db;
+      rec.q64 = q64;
+      rec.r64_oct = ((inc - q64 * b.abs_da) << 3) | (b.x_major ? 1u : 0u) | (major_pos ? 2u : 0u) | (minor_pos ? 4u : 0u);
     }
+    reinterpret_cast<uint4*>(P.recs)[beam] = make_uint4(rec.abs_da, rec.abs_db, rec.q64, rec.r64_oct);
   }
   const unsigned int c_prev = (unsigned int)__shfl_up((int)c, 1);
   if (valid && (lane == 0 || c_prev != c)) {  // of a run of adjacent lanes with the same end cell the first = lowest beam index
@@ -458,83 +481,69 @@ __device__ __forceinline__ unsigned int div_small(unsigned int num, unsigned int
   return q;
 }
 
-// HSM_MARK_GROUP = G beams per wavefront (1, 2 or 4): 64 / G lanes walk one beam (lane k of the sub-group owns steps k, k + 64/G,
-// ...).  The per-beam set-up (two beam_line evaluations -- the beam's own and its predecessor's for the duplicate suppression --
-// and four divisions) is wave-uniform work at G = 1: every lane computes the same thing, and with ~12 loop iterations per level-0
-// beam (3 on level 2) it is HALF of the kernel's 30 M VALU instructions (ISA: ~300 set-up + ~45 per iteration).  With G beams
-// side by side the same instructions set up G beams; the loop runs G times as many iterations per wavefront on G times fewer
-// wavefronts.  Same cells, same values: bit-identical.
-#ifndef HSM_MARK_GROUP
-#define HSM_MARK_GROUP 1
-#endif
-__host__ __device__ __forceinline__ int mark_dense_blocks_g(int n) {  // workgroups of 4 wavefronts x G beams, a multiple of 8
-  return ((n + 4 * HSM_MARK_GROUP - 1) / (4 * HSM_MARK_GROUP) + 7) / 8 * 8;
+__host__ __device__ __forceinline__ int mark_dense_blocks(int n) {  // workgroups of 4 wavefronts = 4 beams, a multiple of 8
+  return ((n + 3) / 4 + 7) / 8 * 8;
 }
 
+// Tried in round 4 and dropped (profiles/r04/update_variants_kernel_us.txt, maps bit-identical in every variant): G = 2 / 4
+// beams side by side in one wavefront, 64 / G lanes each (the set-up amortised over G beams): 76.8 / 120 us against 72.1 --
+// the beams of a group differ in length and octant, so lanes idle and the loop diverges; without the duplicate suppression
+// (HSM_MARK_DEDUP=0): 104 us -- the per-step load only sees marks that have reached this XCD's L2, the predecessor test
+// needs no memory at all.
 __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
-  constexpr int G = HSM_MARK_GROUP, LPB = 64 / G;  // beams per wavefront, lanes per beam
-  static_assert(G == 1 || G == 2 || G == 4 || G == 8, "beams per wavefront");
   const int lane = threadIdx.x & 63;
-  const int sub = lane / LPB, sl = lane % LPB;
   // Neighbouring beams cross the same cells for most of their length, and a mark byte read from another XCD's L2 is stale
   // (this kernel's stores stay in the writer's L2 until they are evicted): with the hardware's round robin of workgroups
   // over the XCDs every XCD walks every part of the fan.  Chunks of consecutive workgroups per XCD (the grid's x extent is
   // a multiple of 8, so workgroup b of any level runs on XCD b % 8) keep a sector's lines in ONE L2, where the walk sees
   // its neighbours' marks and skips the stores.
-  constexpr int kChunk = HSM_MARK_XCD_CHUNK >= G ? HSM_MARK_XCD_CHUNK / G : (HSM_MARK_XCD_CHUNK >= 0 ? 1 : -1);  // the same 64 beams per chunk
-  const int wg = kChunk >= 0 ? xcd_block((int)blockIdx.x, (int)gridDim.x, kChunk) : (int)blockIdx.x;
-  const int beam = (wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * G + sub;
+  const int wg = HSM_MARK_XCD_CHUNK >= 0 ? xcd_block((int)blockIdx.x, (int)gridDim.x, HSM_MARK_XCD_CHUNK) : (int)blockIdx.x;
+  const int beam = __builtin_amdgcn_readfirstlane(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));  // wave-uniform
   if (beam >= P.n) return;
-  const BeamLine b = beam_line(P, beam);
-  if (!b.valid) return;
+  // the beam's record and its predecessor's: wave-uniform 16-byte loads (scalar cache), everything derived from them
+  // stays in SGPRs
+  const uint4* __restrict__ recs = reinterpret_cast<const uint4*>(P.recs);
+  const uint4 rb = recs[beam];
+  const unsigned int da = rb.x;
+  if (da == 0u) return;  // skipped beam (beam_line: invalid)
+  if ((unsigned int)lane >= da) return;
+  const uint4 rp = beam > 0 ? recs[beam - 1] : make_uint4(0u, 0u, 0u, 0u);
+  const unsigned int db = rb.y, q64 = rb.z, r64 = rb.w >> 3, oct = rb.w & 7u;
   const unsigned int key = (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam);
-  if ((unsigned int)sl >= b.abs_da) return;
-  // lane k visits steps k, k + LPB, ...: quotient / remainder of (e0 + i*db) / da carried forward by the per-LPB-steps increment
-  const bool small = b.abs_da < (1u << 17);  // (e0 + 63 db, 64 db < 2^24: always, for maps below 131072 cells a side)
-  const unsigned int num0 = b.e0 + (unsigned int)sl * b.abs_db;
-  unsigned int q = small ? div_small(num0, b.abs_da) : num0 / b.abs_da;
-  unsigned int r = num0 - q * b.abs_da;
-  const unsigned int inc = (unsigned int)LPB * b.abs_db;
-  const unsigned int q64 = small ? div_small(inc, b.abs_da) : inc / b.abs_da, r64 = inc - q64 * b.abs_da;
-  // duplicate suppression against the previous beam (mark_free_block)
+  // lane k visits steps k, k + 64, ...: quotient / remainder of (e0 + i*db) / da carried forward by the per-64-steps increment
+  const bool small = da < (1u << 17);  // (e0 + 63 db, 64 db < 2^24: always, for maps below 131072 cells a side)
+  const unsigned int num0 = (da >> 1) + (unsigned int)lane * db;  // e0 = abs_da / 2
+  unsigned int q = small ? div_small(num0, da) : num0 / da;
+  unsigned int r = num0 - q * da;
+  // duplicate suppression against the previous beam (mark_free_block): valid, same octant
 #ifndef HSM_MARK_DEDUP
 #define HSM_MARK_DEDUP 1
 #endif
-  const BeamLine pb = (HSM_MARK_DEDUP && beam > 0) ? beam_line(P, beam - 1) : b;
-  const bool dedup = HSM_MARK_DEDUP && beam > 0 && pb.valid && pb.offset_a == b.offset_a && pb.offset_b == b.offset_b;
-  const bool psmall = pb.abs_da < (1u << 17);
-  const unsigned int pden = dedup ? pb.abs_da : 1u;
-  const unsigned int pnum0 = pb.e0 + (unsigned int)sl * pb.abs_db;
-  unsigned int pq = dedup ? (psmall ? div_small(pnum0, pden) : pnum0 / pden) : 0u, pr = dedup ? pnum0 - pq * pden : 0u;
-  const unsigned int pinc = (unsigned int)LPB * pb.abs_db;
-  const unsigned int pq64 = dedup ? (psmall ? div_small(pinc, pden) : pinc / pden) : 0u, pr64 = dedup ? pinc - pq64 * pden : 0u;
-  const unsigned int pda = dedup ? pb.abs_da : 0u;  // no step is "also the previous beam's" without dedup
+  const bool dedup = HSM_MARK_DEDUP && rp.x != 0u && (rp.w & 7u) == oct;
+  const unsigned int pda = dedup ? rp.x : 0u;  // no step is "also the previous beam's" without dedup
+  const unsigned int pden = dedup ? rp.x : 1u, pdb = rp.y;
+  const unsigned int pnum0 = (pden >> 1) + (unsigned int)lane * pdb;
+  unsigned int pq = dedup ? (pden < (1u << 17) ? div_small(pnum0, pden) : pnum0 / pden) : 0u, pr = dedup ? pnum0 - pq * pden : 0u;
+  const unsigned int pq64 = dedup ? rp.z : 0u, pr64 = dedup ? rp.w >> 3 : 0u;
   // the walk in (x, y): i steps along the major axis, q along the minor one; both advance by additions
-  const int sgn_a = b.offset_a > 0 ? 1 : -1, sgn_b = b.offset_b > 0 ? 1 : -1;
-  const int ax = b.x_major ? sgn_a : 0, ay = b.x_major ? 0 : sgn_a, mx = b.x_major ? 0 : sgn_b, my = b.x_major ? sgn_b : 0;
-  int cx = P.bx + ax * sl + mx * (int)q, cy = P.by + ay * sl + my * (int)q;
-  const int dx64 = LPB * ax + mx * (int)q64, dy64 = LPB * ay + my * (int)q64;  // per iteration, before the remainder's carry
+  const bool x_major = (oct & 1u) != 0u;
+  const int sgn_a = (oct & 2u) ? 1 : -1, sgn_b = (oct & 4u) ? 1 : -1;
+  const int ax = x_major ? sgn_a : 0, ay = x_major ? 0 : sgn_a, mx = x_major ? 0 : sgn_b, my = x_major ? sgn_b : 0;
+  int cx = P.bx + ax * lane + mx * (int)q, cy = P.by + ay * lane + my * (int)q;
+  const int dx64 = 64 * ax + mx * (int)q64, dy64 = 64 * ay + my * (int)q64;  // per iteration, before the remainder's carry
   const unsigned int tiles_x = pinned_sgpr((unsigned int)P.lv.kf_tiles_x);
   unsigned char* const marks = pinned_sgpr(P.lv.free_bytes);
   unsigned int* const keys = pinned_sgpr(P.lv.key_free);
-  const unsigned int da = b.abs_da;
-  for (unsigned int i = sl; i < da; i += LPB) {  // abs_da free cells: steps 0 .. abs_da-1
-    if (!(i < pda && pq == q)) {
+  auto cell_index = [&]() -> unsigned int {
 #if HSM_KEYFREE_TILE
-      const unsigned int kc = ((__umul24((unsigned int)cy >> 2, tiles_x) + ((unsigned int)cx >> 3)) << 5) | (((unsigned int)cy & 3u) << 3) |
-                              ((unsigned int)cx & 7u);  // == key_free_index(P.lv, cx, cy): rows of tiles and tiles per row are below 2^24
+    return ((__umul24((unsigned int)cy >> 2, tiles_x) + ((unsigned int)cx >> 3)) << 5) | (((unsigned int)cy & 3u) << 3) |
+           ((unsigned int)cx & 7u);  // == key_free_index(P.lv, cx, cy): rows of tiles and tiles per row are below 2^24
 #else
-      const unsigned int kc = key_free_index(P.lv, (unsigned int)cx, (unsigned int)cy);
+    return key_free_index(P.lv, (unsigned int)cx, (unsigned int)cy);
 #endif
-      // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
-      const unsigned char m = marks[kc];
-      if (m & kMarkEnd) {
-        atomicMax(&keys[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
-      } else if (m == 0) {          // (a stale 0 only repeats the store)
-        marks[kc] = kMarkCrossed;
-      }
-    }
+  };
+  auto advance = [&]() {  // 64 steps on: the carries of both error accumulators
     q += q64;
     r += r64;
     cx += dx64;
@@ -551,7 +560,41 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
       pr -= pda;
       ++pq;
     }
+  };
+  auto touch = [&](unsigned int kc, unsigned char m) {
+    if (m & kMarkEnd) {
+      atomicMax(&keys[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
+    } else if (m == 0) {          // (a stale 0 only repeats the store)
+      marks[kc] = kMarkCrossed;
+    }
+  };
+#ifndef HSM_MARK_UNROLL  // 2: two steps (i, i + 64) per iteration with both byte loads in flight before either is acted on
+#define HSM_MARK_UNROLL 1
+#endif
+#if HSM_MARK_UNROLL == 2
+  for (unsigned int i = lane; i < da; i += 128) {
+    const bool need_a = !(i < pda && pq == q);
+    const unsigned int kc_a = cell_index();
+    advance();
+    const bool need_b = i + 64 < da && !(i + 64 < pda && pq == q);
+    const unsigned int kc_b = cell_index();
+    advance();
+    unsigned char m_a = kMarkCrossed, m_b = kMarkCrossed;  // "already marked": nothing to do
+    if (need_a) m_a = marks[kc_a];
+    if (need_b) m_b = marks[kc_b];
+    touch(kc_a, m_a);
+    touch(kc_b, m_b);
   }
+#else
+  for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
+    if (!(i < pda && pq == q)) {
+      const unsigned int kc = cell_index();
+      // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
+      touch(kc, marks[kc]);
+    }
+    advance();
+  }
+#endif
 }
 
 // requires HSM_KEYFREE_TILE (the host checks): the box is widened to 64-column / 4-row boundaries; any map width (the tile

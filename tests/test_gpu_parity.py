@@ -25,10 +25,11 @@ pytestmark = pytest.mark.gpu
 POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
 # fast (tree) summation measured against the exact mode on maps made of a handful of scans, where Gauss-Newton has often not
-# settled (test_randomised_geometries, test_processor_lifecycle_*): bounds = what MI355X measures, with a margin
+# settled (test_randomised_geometries, test_processor_lifecycle_*): bounds = 2x what MI355X measures (round-3 advisor: a few
+# millimetres of drift must not pass; the fast tree is deterministic -- no atomics -- so the measured values repeat)
 # (measured: 83 / 84 within tolerance, worst 2.1e-3 m; lifecycle 34/34, 34/34, 33/34 within 1e-4 m, worst 4.1e-4 m)
-FAST_RANDOM_WITHIN, FAST_RANDOM_WORST_M = 0.95, 1e-2
-FAST_LIFECYCLE_WITHIN, FAST_LIFECYCLE_WORST_M = 0.94, 2e-3
+FAST_RANDOM_WITHIN, FAST_RANDOM_WORST_M = 0.97, 4.2e-3
+FAST_LIFECYCLE_WITHIN, FAST_LIFECYCLE_WORST_M = 0.96, 8.2e-4
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -58,7 +59,17 @@ def capi():
     return m
 
 
+@pytest.fixture(autouse=True)
+def fast_tree_by_default(monkeypatch):
+    """contexts created in this file start in HSM_PARITY_FAST (see make_gpu), also those constructed directly"""
+    monkeypatch.setenv("HSM_PARITY", "fast")
+
+
 def make_gpu(capi, scene, free=0.4, occ=0.9, build=True, **kw):
+    # this file exercises the FAST forms (tree summation: the texel-cache batch kernel, the team kernels, the dense matcher)
+    # against their bars; the library default -- HSM_PARITY_AUTO: the reference's order for every batch -- has its own test
+    # below, and the exact forms theirs in tests/test_gpu_exact_parity.py
+    kw.setdefault("parity", capi.PARITY_FAST)
     g = capi.MapRepMultiMap(scene.resolution, scene.map_size, scene.map_size, scene.levels, **kw)
     g.setUpdateFactorFree(free)
     g.setUpdateFactorOccupied(occ)
@@ -681,6 +692,41 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
         for q in range(3):
             pq, cq = g.matchData(sc.query_init[q], pts)
             assert np.array_equal(bits(pq), bits(ref[q][0])) and np.array_equal(bits(cq), bits(ref[q][1])), (rep, q)
+
+
+def test_default_parity_mode_is_exact_for_batches_and_fast_for_single_scans(capi, oracle_mod, pyramid_scene, kind, monkeypatch):
+    """HSM_PARITY_AUTO (what a context starts in): every batched match runs in the reference's summation order -- poses and
+    covariances bit-identical to the reference, whatever the map size --, single scans keep the fast tree (within 1e-4);
+    hsm_last_launch_parity says which one ran; HSM_PARITY accepts its four words only"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    monkeypatch.delenv("HSM_PARITY")
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    assert g.parity() == capi.PARITY_AUTO
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    pb, cb = g.match_batch(sc.query_init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["parity"] == "auto" and cfg["parity_effective"] == "exact", cfg
+    for q in range(len(sc.query_scans)):
+        po, co = o.match(sc.query_init[q], sc.query_scans[q])
+        assert np.array_equal(bits(pb[q]), bits(po)) and np.array_equal(bits(cb[q]), bits(co)), q
+    p1, _ = g.match_batch(sc.query_init[:1], *synth.pack_scans(sc.query_scans[:1]))  # a batch of one is a batch
+    assert g.last_launch_config()["parity_effective"] == "exact" and np.array_equal(bits(p1[0]), bits(pb[0]))
+    ps, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
+    assert g.last_launch_config()["parity_effective"] == "fast"
+    assert_pose_close(ps, pb[0], "single scan (fast tree) vs the batch's exact result")
+    g.close()
+    for word, ok in (("exact", True), ("fast", True), ("relaxed", True), ("auto", True), ("Exact", False), ("1", False)):
+        monkeypatch.setenv("HSM_PARITY", word)
+        if ok:
+            capi.MapRepMultiMap(sc.resolution, 64, 64, 1).close()
+        else:
+            with pytest.raises(capi.HsmError):
+                capi.MapRepMultiMap(sc.resolution, 64, 64, 1)
 
 
 def test_dense_matcher_exchange_forms_agree(capi, pyramid_scene, monkeypatch):
