@@ -33,6 +33,9 @@ FAMILIES = {
     "hall_100x80_dotted_walls": dict(room=(100.0, 80.0), boxes=12, res=0.05, size=2048, start=(0.5, 0.5), rmax=60.0, sigma=0.01, frac=0.55),
     "corridor_80x3": dict(room=(80.0, 3.0), boxes=0, res=0.05, size=2048, start=(0.5, 0.5), rmax=30.0, sigma=0.01, frac=0.6),
     "third_of_beams_out_of_map": dict(room=(40.0, 30.0), boxes=12, res=0.05, size=2048, start=(0.115, 0.5), rmax=30.0, sigma=0.01, frac=0.55),
+    # the map's origin pushed to the left so that ~30 % of all end points fall outside level 0 (and the robot itself is off the
+    # map on a third of the loop); "third_of_beams_out_of_map" above averages 20 % over the whole loop
+    "30pct_beams_out_of_map": dict(room=(40.0, 30.0), boxes=12, res=0.05, size=2048, start=(0.06, 0.5), rmax=30.0, sigma=0.01, frac=0.55),
     "coarse_cells_res02_noisy": dict(room=(160.0, 120.0), boxes=12, res=0.2, size=1024, start=(0.5, 0.5), rmax=120.0, sigma=0.05, frac=0.55),
 }
 
@@ -108,11 +111,12 @@ def main():
             m.setUpdateFactorOccupied(0.9)
             m.build_map(build_poses, build_scans)
             # share of the end points that the level-0 map does not contain (they sample zeros / are skipped by the update)
-            mp = np.stack([o.map_coords_pose(0, p) for p in truth[:64]])
+            probe = np.linspace(0, B - 1, min(B, 256)).astype(int)  # spread over the whole loop
+            mp = np.stack([o.map_coords_pose(0, truth[q]) for q in probe])
             out_frac = []
-            for q in range(64):
+            for q in range(len(probe)):
                 c, s_ = math.cos(mp[q, 2]), math.sin(mp[q, 2])
-                sc = scans[q]
+                sc = scans[probe[q]]
                 ex, ey = mp[q, 0] + c * sc[:, 0] - s_ * sc[:, 1], mp[q, 1] + s_ * sc[:, 0] + c * sc[:, 1]
                 out_frac.append(float(((ex < 0) | (ex > size - 2) | (ey < 0) | (ey > size - 2)).mean()))
 
