@@ -64,10 +64,13 @@ typedef struct hsm_opts {
  *   RELAXED  FAST with the multiply-add pairs of the per-beam arithmetic contracted to fused operations (32 instead of
  *          51 fp32 operations per beam) in the batched throughput kernel; everything else runs as FAST.  Per-beam terms
  *          are no longer bit-exact; the bar is north_star's 1e-4 m / 1e-4 rad on the pose, measured at full size.
- *   AUTO   (default) FAST, except that BATCHED matches on maps of more than 2^23 cells run EXACT: that is where the fast
- *          tree was measured to miss the 1e-4 m bar (0.7 % of the scans of the 4096^2 / 160 m-room workload; none of
- *          36 864 on the 2048^2 workloads).  Single scans stay FAST.
- * env HSM_PARITY=fast|exact|relaxed|auto selects a mode at hsm_create, hsm_set_parity switches at run time. */
+ *   AUTO   (default) every BATCHED match (hsm_match_batch*, hsm_group_match_batch*) runs EXACT, single scans run FAST.  Round 4's
+ *          scene sweep (profiles/r04/parity_scene_sweep.jsonl: six scene families on maps of up to 2^23 cells, three start /
+ *          level set-ups, 4096 scans each) finds the fast tree beyond 1e-4 m of the reference on some scans of every family
+ *          wherever the reference's own iteration has not settled; single scans were within on 100 % in five families and
+ *          over a 5 000-scan node loop (the exact single-scan form costs 4x the latency).  hsm_last_launch_parity() tells.
+ * env HSM_PARITY=fast|exact|relaxed|auto selects a mode at hsm_create (any other word: hsm_create fails), hsm_set_parity
+ * switches at run time. */
 enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2, HSM_PARITY_AUTO = 3 };
 
 /* ---- construction ---------------------------------------------------------
