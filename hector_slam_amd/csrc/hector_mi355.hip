@@ -2124,11 +2124,12 @@ int hsm_group_set_gather(hsm_group* g, int mode) {
     return fail(HSM_ERR_INVALID, "hsm_group_set_gather: unknown mode");
   std::lock_guard<std::mutex> glk(g->mu);
   g->gather_pref = mode;
-  if (mode == HSM_GATHER_PEER || (mode == HSM_GATHER_RCCL && g->gather_mode == HSM_GATHER_PEER) ||
-      (mode == HSM_GATHER_AUTO && g->comms.empty()))
-    g->gather_mode = mode == HSM_GATHER_PEER ? HSM_GATHER_PEER : HSM_GATHER_AUTO;  // (communicators, once made, are kept)
-  else if (!g->comms.empty())
-    g->gather_mode = HSM_GATHER_RCCL;
+  if (mode == HSM_GATHER_PEER) {
+    g->gather_mode = HSM_GATHER_PEER;
+    return HSM_OK;
+  }
+  // AUTO / RCCL: decide again (communicators, once made, are kept and reused)
+  g->gather_mode = g->comms.empty() ? HSM_GATHER_AUTO : HSM_GATHER_RCCL;
   return mode == HSM_GATHER_RCCL ? group_ensure_gather(g) : HSM_OK;
 }
 

@@ -197,3 +197,48 @@ def test_two_rank_replica_broadcast_rejects_an_oversize_scan_on_every_rank():
         assert p.exitcode == 0
     for rank, ok1, raised, pose, shape in res:
         assert ok1 and raised and pose == [2.0, 2.0, 2.0] and shape == (3, 2), (rank, ok1, raised, pose, shape)
+
+
+def _worker_group_child(rank, world, port, q):
+    """bench.py's hand-off around the `--group N` child of rank 0: the other ranks wait on the rendezvous store (NOT on a
+    device barrier) until rank 0's child has finished; nothing may hang, whatever the child does"""
+    sys.path.insert(0, ROOT)
+    import time
+    import types
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def fake_child(extra_args, timeout_s=300, env=None):
+            calls.append((list(extra_args), dict(env or {})))
+            time.sleep(1.0)
+            return {"value": 1.0, "args": list(extra_args)}
+
+        bench.run_child = fake_child
+        os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+        args = types.SimpleNamespace(steps=20, batch=4096)
+        t0 = time.time()
+        rec = bench.group_child_from_rank0(args, world, dist)
+        dt = time.time() - t0
+        ok = (rec is not None and rec["value"] == 1.0 and "--group" in rec["args"] and str(world) in rec["args"]) if rank == 0 else rec is None
+        if rank == 0:  # the child must not inherit the torchrun identity of rank 0
+            ok = ok and all(k not in calls[0][1] for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"))
+        q.put((rank, bool(ok), dt))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_group_child_handoff_does_not_hang():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_group_child, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True], res
+    assert all(0.5 < r[2] < 30 for r in res), res  # rank 1 waited for the child, nobody waited for a timeout
