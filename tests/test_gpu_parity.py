@@ -7,7 +7,8 @@ Bars (BASELINE.json north_star / SURVEY.md 8(d)):
   * sinf / cosf / expf on the device: BIT-EXACT against the host libm the reference links (glibc's
     algorithms restated in csrc/libm_exact.h)
   * per-beam terms M, dM/dx, dM/dy, rotDeriv and the probability texels: BIT-EXACT
-  * pose estimate, default (fast) summation: |dx|, |dy| <= 1e-4 m, |dtheta| <= 1e-4 rad  (POSE_TOL below);
+  * pose estimate, fast (tree) summation -- what single scans run by default and batches on request: |dx|, |dy| <= 1e-4 m,
+    |dtheta| <= 1e-4 rad  (POSE_TOL below);
     HSM_PARITY_EXACT: bit-identical (tests/test_gpu_exact_parity.py)
 
 Every test that takes an oracle runs twice where oracle/_ref/libhector_ref.so is present: against the plain-C++
