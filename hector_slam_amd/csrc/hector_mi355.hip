@@ -171,6 +171,7 @@ struct hsm_ctx {
   size_t d_cells_cap = 0;
   int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
   int exact_batch_form = 2;      // env HSM_EXACT_BATCH: 0 = the one-wavefront-per-scan exact form for batches, too; 1 = producer / chain workgroups on maps <= 2^23 cells only (the rule until the <8,2> shape); 2 = on every map
+  int xcd_chunk_exact = 0;       // env HSM_XCD_CHUNK_EXACT: the same for the exact-order texel-cache form (0 = contiguous eighths, its default)
   int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
   unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
   bool cached_wps2 = false;      // env HSM_CACHED_WPS2=1: with waves_per_scan = 2, batches use the two-wave texel-cache form (experimental)
@@ -362,7 +363,12 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
 template <int NS, int BPL, int BPC = BPL>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   const int grid = (P.batch + NS - 1) / NS, block = 64 * NS;
-  if (P.xcd_chunk > 0) P.xcd_chunk = P.xcd_chunk * 4 / NS > 0 ? P.xcd_chunk * 4 / NS : 1;  // chunks of the same number of scans
+  // workgroup -> XCD mapping: this form runs best with one contiguous eighth of the batch per XCD on every map size (2048^2
+  // headline: 57.5 us against 58.3 with the fast form's chunks of 16 workgroups dealt in turn; chunks of 8 / 32: 58.4;
+  // profiles/r04/exact_kernel_param_sweep.txt) -- its rounds are paced by barriers and chain jobs, not by how long a scan's
+  // gathers take, so the load balancing the chunks buy the fast form is not needed and the compacter L2 footprint wins.
+  // env HSM_XCD_CHUNK_EXACT=n restores chunks of n workgroups.
+  P.xcd_chunk = h->xcd_chunk_exact > 0 ? (h->xcd_chunk_exact * 4 / NS > 0 ? h->xcd_chunk_exact * 4 / NS : 1) : 0;
   hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
   h->last_cfg[0] = h->layout;
@@ -919,6 +925,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
   if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
+  if (const char* env = getenv("HSM_XCD_CHUNK_EXACT")) h->xcd_chunk_exact = atoi(env) > 0 ? atoi(env) : 0;
 
 #define CREATE_TRY(expr)                                   \
   do {                                                     \
