@@ -171,6 +171,14 @@ def cpu_baseline(build_poses, build_scans, init, pts, offs, gpu_pose, levels: in
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
+    # cold after an update: onMapUpdated() bumps the generation of the reference's probability cache
+    # (GridMapCacheArray.h:69-72), so the first matchData after every map update pays exp() + a divide per touched cell
+    n_cold = min(B, 256) if budget_s > 0 else 0
+    tc0 = time.perf_counter()
+    for q in range(n_cold):
+        o.on_map_updated()
+        o.match(init[q], pts[offs[q]:offs[q + 1]])
+    dt_cold = max(time.perf_counter() - tc0, 1e-9)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -192,6 +200,8 @@ def cpu_baseline(build_poses, build_scans, init, pts, offs, gpu_pose, levels: in
                   f"{B} scans + map, warm probability cache, single thread; "
                   + ("unmodified reference headers via private Eigen stand-in" if kind == "hr"
                      else "plain-C++ restatement of the reference"),
+        "cold_after_update": {"value": n_cold * its_per_match / dt_cold, "unit": "GN it/s",
+                              "sample": f"{n_cold} matchData calls, each right after onMapUpdated() (probability cache invalidated), {dt_cold:.2f} s"},
         "host_cpu": model, "host_logical_cores": os.cpu_count(), **par,
     }
 
