@@ -582,6 +582,12 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             if gatherer:
                 gatherer.launch()
 
+        if args.prewarm_ms > 0 and args.leg != "pmc":  # engine clock settling (see run() of the headline path)
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         if nranks > 1:
