@@ -3,7 +3,9 @@
 ``Oracle("ho")`` drives oracle/build/libhector_oracle.so (plain-C++ restatement),
 ``Oracle("hr")`` drives oracle/_ref/libhector_ref.so (the unmodified reference
 headers compiled through the private Eigen/tf stand-in).  Same API, see
-oracle/oracle_api.h.  Only tests/, __graft_entry__.smoke() and bench.py's
+oracle/oracle_api.h.  ``NodeRef`` drives oracle/_ref/libhector_node_ref.so: the reference's ROS
+node source (hector_mapping/src/HectorMappingRos.cpp) compiled unmodified through
+oracle/stubs_node/ -- the checker of the node-side rows.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module.
 """
 from __future__ import annotations
@@ -17,7 +19,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SAN = os.environ.get("HSM_ORACLE_SAN") == "1"  # tools/sanitize_cpu.sh: the ASan/UBSan builds (make -C oracle SAN=1)
 _LIBS = {"ho": os.path.join(_HERE, "build", *(["san"] if _SAN else []), "libhector_oracle.so"),
-         "hr": os.path.join(_HERE, "_ref", *(["san"] if _SAN else []), "libhector_ref.so")}
+         "hr": os.path.join(_HERE, "_ref", *(["san"] if _SAN else []), "libhector_ref.so"),
+         # the UNMODIFIED ROS node source (hector_mapping/src/HectorMappingRos.cpp) through oracle/stubs_node/: rows f1 / f2
+         "node": os.path.join(_HERE, "_ref", "libhector_node_ref.so"),
+         # ... and the same unmodified node source on the drop-in facade + libhector_mi355.so (needs a GPU to construct)
+         "node_mi355": os.path.join(_HERE, "_ref", "libhector_node_mi355.so")}
 _loaded: dict = {}
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -150,6 +156,107 @@ def libm_expf(x, kind="ho"):
     e, p = np.empty_like(x), np.empty_like(x)
     _load(kind)["libm_expf"](x.size, x, e, p)
     return e, p
+
+
+class NodeRef:
+    """The reference's ROS node source compiled unmodified (oracle/node_shim.cpp): its own rosLaserScanToDataContainer,
+    rosPointCloudToDataContainer, the projectLaser + conversion step of scanCallback, publishMap and setServiceGetMapData.
+    The node reads its gates from parameters: laser_min_dist / laser_max_dist (squared in double, narrowed to float, as
+    HectorMappingRos.cpp:95-100 does), laser_z_min_value / laser_z_max_value."""
+
+    def __init__(self, laser_min_dist=0.4, laser_max_dist=30.0, laser_z_min=-1.0, laser_z_max=1.0, map_size=0, levels=1,
+                 resolution=0.05, update_dist_thresh=0.4, update_angle_thresh=0.9, factor_free=0.4, factor_occ=0.9, kind="node"):
+        """map_size = 0: a handle for the container conversions / publish_map only; map_size > 0: a whole node whose
+        scan_callback runs rosLaserScanToDataContainer + HectorSlamProcessor::update on its own map.  kind "node" = on the
+        reference's CPU map representation, "node_mi355" = the same node source on the drop-in facade (GPU)."""
+        lib = C.CDLL(_LIBS[kind])
+        vp, i, f, d = C.c_void_p, C.c_int, C.c_float, C.c_double
+        f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+        self.map_size = map_size
+        sig = {"hn_create": (vp, [d, d, d, d, i, i, d, d, d, d, d]), "hn_destroy": (None, [vp]),
+               "hn_scan_callback": (None, [vp, _f32p, i, f, f, f, f, _f32p, _f32p]),
+               "hn_node_map": (i, [vp, i8p, _f32p]),
+               "hn_laser_scan_to_container": (i, [vp, _f32p, i, f, f, f, f, f, _f32p, _f32p]),
+               "hn_point_cloud_to_container": (i, [vp, _f32p, i, f64p, f, _f32p, _f32p]),
+               "hn_project_and_convert": (i, [vp, _f32p, i, f, f, f, f, d, f64p, f, _f32p, _f32p, _f32p, C.POINTER(i)]),
+               "hn_publish_map": (None, [vp, f, i, i, f, f, _f32p, i8p, f64p])}
+        self.f = {}
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+            self.f[name] = fn
+        self.h = self.f["hn_create"](laser_min_dist, laser_max_dist, laser_z_min, laser_z_max, map_size, levels, resolution,
+                                     update_dist_thresh, update_angle_thresh, factor_free, factor_occ)
+        # what the node makes of its two distance parameters (HectorMappingRos.cpp:96,99): the gates the other checkers take
+        self.sqr_min = float(np.float32(laser_min_dist * laser_min_dist))
+        self.sqr_max = float(np.float32(laser_max_dist * laser_max_dist))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.f["hn_destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scan_callback(self, ranges, angle_min, angle_increment, range_min, range_max):
+        """HectorMappingRos::scanCallback on one LaserScan -> (pose [3], covariance [9] column major) of the processor"""
+        r = np.ascontiguousarray(ranges, np.float32).reshape(-1)
+        pose, cov = np.empty(3, np.float32), np.empty(9, np.float32)
+        self.f["hn_scan_callback"](self.h, r if r.size else np.zeros(1, np.float32), r.size, angle_min, angle_increment, range_min,
+                                   range_max, pose, cov)
+        return pose, cov
+
+    def node_map(self):
+        """publishMap of the node's own level-0 map -> (int8 cells [S,S], log-odds [S,S], update index)"""
+        S = self.map_size
+        cells, lo = np.empty((S, S), np.int8), np.empty((S, S), np.float32)
+        ui = self.f["hn_node_map"](self.h, cells.reshape(-1), lo.reshape(-1))
+        return cells, lo, ui
+
+    def laser_scan_to_container(self, ranges, angle_min, angle_increment, range_min, range_max, scale_to_map):
+        r = np.ascontiguousarray(ranges, np.float32).reshape(-1)
+        out = np.empty(2 * max(r.size, 1), np.float32)
+        origo = np.empty(2, np.float32)
+        m = self.f["hn_laser_scan_to_container"](self.h, r if r.size else np.zeros(1, np.float32), r.size, angle_min,
+                                                 angle_increment, range_min, range_max, scale_to_map, out, origo)
+        return out[:2 * m].reshape(m, 2).copy(), origo
+
+    def point_cloud_to_container(self, pts_xyz, tf_rows, scale_to_map):
+        p = np.ascontiguousarray(pts_xyz, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(tf_rows, np.float64).reshape(12)
+        out = np.empty(2 * max(p.shape[0], 1), np.float32)
+        origo = np.empty(2, np.float32)
+        m = self.f["hn_point_cloud_to_container"](self.h, p.reshape(-1) if p.size else np.zeros(3, np.float32), p.shape[0], T,
+                                                  scale_to_map, out, origo)
+        return out[:2 * m].reshape(m, 2).copy(), origo
+
+    def project_and_convert(self, ranges, angle_min, angle_increment, range_min, range_max, range_cutoff, tf_rows, scale_to_map):
+        """scanCallback's default ingestion: projectLaser (laser_geometry: restated stand-in) + rosPointCloudToDataContainer
+        -> (endpoints [m,2], origo [2], projected cloud [k,3])"""
+        r = np.ascontiguousarray(ranges, np.float32).reshape(-1)
+        T = np.ascontiguousarray(tf_rows, np.float64).reshape(12)
+        out = np.empty(2 * max(r.size, 1), np.float32)
+        cloud = np.empty(3 * max(r.size, 1), np.float32)
+        origo = np.empty(2, np.float32)
+        k = C.c_int()
+        m = self.f["hn_project_and_convert"](self.h, r if r.size else np.zeros(1, np.float32), r.size, angle_min, angle_increment,
+                                             range_min, range_max, range_cutoff, T, scale_to_map, out, origo, cloud, C.byref(k))
+        return out[:2 * m].reshape(m, 2).copy(), origo, cloud[:3 * k.value].reshape(k.value, 3).copy()
+
+    def publish_map(self, resolution, logodds, start=(0.5, 0.5)):
+        """publishMap's cells + setServiceGetMapData's metadata for a level-0 grid with these log-odds
+        -> (int8 [sy,sx], (origin_x, origin_y, resolution, width, height))"""
+        lo = np.ascontiguousarray(logodds, np.float32)
+        sy, sx = lo.shape
+        out = np.empty((sy, sx), np.int8)
+        meta = np.empty(5, np.float64)
+        self.f["hn_publish_map"](self.h, resolution, sx, sy, start[0], start[1], lo.reshape(-1), out.reshape(-1), meta)
+        return out, tuple(float(v) for v in meta)
 
 
 class Oracle:

@@ -1,0 +1,12 @@
+// TEST INFRASTRUCTURE ONLY -- private stand-in (oracle/stubs_node/) so that the UNMODIFIED node source
+// /root/reference/hector_mapping/src/HectorMappingRos.cpp compiles without ROS / tf / boost (none is in this image).
+// Nothing here is part of the product; see oracle/node_shim.cpp.
+#pragma once
+#include "geometry_msgs/Pose.h"
+#include "std_msgs/Header.h"
+namespace geometry_msgs {
+struct PoseStamped {
+  std_msgs::Header header;
+  Pose pose;
+};
+}  // namespace geometry_msgs

@@ -1,0 +1,9 @@
+// TEST INFRASTRUCTURE ONLY -- private stand-in (oracle/stubs_node/) so that the UNMODIFIED node source
+// /root/reference/hector_mapping/src/HectorMappingRos.cpp compiles without ROS / tf / boost (none is in this image).
+// Nothing here is part of the product; see oracle/node_shim.cpp.
+#pragma once
+namespace geometry_msgs {
+struct Quaternion {  // float64 x y z w (the message constructor zero-initialises)
+  double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+};
+}  // namespace geometry_msgs

@@ -1,0 +1,14 @@
+// TEST INFRASTRUCTURE ONLY -- private stand-in (oracle/stubs_node/) so that the UNMODIFIED node source
+// /root/reference/hector_mapping/src/HectorMappingRos.cpp compiles without ROS / tf / boost (none is in this image).
+// Nothing here is part of the product; see oracle/node_shim.cpp.
+#pragma once
+#include <vector>
+#include "nav_msgs/MapMetaData.h"
+#include "std_msgs/Header.h"
+namespace nav_msgs {
+struct OccupancyGrid {
+  std_msgs::Header header;
+  MapMetaData info;
+  std::vector<int8_t> data;
+};
+}  // namespace nav_msgs

@@ -1,0 +1,10 @@
+// TEST INFRASTRUCTURE ONLY -- private stand-in (oracle/stubs_node/) so that the UNMODIFIED node source
+// /root/reference/hector_mapping/src/HectorMappingRos.cpp compiles without ROS / tf / boost (none is in this image).
+// Nothing here is part of the product; see oracle/node_shim.cpp.
+#pragma once
+#include <string>
+namespace std_msgs {
+struct String {
+  std::string data;
+};
+}  // namespace std_msgs

@@ -1,0 +1,11 @@
+// TEST INFRASTRUCTURE ONLY -- private stand-in (oracle/stubs_node/) so that the UNMODIFIED node source
+// /root/reference/hector_mapping/src/HectorMappingRos.cpp compiles without ROS / tf / boost (none is in this image).
+// Nothing here is part of the product; see oracle/node_shim.cpp.
+#pragma once
+#include "tf/transform_datatypes.h"
+namespace tf {
+class TransformBroadcaster {
+ public:
+  void sendTransform(const StampedTransform&) {}
+};
+}  // namespace tf

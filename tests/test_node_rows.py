@@ -1,7 +1,9 @@
 """Rows next to the hot path: LaserScan ingestion (rosLaserScanToDataContainer,
 hector_mapping/src/HectorMappingRos.cpp:483-507), PointCloud ingestion (rosPointCloudToDataContainer, :509-542,
 the node's default with use_tf_scan_transformation) and occupancy export (publishMap's cell loop, :449-468).
-Integer / byte / index work: BIT-EXACT against the oracle."""
+Integer / byte / index work: BIT-EXACT against the oracle -- and, since round 4, against the reference's ROS node source
+itself: HectorMappingRos.cpp compiled UNMODIFIED through roscpp / tf / boost stand-ins (oracle/node_shim.cpp,
+oracle/_ref/libhector_node_ref.so, `pyoracle.NodeRef`), which pins the restatement of these rows."""
 import numpy as np
 import pytest
 
@@ -113,6 +115,92 @@ def test_oracle_point_cloud_restatement_is_pinned(oracle_mod):
         assert np.array_equal(bits(o.project_laser(r, a0, inc, 0.1, 30.0, -1.0)), bits(cloud))
 
 
+NODE_GATES = [(0.4, 30.0, -1.0, 1.0), (0.25, 12.5, -0.3, 0.7)]  # laser_min_dist, laser_max_dist, laser_z_min / max_value
+SCAN_GEOMS = [(-2.35619449, 0.00436332, 1081), (-1.5707964, 0.017453292, 181), (-3.1415927, 0.00038349519, 16384), (0.3, -0.01, 700)]
+
+
+def test_node_source_pins_the_restatement_of_the_node_rows(oracle_mod, small_scene):
+    """CPU: the reference's own HectorMappingRos member functions (compiled from the unmodified .cpp) against the restatement
+    the other tests use -- LaserScan ingestion, PointCloud ingestion for two gate settings, scanCallback's projectLaser +
+    conversion, publishMap's cells and setServiceGetMapData's metadata: bit for bit, NaN / inf / gate values included"""
+    if not oracle_mod.available("node"):
+        pytest.skip("oracle/_ref/libhector_node_ref.so not built (needs /root/reference)")
+    ho = oracle_mod.Oracle("ho", 0.05, 64, 64, 1)
+    rng = np.random.default_rng(21)
+    for lmin, lmax, zmin, zmax in NODE_GATES:
+        node = oracle_mod.NodeRef(lmin, lmax, zmin, zmax)
+        assert node.sqr_min == float(np.float32(lmin * lmin)) and node.sqr_max == float(np.float32(lmax * lmax))
+        for a0, inc, n in SCAN_GEOMS + [(0.0, 0.01, 0), (0.0, 0.01, 1)]:
+            r = synthetic_ranges(rng, n) if n else np.zeros(0, np.float32)
+            for rmin, rmax, scale in ((0.4, 30.0, 20.0), (0.1, 60.0, 40.0)):
+                got, origo = node.laser_scan_to_container(r, a0, inc, rmin, rmax, scale)
+                want = ho.laser_scan_to_container(r, a0, inc, rmin, rmax, scale)
+                assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (n, rmin)
+                assert not origo.any()  # dataContainer.setOrigo(Eigen::Vector2f::Zero()), :491
+        for n in (0, 1, 10, 1081, 5000):
+            c, T = synthetic_cloud(rng, n), rigid_rows(rng)
+            got, go = node.point_cloud_to_container(c, T, 20.0)
+            want, wo = ho.point_cloud_to_container(c, T, node.sqr_min, node.sqr_max, zmin, zmax, 20.0)
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)) and np.array_equal(bits(go), bits(wo)), n
+        for a0, inc, n in SCAN_GEOMS:
+            for cutoff in (30.0, -1.0, 12.5):
+                r, T = synthetic_ranges(rng, n), rigid_rows(rng)
+                got, go, cloud = node.project_and_convert(r, a0, inc, 0.1, 30.0, cutoff, T, 20.0)
+                wc = ho.project_laser(r, a0, inc, 0.1, 30.0, cutoff)
+                want, wo = ho.point_cloud_to_container(wc, T, node.sqr_min, node.sqr_max, zmin, zmax, 20.0)
+                assert np.array_equal(bits(cloud), bits(wc))
+                assert got.shape == want.shape and np.array_equal(bits(got), bits(want)) and np.array_equal(bits(go), bits(wo))
+        node.close()
+    # publishMap / setServiceGetMapData on a real map
+    sc = small_scene
+    o = make_oracle(oracle_mod, "ho", sc)
+    lo, _ = o.download_level(0)
+    node = oracle_mod.NodeRef()
+    cells, meta = node.publish_map(sc.resolution, lo)
+    assert np.array_equal(cells, o.occupancy_grid(0)) and set(np.unique(cells)) == {-1, 0, 100}
+    w = o.world_coords_pose(0, np.zeros(3, np.float32))  # getWorldCoords(Vector2f::Zero()), then -= cellLength * 0.5f (:546-547)
+    half = np.float32(o.level_info(0)[2]) * np.float32(0.5)
+    assert np.float32(meta[0]) == np.float32(w[0]) - half and np.float32(meta[1]) == np.float32(w[1]) - half
+    assert np.float32(meta[2]) == np.float32(o.level_info(0)[2]) and meta[3:] == (sc.map_size, sc.map_size)
+
+
+def laser_scan_messages(n_scans, seed=3):
+    """raw LaserScan ranges along a loop in a 20 m x 15 m room (1081 beams), as a driver would publish them"""
+    from hector_slam_amd import synth
+    world = synth.World.make(20.0, 15.0, seed=99)
+    poses = synth.loop_trajectory(world, 4 * n_scans)[:n_scans]  # ~0.1 m between scans
+    ang = synth.beam_angles(1081)
+    rng = np.random.default_rng(seed)
+    scans = [(world.raycast(p, ang) + rng.normal(0.0, 0.01, ang.shape)).astype(np.float32) for p in poses]
+    return scans, float(ang[0]), float(np.float32(synth.SCAN_SHAPES[1081][1]))
+
+
+def test_node_scan_callback_equals_the_processor_loop(oracle_mod):
+    """CPU: HectorMappingRos::scanCallback itself (unmodified node source, no tf path) over 40 raw LaserScans == the
+    HectorSlamProcessor loop the other tests drive (container from the restated ingestion, start = last pose): every pose,
+    every covariance, the final map and its occupancy grid, bit for bit"""
+    if not (oracle_mod.available("node") and oracle_mod.available("hr")):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    scans, a0, inc = laser_scan_messages(40)
+    node = oracle_mod.NodeRef(map_size=512, levels=3, resolution=0.05, update_dist_thresh=0.05, update_angle_thresh=0.02)
+    o = oracle_mod.Oracle("hr", 0.05, 512, 512, 3)
+    o.set_update_factor_free(0.4)
+    o.set_update_factor_occupied(0.9)
+    o.proc_set_thresholds(0.05, 0.02)
+    last = np.zeros(3, np.float32)
+    for t, r in enumerate(scans):
+        pn, cn = node.scan_callback(r, a0, inc, 0.4, 30.0)
+        pts = o.laser_scan_to_container(r, a0, inc, 0.4, 30.0, o.scale_to_map())
+        o.proc_update(pts, last)
+        po, co = o.proc_last_pose()
+        assert np.array_equal(bits(pn), bits(po)) and np.array_equal(bits(cn), bits(co)), t
+        last = po
+    cells, lo, ui = node.node_map()
+    lo_o, _ = o.download_level(0)
+    assert np.array_equal(bits(lo), bits(lo_o)) and np.array_equal(cells, o.occupancy_grid(0)) and (cells == 100).sum() > 200
+    assert np.abs(last[:2]).max() > 0.5  # the robot did move through the map
+
+
 @pytest.fixture(scope="module")
 def capi():
     import torch
@@ -120,6 +208,84 @@ def capi():
     from hector_slam_amd import capi as m
     m.load_library()
     return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parity", ["auto", "exact"])
+def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, oracle_mod, monkeypatch, parity):
+    """THE drop-in: hector_mapping/src/HectorMappingRos.cpp, unmodified, compiled once against the reference's include tree and
+    once against the tree in which only slam_main/MapRepMultiMap.h is ours (+ libhector_mi355.so).  60 raw LaserScan messages
+    through scanCallback on both: default mode -- every pose within 1e-4 m / 1e-4 rad; HSM_PARITY=exact -- every pose, every
+    covariance, the published occupancy grid and the log-odds of the node's map bit-identical"""
+    if not (oracle_mod.available("node") and oracle_mod.available("node_mi355")):
+        pytest.skip("oracle/_ref/libhector_node_{ref,mi355}.so not prebuilt (run __graft_entry__.build() where /root/reference exists)")
+    monkeypatch.setenv("HSM_PARITY", parity)
+    scans, a0, inc = laser_scan_messages(60)
+    kw = dict(map_size=512, levels=3, resolution=0.05, update_dist_thresh=0.05, update_angle_thresh=0.02)
+    ref = oracle_mod.NodeRef(kind="node", **kw)
+    gpu = oracle_mod.NodeRef(kind="node_mi355", **kw)
+    worst = 0.0
+    for t, r in enumerate(scans):
+        pr, cr = ref.scan_callback(r, a0, inc, 0.4, 30.0)
+        pg, cg = gpu.scan_callback(r, a0, inc, 0.4, 30.0)
+        d = np.abs(pr.astype(np.float64) - pg)
+        worst = max(worst, float(d[:2].max()))
+        assert d[0] <= 1e-4 and d[1] <= 1e-4 and d[2] <= 1e-4, (parity, t, pr, pg)
+        if parity == "exact":
+            assert np.array_equal(bits(pr), bits(pg)) and np.array_equal(bits(cr), bits(cg)), t
+    cells_r, lo_r, ui_r = ref.node_map()
+    cells_g, lo_g, ui_g = gpu.node_map()
+    assert ui_r == ui_g and (cells_r == 100).sum() > 200
+    if parity == "exact":
+        assert np.array_equal(cells_r, cells_g) and np.array_equal(bits(lo_r), bits(lo_g))
+    else:
+        assert (cells_r != cells_g).sum() <= 0.002 * (cells_r != -1).sum()
+    print(f"node source on the facade, HSM_PARITY={parity}: worst pose deviation {worst:.2e} m over {len(scans)} scans")
+    ref.close()
+    gpu.close()
+
+
+@pytest.mark.gpu
+def test_gpu_node_rows_equal_the_reference_node_source(capi, oracle_mod, small_scene):
+    """rows f1 / f2 against the reference's ROS node source itself (oracle/node_shim.cpp): the device's LaserScan ingestion,
+    PointCloud ingestion, fused projectLaser + ingestion, occupancy export and map metadata equal what the unmodified
+    HectorMappingRos member functions produce, bit for bit"""
+    if not oracle_mod.available("node"):
+        pytest.skip("oracle/_ref/libhector_node_ref.so not prebuilt (run __graft_entry__.build() where /root/reference exists)")
+    g = capi.MapRepMultiMap(0.05, 256, 256, 2)
+    s = g.getScaleToMap()
+    rng = np.random.default_rng(22)
+    for lmin, lmax, zmin, zmax in NODE_GATES:
+        node = oracle_mod.NodeRef(lmin, lmax, zmin, zmax)
+        gates = (np.float32(node.sqr_min), np.float32(node.sqr_max), zmin, zmax)
+        for a0, inc, n in SCAN_GEOMS:
+            r = synthetic_ranges(rng, n)
+            want, _ = node.laser_scan_to_container(r, a0, inc, 0.4, 30.0, s)
+            got = g.ingest_laser_scan(r, a0, inc, 0.4, 30.0)
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (n, "laser scan")
+            T = rigid_rows(rng)
+            for cutoff in (30.0, -1.0):
+                want, wo, _cloud = node.project_and_convert(r, a0, inc, 0.1, 30.0, cutoff, T, s)
+                got, go = g.ingest_laser_scan_tf(r, a0, inc, 0.1, 30.0, cutoff, T, *gates)
+                assert got.shape == want.shape and np.array_equal(bits(got), bits(want)) and np.array_equal(bits(go), bits(wo)), (n, cutoff)
+        for n in (1, 10, 1081, 5000):
+            c, T = synthetic_cloud(rng, n), rigid_rows(rng)
+            want, wo = node.point_cloud_to_container(c, T, s)
+            got, go = g.ingest_point_cloud(c, T, *gates)
+            assert got.shape == want.shape and np.array_equal(bits(got), bits(want)) and np.array_equal(bits(go), bits(wo)), n
+        node.close()
+    # occupancy export + metadata of a map the device built
+    sc = small_scene
+    m = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    m.setUpdateFactorFree(0.4)
+    m.setUpdateFactorOccupied(0.9)
+    m.build_map(sc.build_poses, sc.build_scans)
+    lo, _ = m.download_level(0)
+    node = oracle_mod.NodeRef()
+    cells, meta = node.publish_map(sc.resolution, lo)
+    assert np.array_equal(m.occupancy_grid(0), cells) and (cells == 100).sum() > 50
+    ox, oy, res = m.map_metadata(0)
+    assert (np.float32(ox), np.float32(oy), np.float32(res)) == (np.float32(meta[0]), np.float32(meta[1]), np.float32(meta[2]))
 
 
 @pytest.mark.gpu
