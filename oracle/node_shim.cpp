@@ -35,6 +35,21 @@ struct Node {
 
 extern "C" {
 
+static tf::StampedTransform transform_of(const double T[12]);
+
+// the one transform of the stand-in tf tree: base_link <- laser (rows [R | t]); NULL = empty tree.  Set BEFORE hn_create: a node
+// created with a transform runs scanCallback's default path (:260-327: lookupTransform, projectLaser, rosPointCloudToDataContainer,
+// update from the last pose), a node created without runs the LaserScan path (:253-259)
+void hn_set_laser_transform(const double* T) {
+  tf::StaticTree& s = tf::static_tree();
+  s.have = T != nullptr;
+  if (T) {
+    s.target = "base_link";  // p_base_frame_'s default (:82)
+    s.source = "laser";      // the frame_id hn_scan_callback stamps on its messages
+    s.t = transform_of(T);
+  }
+}
+
 // The node with the parameters its constructor reads from the parameter server (HectorMappingRos.cpp:56-107).  map_size <= 0:
 // a 64-cell single-level map (handles that only convert containers / publish given cells).  The scan path is the one without
 // the tf tree (use_tf_scan_transformation = false: rosLaserScanToDataContainer + update from the last pose, :253-259).
@@ -50,7 +65,7 @@ void* hn_create(double laser_min_dist, double laser_max_dist, double laser_z_min
   p["map_update_angle_thresh"] = update_angle_thresh;
   p["update_factor_free"] = factor_free;
   p["update_factor_occupied"] = factor_occ;
-  p["use_tf_scan_transformation"] = 0;
+  p["use_tf_scan_transformation"] = tf::static_tree().have ? 1 : 0;  // hn_set_laser_transform() before hn_create() selects the tf path
   p["laser_min_dist"] = laser_min_dist;  // -> p_sqr_laser_min_dist_ = (float)(d * d), :95-100
   p["laser_max_dist"] = laser_max_dist;
   p["laser_z_min_value"] = laser_z_min;
@@ -95,7 +110,7 @@ int hn_laser_scan_to_container(void* h, const float* ranges, int n, float angle_
   return take(c, out_xy, origo);
 }
 
-static tf::StampedTransform transform_of(const double T[12]) {  // rows [R | t] of the laser -> base transform
+tf::StampedTransform transform_of(const double T[12]) {  // rows [R | t] of the laser -> base transform
   tf::Matrix3x3 b;
   b.setValue(T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]);
   return tf::StampedTransform(tf::Transform(b, tf::Vector3(T[3], T[7], T[11])), ros::Time(), "base_link", "laser");

@@ -165,10 +165,13 @@ class NodeRef:
     HectorMappingRos.cpp:95-100 does), laser_z_min_value / laser_z_max_value."""
 
     def __init__(self, laser_min_dist=0.4, laser_max_dist=30.0, laser_z_min=-1.0, laser_z_max=1.0, map_size=0, levels=1,
-                 resolution=0.05, update_dist_thresh=0.4, update_angle_thresh=0.9, factor_free=0.4, factor_occ=0.9, kind="node"):
+                 resolution=0.05, update_dist_thresh=0.4, update_angle_thresh=0.9, factor_free=0.4, factor_occ=0.9, kind="node",
+                 laser_transform=None):
         """map_size = 0: a handle for the container conversions / publish_map only; map_size > 0: a whole node whose
         scan_callback runs rosLaserScanToDataContainer + HectorSlamProcessor::update on its own map.  kind "node" = on the
-        reference's CPU map representation, "node_mi355" = the same node source on the drop-in facade (GPU)."""
+        reference's CPU map representation, "node_mi355" = the same node source on the drop-in facade (GPU).
+        laser_transform (12 doubles [R | t], base_link <- laser): the node is created with use_tf_scan_transformation (its
+        default) and scan_callback takes the tf path: lookupTransform, projectLaser, rosPointCloudToDataContainer."""
         lib = C.CDLL(_LIBS[kind])
         vp, i, f, d = C.c_void_p, C.c_int, C.c_float, C.c_double
         f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -176,6 +179,7 @@ class NodeRef:
         self.map_size = map_size
         sig = {"hn_create": (vp, [d, d, d, d, i, i, d, d, d, d, d]), "hn_destroy": (None, [vp]),
                "hn_scan_callback": (None, [vp, _f32p, i, f, f, f, f, _f32p, _f32p]),
+               "hn_set_laser_transform": (None, [C.c_void_p]),
                "hn_node_map": (i, [vp, i8p, _f32p]),
                "hn_laser_scan_to_container": (i, [vp, _f32p, i, f, f, f, f, f, _f32p, _f32p]),
                "hn_point_cloud_to_container": (i, [vp, _f32p, i, f64p, f, _f32p, _f32p]),
@@ -186,6 +190,8 @@ class NodeRef:
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
             self.f[name] = fn
+        T = None if laser_transform is None else np.ascontiguousarray(laser_transform, np.float64).reshape(12)
+        self.f["hn_set_laser_transform"](None if T is None else T.ctypes.data)  # read by the constructor, per library
         self.h = self.f["hn_create"](laser_min_dist, laser_max_dist, laser_z_min, laser_z_max, map_size, levels, resolution,
                                      update_dist_thresh, update_angle_thresh, factor_free, factor_occ)
         # what the node makes of its two distance parameters (HectorMappingRos.cpp:96,99): the gates the other checkers take

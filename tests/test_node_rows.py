@@ -199,6 +199,23 @@ def test_node_scan_callback_equals_the_processor_loop(oracle_mod):
     lo_o, _ = o.download_level(0)
     assert np.array_equal(bits(lo), bits(lo_o)) and np.array_equal(cells, o.occupancy_grid(0)) and (cells == 100).sum() > 200
     assert np.abs(last[:2]).max() > 0.5  # the robot did move through the map
+    # the node's DEFAULT path (use_tf_scan_transformation: lookupTransform -> projectLaser -> rosPointCloudToDataContainer ->
+    # update from the last pose, :260-327) with the laser 12 cm ahead of and 30 cm above base_link
+    T = np.array([1, 0, 0, 0.12, 0, 1, 0, -0.05, 0, 0, 1, 0.3], np.float64)
+    node = oracle_mod.NodeRef(map_size=512, levels=3, resolution=0.05, update_dist_thresh=0.05, update_angle_thresh=0.02, laser_transform=T)
+    o = oracle_mod.Oracle("hr", 0.05, 512, 512, 3)
+    o.set_update_factor_free(0.4)
+    o.set_update_factor_occupied(0.9)
+    o.proc_set_thresholds(0.05, 0.02)
+    last = np.zeros(3, np.float32)
+    for t, r in enumerate(scans[:25]):
+        pn, cn = node.scan_callback(r, a0, inc, 0.4, 30.0)
+        cloud = o.project_laser(r, a0, inc, 0.4, 30.0, 30.0)  # projector_.projectLaser(scan, cloud, 30.0), :273
+        pts, origo = o.point_cloud_to_container(cloud, T, node.sqr_min, node.sqr_max, -1.0, 1.0, o.scale_to_map())
+        o.proc_update(pts, last, origo=origo)
+        po, co = o.proc_last_pose()
+        assert np.array_equal(bits(pn), bits(po)) and np.array_equal(bits(cn), bits(co)), ("tf path", t)
+        last = po
 
 
 @pytest.fixture(scope="module")
@@ -211,8 +228,9 @@ def capi():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tf_path", [False, True], ids=["laser-scan path", "tf path (node default)"])
 @pytest.mark.parametrize("parity", ["auto", "exact"])
-def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, oracle_mod, monkeypatch, parity):
+def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, oracle_mod, monkeypatch, parity, tf_path):
     """THE drop-in: hector_mapping/src/HectorMappingRos.cpp, unmodified, compiled once against the reference's include tree and
     once against the tree in which only slam_main/MapRepMultiMap.h is ours (+ libhector_mi355.so).  60 raw LaserScan messages
     through scanCallback on both: default mode -- every pose within 1e-4 m / 1e-4 rad; HSM_PARITY=exact -- every pose, every
@@ -222,6 +240,8 @@ def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, or
     monkeypatch.setenv("HSM_PARITY", parity)
     scans, a0, inc = laser_scan_messages(60)
     kw = dict(map_size=512, levels=3, resolution=0.05, update_dist_thresh=0.05, update_angle_thresh=0.02)
+    if tf_path:  # use_tf_scan_transformation, the node's default: laser 12 cm ahead of and 30 cm above base_link
+        kw["laser_transform"] = np.array([1, 0, 0, 0.12, 0, 1, 0, -0.05, 0, 0, 1, 0.3], np.float64)
     ref = oracle_mod.NodeRef(kind="node", **kw)
     gpu = oracle_mod.NodeRef(kind="node_mi355", **kw)
     worst = 0.0
