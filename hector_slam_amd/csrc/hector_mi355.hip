@@ -917,12 +917,14 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   }
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
-  if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
-  if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
   if (const char* env = getenv("HSM_DENSE_BITS")) h->dense_bits = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
+#if defined(HSM_EXPERIMENTS)  // switches of forms that only an experiment build holds
+  if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
+  if (const char* env = getenv("HSM_EXACT_SHAPE")) h->exact_shape = atoi(env);
   if (const char* env = getenv("HSM_CACHED_WPS2")) h->cached_wps2 = atoi(env) != 0;
+#endif
   if (const char* env = getenv("HSM_SPB_LARGE")) h->spb_large = atoi(env) == 8 ? 8 : 4;
   if (const char* env = getenv("HSM_XCD_CHUNK")) h->xcd_chunk = atoi(env) > 0 ? atoi(env) : 0;
   if (const char* env = getenv("HSM_XCD_CHUNK_EXACT")) h->xcd_chunk_exact = atoi(env) > 0 ? atoi(env) : 0;
@@ -1272,7 +1274,9 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     // one beam per lane.  16 k beams, matchData us for K = 16 / 24 / 32 / 64 workgroups: 79.8 / 71 / 66-70 / 64 with round 2's grid
     // barrier; 70 (24) / 67-71 (31) / 76 (48) / 63-64 (64) with the tagged exchange (profiles/r03/README.md)
     int K = (n + 255) / 256;
+#if defined(HSM_EXPERIMENTS)
     if (const char* env = getenv("HSM_COOP_K")) K = atoi(env);
+#endif
     if (K > 64) K = 64;
     if (K < 2) K = 2;
     float* partials = h->d_partials;
