@@ -474,20 +474,39 @@ __device__ __forceinline__ void beam_products(const BeamSample& b, const BeamRot
 // one round: beams base .. base+T-1 (thread tid holds beam base+tid).  `run` is meaningful in threads
 // 0..8 of the team only.  T == 64: one wavefront, whose LDS operations execute in program order -- no
 // barrier; T > 64: the team owns its workgroup and synchronises around the chain.
+// `count` = beams of this round that exist (the lanes beyond stage +-0 products, which leave a running sum unchanged bit for
+// bit, so the chain stops after the last float4 pair that holds a real beam).  The row streams through two 32-byte halves:
+// a half is requested again right after its values are consumed, so a dependent addition costs its own latency (8.5 cycles
+// on a lone wavefront, tools/ubench_chain.hip) instead of 14.4 with one 16-byte read in flight -- the chain is 1081 x 14
+// additions of a single-scan match in exact mode, ~100 of its ~135 us before.
 template <int T>
-__device__ __forceinline__ float exact_round(const float pr[9], float* __restrict__ stage, int tid, float run) {
+__device__ __forceinline__ float exact_round(const float pr[9], float* __restrict__ stage, int tid, float run, int count = T) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) stage[t * (T + kExactPad) + tid] = pr[t];
   if (T > 64) __syncthreads();
   if (tid < 9) {
-    const float* row = stage + tid * (T + kExactPad);
-#pragma unroll 4
-    for (int j = 0; j < T; j += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(row + j);
-      run += v.x;
-      run += v.y;
-      run += v.z;
-      run += v.w;
+    const f4v* row = reinterpret_cast<const f4v*>(stage + tid * (T + kExactPad));
+    // 16 beams per iteration, branch-free (loads behind a branch make the compiler wait for all of them): the last
+    // iteration's read-ahead is clamped into the row, beams between `count` and the next multiple of 16 add their +-0
+    const int nq = ((count + 15) >> 4) << 2;  // float4s, a multiple of 4, <= T / 4
+    f4v a0 = row[0], a1 = row[1], b0 = row[2], b1 = row[3];  // two 32-byte halves in flight
+    // (the additions as inline asm: left to itself the compiler keeps the running sum in the registers of the half it is
+    // consuming, which postpones that half's refill to the end of the iteration -- one exposed LDS round trip per 16 beams)
+    auto add8 = [&](const f4v& u, const f4v& v) {
+      asm volatile(
+          "v_add_f32 %0, %1, %0\n\tv_add_f32 %0, %2, %0\n\tv_add_f32 %0, %3, %0\n\tv_add_f32 %0, %4, %0\n\t"
+          "v_add_f32 %0, %5, %0\n\tv_add_f32 %0, %6, %0\n\tv_add_f32 %0, %7, %0\n\tv_add_f32 %0, %8, %0"
+          : "+v"(run)
+          : "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)
+          : "memory");
+    };
+#pragma unroll 2
+    for (int q = 0; q < nq; q += 4) {
+      add8(a0, a1);
+      const int qa = min(q + 4, T / 4 - 4);  // refilled right behind its last use: eight additions to arrive in
+      a0 = row[qa], a1 = row[qa + 1];
+      add8(b0, b1);
+      b0 = row[qa + 2], b1 = row[qa + 3];
     }
   }
   if (T > 64) __syncthreads();
@@ -822,14 +841,30 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       } else if (EXACT) {
         float run = 0.0f;
         float* st = stage + team * 9 * (T + kExactPad);
-        for (int base = 0; base < n; base += T) {  // team-uniform trip count
-          const int i = base + tid_in_team;
-          const float2 p = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products (see above)
-          BeamRot r;
-          const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x * ps, p.y * ps}, r);
-          float pr[9];
-          beam_products(b, r, pr);
-          run = exact_round<T>(pr, st, tid_in_team, run);
+        // Rounds in groups of kXGroup: the endpoints of the whole group are requested together, then its texels, then the
+        // rounds are summed one after the other -- two memory round trips per group instead of two per round (a 1081-beam
+        // scan on four wavefronts is ONE group per GN step; the dependent loads were ~40 % of the exact single-scan match).
+        constexpr int kXGroup = 5;
+        for (int base0 = 0; base0 < n; base0 += kXGroup * T) {  // team-uniform trip count
+          float2 q[kXGroup];
+#pragma unroll
+          for (int g = 0; g < kXGroup; ++g) {
+            const int i = base0 + g * T + tid_in_team;
+            q[g] = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products (see above)
+          }
+          BeamSample b[kXGroup];
+          BeamRot r[kXGroup];
+#pragma unroll
+          for (int g = 0; g < kXGroup; ++g) b[g] = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{q[g].x * ps, q[g].y * ps}, r[g]);
+#pragma unroll
+          for (int g = 0; g < kXGroup; ++g) {
+            const int base = base0 + g * T;
+            if (base < n) {  // team-uniform
+              float pr[9];
+              beam_products(b[g], r[g], pr);
+              run = exact_round<T>(pr, st, tid_in_team, run, min(T, n - base));
+            }
+          }
         }
         float t[9];
         if (WPS == 1) {
@@ -1720,7 +1755,7 @@ __global__ void __launch_bounds__(1024) gn_eval_kernel(const LevelView L, const 
       const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{p.x, p.y}, r);
       float pr[9];
       beam_products(b, r, pr);
-      run = exact_round<1024>(pr, stage, (int)threadIdx.x, run);
+      run = exact_round<1024>(pr, stage, (int)threadIdx.x, run, min(1024, n - base));
     }
     float* const redf = &red[0][0][0];
     if (threadIdx.x < 9) redf[threadIdx.x] = run;
