@@ -500,7 +500,6 @@ __device__ __forceinline__ float exact_round(const float pr[9], float* __restric
           : "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)
           : "memory");
     };
-#pragma unroll 2
     for (int q = 0; q < nq; q += 4) {
       add8(a0, a1);
       const int qa = min(q + 4, T / 4 - 4);  // refilled right behind its last use: eight additions to arrive in
