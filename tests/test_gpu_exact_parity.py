@@ -81,7 +81,8 @@ def test_single_scan_match_bit_identical_for_every_team_width(capi, oracle_mod, 
         assert same(pg, po) and same(cg, co), (q, pg, po)
     full = sc.query_scans[2]
     # beam counts around every boundary of the chain: 16 beams per chain iteration, rounds of 64 x team width, groups of five rounds
-    for n in (1, 2, 15, 16, 17, 40, 63, 64, 65, 127, 129, 255, 256, 257, 319, 320, 321, 639, 641, 1000, 1023, 1025):
+    # (from 15 beams up: with one or two beams H is singular, the reference's estimate turns NaN and it indexes the map with it)
+    for n in (15, 16, 17, 40, 63, 64, 65, 127, 129, 255, 256, 257, 319, 320, 321, 639, 641, 1000, 1023, 1025):
         pts = full[np.linspace(0, full.shape[0] - 1, n).astype(int)]
         pg, cg = g.matchData(sc.query_init[2], pts)
         po, co = o.match(sc.query_init[2], pts)
