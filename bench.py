@@ -474,6 +474,17 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             pg, _ = m.matchData(init[q], scans[q])
             lat.append(time.perf_counter() - a)
         lat = np.array(lat[args.warmup:])
+        # the same call with HSM_PARITY=exact (the reference's summation order on a single scan: nine sequential chains of
+        # n additions per GN step; opt-in for single scans, AUTO keeps the fast tree there)
+        m.set_parity(capi.PARITY_EXACT)
+        lat_x = []
+        for k in range(10 + min(args.steps, 100)):
+            q = k % nq
+            a = time.perf_counter()
+            m.matchData(init[q], scans[q])
+            lat_x.append(time.perf_counter() - a)
+        m.set_parity(capi.PARITY_AUTO)
+        out["exact_single_scan_latency_us"] = {"median": float(np.median(lat_x[10:])) * 1e6, "p90": float(np.percentile(lat_x[10:], 90)) * 1e6}
         # the other half of HectorSlamProcessor::update: updateByScan on all levels + onMapUpdated, host call
         m2 = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
         m2.setUpdateFactorFree(0.4)
