@@ -479,16 +479,22 @@ __device__ __forceinline__ void beam_products(const BeamSample& b, const BeamRot
 // a half is requested again right after its values are consumed, so a dependent addition costs its own latency (8.5 cycles
 // on a lone wavefront, tools/ubench_chain.hip) instead of 14.4 with one 16-byte read in flight -- the chain is 1081 x 14
 // additions of a single-scan match in exact mode, ~100 of its ~135 us before.
-template <int T>
-__device__ __forceinline__ float exact_round(const float pr[9], float* __restrict__ stage, int tid, float run, int count = T) {
+// stage the nine products of the beam at position `pos` of rows of RL beams
+template <int RL>
+__device__ __forceinline__ void exact_stage(const float pr[9], float* __restrict__ stage, int pos) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) stage[t * (T + kExactPad) + tid] = pr[t];
-  if (T > 64) __syncthreads();
+  for (int t = 0; t < 9; ++t) stage[t * (RL + kExactPad) + pos] = pr[t];
+}
+
+// the chains over the first `count` beams of the staged rows (rows of RL beams; SYNC: the team is wider than one wavefront)
+template <int RL, bool SYNC>
+__device__ __forceinline__ float exact_chain(float* __restrict__ stage, int tid, float run, int count) {
+  if (SYNC) __syncthreads();
   if (tid < 9) {
-    const f4v* row = reinterpret_cast<const f4v*>(stage + tid * (T + kExactPad));
+    const f4v* row = reinterpret_cast<const f4v*>(stage + tid * (RL + kExactPad));
     // 16 beams per iteration, branch-free (loads behind a branch make the compiler wait for all of them): the last
     // iteration's read-ahead is clamped into the row, beams between `count` and the next multiple of 16 add their +-0
-    const int nq = ((count + 15) >> 4) << 2;  // float4s, a multiple of 4, <= T / 4
+    const int nq = ((count + 15) >> 4) << 2;  // float4s, a multiple of 4, <= RL / 4
     f4v a0 = row[0], a1 = row[1], b0 = row[2], b1 = row[3];  // two 32-byte halves in flight
     // (the additions as inline asm: left to itself the compiler keeps the running sum in the registers of the half it is
     // consuming, which postpones that half's refill to the end of the iteration -- one exposed LDS round trip per 16 beams)
@@ -502,14 +508,21 @@ __device__ __forceinline__ float exact_round(const float pr[9], float* __restric
     };
     for (int q = 0; q < nq; q += 4) {
       add8(a0, a1);
-      const int qa = min(q + 4, T / 4 - 4);  // refilled right behind its last use: eight additions to arrive in
+      const int qa = min(q + 4, RL / 4 - 4);  // refilled right behind its last use: eight additions to arrive in
       a0 = row[qa], a1 = row[qa + 1];
       add8(b0, b1);
       b0 = row[qa + 2], b1 = row[qa + 3];
     }
   }
-  if (T > 64) __syncthreads();
+  if (SYNC) __syncthreads();
   return run;
+}
+
+// one round of T beams: stage, sum
+template <int T>
+__device__ __forceinline__ float exact_round(const float pr[9], float* __restrict__ stage, int tid, float run, int count = T) {
+  exact_stage<T>(pr, stage, tid);
+  return exact_chain<T, (T > 64)>(stage, tid, run, count);
 }
 
 // Wavefront all-reduce without LDS traffic: four DPP steps inside each row of 16 lanes (the
@@ -710,7 +723,12 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
   static_assert(!EXACT || BPL == 0, "the exact-order form streams the endpoints");
   constexpr int T = 64 * WPS;  // lanes per team
   __shared__ __attribute__((aligned(16))) float red[2][9][WPS < 4 ? 4 : WPS];
-  __shared__ float stage[EXACT ? SPB * 9 * (T + kExactPad) : 1];  // exact_round(): [team][term][beam of the round]
+  // exact order: [team][term][beam]; single-scan teams of up to four wavefronts stage a whole GROUP of rounds (kXGroup x T beams,
+  // 46 KB at four wavefronts) and sum it in one go, the others round by round
+  constexpr int kXGroup = 5;
+  constexpr int kXStaged = (EXACT && SPB == 1 && T <= 256) ? kXGroup : 1;  // rounds staged together
+  constexpr int kXRowLen = kXStaged * T;
+  __shared__ float stage[EXACT ? SPB * 9 * (kXRowLen + kExactPad) : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int team = wave / WPS;
@@ -839,11 +857,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
 #endif
       } else if (EXACT) {
         float run = 0.0f;
-        float* st = stage + team * 9 * (T + kExactPad);
+        float* st = stage + team * 9 * (kXRowLen + kExactPad);
         // Rounds in groups of kXGroup: the endpoints of the whole group are requested together, then its texels, then the
         // rounds are summed one after the other -- two memory round trips per group instead of two per round (a 1081-beam
         // scan on four wavefronts is ONE group per GN step; the dependent loads were ~40 % of the exact single-scan match).
-        constexpr int kXGroup = 5;
         for (int base0 = 0; base0 < n; base0 += kXGroup * T) {  // team-uniform trip count
           float2 q[kXGroup];
 #pragma unroll
@@ -855,13 +872,25 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
           BeamRot r[kXGroup];
 #pragma unroll
           for (int g = 0; g < kXGroup; ++g) b[g] = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{q[g].x * ps, q[g].y * ps}, r[g]);
+          if (kXStaged == kXGroup) {
+            // the whole group behind ONE barrier pair, the chain runs through it without a stop (rounds beyond the scan
+            // stage +-0 and are not summed)
 #pragma unroll
-          for (int g = 0; g < kXGroup; ++g) {
-            const int base = base0 + g * T;
-            if (base < n) {  // team-uniform
+            for (int g = 0; g < kXGroup; ++g) {
               float pr[9];
               beam_products(b[g], r[g], pr);
-              run = exact_round<T>(pr, st, tid_in_team, run, min(T, n - base));
+              exact_stage<kXRowLen>(pr, st, g * T + tid_in_team);
+            }
+            run = exact_chain<kXRowLen, (T > 64)>(st, tid_in_team, run, min(kXRowLen, n - base0));
+          } else {
+#pragma unroll
+            for (int g = 0; g < kXGroup; ++g) {
+              const int base = base0 + g * T;
+              if (base < n) {  // team-uniform
+                float pr[9];
+                beam_products(b[g], r[g], pr);
+                run = exact_round<T>(pr, st, tid_in_team, run, min(T, n - base));
+              }
             }
           }
         }
