@@ -777,6 +777,17 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
       pt[k] = f2{q.x, q.y};
     }
   }
+  // exact order: a scan that is ONE group of rounds keeps its endpoints (unscaled) in registers across all levels and GN steps
+  // -- one dependent memory round trip per step, the texel gather, instead of two
+  const bool xq_resident = EXACT && n <= kXGroup * T;  // (team-uniform)
+  float2 xq[EXACT ? kXGroup : 1];
+  if (xq_resident) {
+#pragma unroll
+    for (int g = 0; g < (EXACT ? kXGroup : 1); ++g) {
+      const int i = g * T + tid_in_team;
+      xq[g] = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);
+    }
+  }
   Acc9 acc;
   acc.zero();
   int buf = 0;
@@ -865,8 +876,12 @@ __global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const Match
           float2 q[kXGroup];
 #pragma unroll
           for (int g = 0; g < kXGroup; ++g) {
-            const int i = base0 + g * T + tid_in_team;
-            q[g] = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products (see above)
+            if (xq_resident) {  // a scan of one group: its endpoints were loaded once, before the first level
+              q[g] = xq[g];
+            } else {
+              const int i = base0 + g * T + tid_in_team;
+              q[g] = i < n ? pts[i] : make_float2(1.0e30f, 1.0e30f);  // padding: exact +-0 products (see above)
+            }
           }
           BeamSample b[kXGroup];
           BeamRot r[kXGroup];
