@@ -3,7 +3,7 @@
 # pmc dumps (python bench.py), the driver's command, single-scan timings per parity mode
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/r04k
+OUT=$ROOT/gpurun_out/${CALL:-r04k}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 S=$(date +%s)
