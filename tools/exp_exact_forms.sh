@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 2 experiment; since round 4 the producer / chain-wavefront form and its HSM_EXACT_SHAPE / HSM_EXACT_BATCH switches exist in
+#  -DHSM_EXPERIMENTS builds only: tools/build_variants.py x:"-DHSM_EXPERIMENTS" and HSM_LIB=<that library>)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/exp_exact

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 2 experiment; since round 4 the producer / chain-wavefront form and its HSM_EXACT_SHAPE / HSM_EXACT_BATCH switches exist in
+#  -DHSM_EXPERIMENTS builds only: tools/build_variants.py x:"-DHSM_EXPERIMENTS" and HSM_LIB=<that library>)
 # exact batch form: 7 producers + 1 consumer vs 8 + 2 per workgroup (HSM_EXACT_SHAPE), kernel time per launch
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"; mkdir -p gpurun_out/exact_shape
