@@ -47,9 +47,9 @@ struct LevelRW {
   unsigned int* key_free; // first free-touching beam of the current scan
   unsigned int* key_occ;  // first end-cell beam of the current scan
   unsigned int* occ_bits; // 1 bit per cell: "some beam of the current scan ends here" (set in pass 1a, cleared in pass 2)
-  unsigned char* free_bytes; // dense scans: 1 byte per cell "some beam of the current scan crosses this cell", in the key_free
-                             // tiling (index = key_free_index: an 8x4-cell tile is 32 contiguous bytes); set by
-                             // update_mark_free_dense_kernel, cleared by update_apply_dense_kernel
+  unsigned char* free_bytes; // dense scans: 1 byte per cell "some beam of the current scan crosses this cell", in tiles of 16 x 8
+                             // cells (index = mark_index: a tile is one 128-byte line); set by update_mark_free_dense_kernel,
+                             // cleared by the dense apply pass
   int sx, sy;
   int tiles_x, quad_texels;  // tiled texel plane geometry (gn_match.h quad_index)
   int kf_tiles_x;            // free-key tiles per row = key_free_tiles_x(sx): ceil(sx / 64) * 8   (key_free_index)
@@ -78,6 +78,33 @@ __device__ __forceinline__ unsigned int key_free_index(const LevelRW& L, unsigne
   return ((((y >> 2) * (unsigned int)L.kf_tiles_x) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);
 #else
   return y * (unsigned int)L.sx + x;
+#endif
+}
+
+// The mark BYTES of the dense form (free_bytes): tiles of 16 x 8 cells = one 128-byte line each (HSM_MARK_TILE16=1, the default
+// since the end of round 4).  Until then they shared the free-key plane's 8 x 4-cell tiling (HSM_MARK_TILE16=0), in which a
+// 128-byte line of BYTES is four tiles side by side = 32 x 4 cells: the 64 steps of a line-walk iteration cross about
+// (dx / 32 + dy / 4 + 1) lines -- ~14.5 averaged over the beam directions of a 360-degree scan -- against (dx / 16 + dy / 8 + 1)
+// ~ 10 with the squarer tile.  The line walk is bound by exactly these scattered byte accesses (profiles/r04/README.md 5):
+// 65.2 -> 57.6 us on configs[4]; the apply pass, which now owns 32 x 8-cell blocks (two tiles = 256 contiguous mark bytes, its
+// plane accesses two 128-byte row segments per wavefront): 68.4 -> 65.1 us; update 0.144 -> 0.1355 ms, maps bit-identical
+// (profiles/r04/README.md 20).
+#ifndef HSM_MARK_TILE16
+#define HSM_MARK_TILE16 1
+#endif
+__host__ __device__ __forceinline__ int mark_tiles_x(int sx) { return ((sx + 31) / 32) * 2; }  // 16-cell tiles per row, whole 32-cell blocks
+__host__ __device__ __forceinline__ size_t mark_bytes(int sx, int sy) {
+#if HSM_MARK_TILE16
+  return (size_t)mark_tiles_x(sx) * (size_t)((sy + 7) / 8) * 128u;
+#else
+  return key_free_cells(sx, sy);
+#endif
+}
+__device__ __forceinline__ unsigned int mark_index(const LevelRW& L, unsigned int x, unsigned int y) {
+#if HSM_MARK_TILE16
+  return ((((y >> 3) * (unsigned int)mark_tiles_x(L.sx)) + (x >> 4)) << 7) | ((y & 7u) << 4) | (x & 15u);
+#else
+  return key_free_index(L, x, y);
 #endif
 }
 
@@ -248,7 +275,7 @@ __global__ void __launch_bounds__(256) update_mark_occ_dense_kernel(const Update
     BeamRec rec = {0u, 0u, 0u, 0u};
     if (valid) {
       c = (unsigned int)(b.y1 * P.lv.sx + b.x1);
-      kc = key_free_index(P.lv, (unsigned int)b.x1, (unsigned int)b.y1);
+      kc = mark_index(P.lv, (unsigned int)b.x1, (unsigned int)b.y1);
       // the walk's per-64-steps increment of (e0 + i * db) / da: quotient and remainder (abs_da >= 1 for a valid beam)
       const unsigned int inc = 64u * b.abs_db;
       const unsigned int q64 = inc / b.abs_da;
@@ -535,12 +562,23 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   const unsigned int tiles_x = pinned_sgpr((unsigned int)P.lv.kf_tiles_x);
   unsigned char* const marks = pinned_sgpr(P.lv.free_bytes);
   unsigned int* const keys = pinned_sgpr(P.lv.key_free);
-  auto cell_index = [&]() -> unsigned int {
+#if HSM_MARK_TILE16
+  const unsigned int mtiles_x = pinned_sgpr((unsigned int)mark_tiles_x(P.lv.sx));
+#endif
+  auto key_index = [&]() -> unsigned int {  // of the current cell, in the free-key plane
 #if HSM_KEYFREE_TILE
     return ((__umul24((unsigned int)cy >> 2, tiles_x) + ((unsigned int)cx >> 3)) << 5) | (((unsigned int)cy & 3u) << 3) |
            ((unsigned int)cx & 7u);  // == key_free_index(P.lv, cx, cy): rows of tiles and tiles per row are below 2^24
 #else
     return key_free_index(P.lv, (unsigned int)cx, (unsigned int)cy);
+#endif
+  };
+  auto cell_index = [&]() -> unsigned int {  // of the current cell, in the mark-byte plane
+#if HSM_MARK_TILE16
+    return ((__umul24((unsigned int)cy >> 3, mtiles_x) + ((unsigned int)cx >> 4)) << 7) | (((unsigned int)cy & 7u) << 4) |
+           ((unsigned int)cx & 15u);  // == mark_index(P.lv, cx, cy)
+#else
+    return key_index();
 #endif
   };
   auto advance = [&]() {  // 64 steps on: the carries of both error accumulators
@@ -561,10 +599,10 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
       ++pq;
     }
   };
-  auto touch = [&](unsigned int kc, unsigned char m) {
+  auto touch = [&](unsigned int kc, unsigned char m, unsigned int kkey) {  // kkey: the cell's index in the free-key plane
     if (m & kMarkEnd) {
-      atomicMax(&keys[kc], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
-    } else if (m == 0) {          // (a stale 0 only repeats the store)
+      atomicMax(&keys[kkey], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
+    } else if (m == 0) {            // (a stale 0 only repeats the store)
       marks[kc] = kMarkCrossed;
     }
   };
@@ -574,23 +612,23 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
 #if HSM_MARK_UNROLL == 2
   for (unsigned int i = lane; i < da; i += 128) {
     const bool need_a = !(i < pda && pq == q);
-    const unsigned int kc_a = cell_index();
+    const unsigned int kc_a = cell_index(), kk_a = key_index();
     advance();
     const bool need_b = i + 64 < da && !(i + 64 < pda && pq == q);
-    const unsigned int kc_b = cell_index();
+    const unsigned int kc_b = cell_index(), kk_b = key_index();
     advance();
     unsigned char m_a = kMarkCrossed, m_b = kMarkCrossed;  // "already marked": nothing to do
     if (need_a) m_a = marks[kc_a];
     if (need_b) m_b = marks[kc_b];
-    touch(kc_a, m_a);
-    touch(kc_b, m_b);
+    touch(kc_a, m_a, kk_a);
+    touch(kc_b, m_b, kk_b);
   }
 #else
   for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
       const unsigned int kc = cell_index();
       // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
-      touch(kc, marks[kc]);
+      touch(kc, marks[kc], HSM_MARK_TILE16 ? key_index() : kc);
     }
     advance();
   }
@@ -608,6 +646,7 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
 #ifndef HSM_APPLY_BLOCKS  // 64 x 4-cell blocks a wavefront of the dense apply pass has in flight
 #define HSM_APPLY_BLOCKS 1
 #endif
+#if !HSM_MARK_TILE16
 template <bool SCATTER_TEXELS>
 __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBatch B) {
   const UpdateParams& P = B.lv[blockIdx.y];
@@ -730,6 +769,106 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
     }
   }
 }
+
+#endif  // !HSM_MARK_TILE16
+
+#if HSM_MARK_TILE16
+// HSM_MARK_TILE16: the dense apply pass on 32 x 8-cell blocks (two 16 x 8 mark tiles = 256 contiguous mark bytes, one dword
+// per lane).  Lane l works on column l % 32 of the block and on rows 2 i + l / 32 (i = 0 .. 3): every access of the log-odds /
+// stamp / probability planes is two 128-byte row segments per wavefront.  Otherwise update_apply_dense_kernel's block: skip
+// when no mark is set, the reference's rule on the marked cells, marks cleared; the next block's marks are requested first.
+template <bool SCATTER_TEXELS>
+__global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBatch B) {
+  const UpdateParams& P = B.lv[blockIdx.y];
+  if (P.x1 < P.x0) return;
+  const int lane = threadIdx.x & 63;
+  const int xl = lane & 31, rh = lane >> 5;
+  const int bx0 = P.x0 & ~31, by0 = P.y0 & ~7;
+  const int nbx = ((P.x1 | 31) - bx0 + 1) >> 5, nby = (((P.y1 | 7) - by0) >> 3) + 1;
+  const int nblocks = nbx * nby;
+  const int waves = (int)((gridDim.x * blockDim.x) >> 6);
+  const int sx = P.lv.sx, sy = P.lv.sy;
+  const unsigned int mtx = (unsigned int)mark_tiles_x(sx);
+  auto marks_of = [&](int blk) -> unsigned int* {
+    const int X0 = bx0 + ((blk % nbx) << 5), Y0 = by0 + ((blk / nbx) << 3);
+    const unsigned int t0 = (((unsigned int)(Y0 >> 3) * mtx) + (unsigned int)(X0 >> 4)) << 7;  // byte index of the block's first tile
+    return reinterpret_cast<unsigned int*>(P.lv.free_bytes + t0) + lane;
+  };
+  int blk = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (blk >= nblocks) return;
+  unsigned int fw_next = *marks_of(blk);
+  for (; blk < nblocks; blk += waves) {
+    const unsigned int fw = fw_next;
+    fw_next = blk + waves < nblocks ? *marks_of(blk + waves) : 0u;
+    if (__ballot(fw != 0u) == 0ull) continue;  // wave-uniform: nothing of this scan in the block
+    const int X0 = bx0 + ((blk % nbx) << 5), Y0 = by0 + ((blk / nbx) << 3);
+    const int x = X0 + xl;
+    if (fw != 0u) *marks_of(blk) = 0u;
+    bool fre[4], occ[4];
+    float l[4];
+    unsigned int ko[4], kf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 2 * i + rh, y = Y0 + r;
+      const size_t c = (size_t)y * sx + x;
+      // the byte of cell (xl, r): tile xl / 16, byte r * 16 + xl % 16 = dword (xl / 16) * 32 + r * 4 + (xl % 16) / 4, byte xl & 3
+      const unsigned int fwd = (unsigned int)__shfl((int)fw, ((xl >> 4) << 5) + (r << 2) + ((xl & 15) >> 2));
+      const unsigned int mark = (fwd >> ((xl & 3) << 3)) & 0xffu;
+      occ[i] = (mark & kMarkEnd) != 0u && y < sy && x < sx;
+      fre[i] = (mark & kMarkCrossed) != 0u && y < sy && x < sx;
+      l[i] = 0.0f;
+      ko[i] = kf[i] = 0u;
+      if (fre[i] || occ[i]) l[i] = P.lv.logodds[c];
+      if (occ[i]) {
+        ko[i] = P.lv.key_occ[c];
+        kf[i] = P.lv.key_free[key_free_index(P.lv, (unsigned int)x, (unsigned int)y)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = Y0 + 2 * i + rh;
+      const size_t c = (size_t)y * sx + x;
+      bool is_occ = occ[i], is_fre = fre[i];
+      if (is_occ) {
+        is_occ = (ko[i] >> kBeamBits) == P.serial;
+        is_fre = (kf[i] >> kBeamBits) == P.serial;
+      }
+      if (!is_fre && !is_occ) continue;
+      float lo = l[i];
+      int stamp;
+      if (is_occ) {
+        if (is_fre && (kBeamMask - (kf[i] & kBeamMask)) < (kBeamMask - (ko[i] & kBeamMask))) {
+          lo += P.log_odds_free;
+          lo -= P.log_odds_free;
+        }
+        if (lo < 50.0f) lo += P.log_odds_occ;
+        stamp = P.mark_occ;
+      } else {
+        lo += P.log_odds_free;
+        stamp = P.mark_free;
+      }
+      __builtin_nontemporal_store(lo, &P.lv.logodds[c]);
+      __builtin_nontemporal_store(stamp, &P.lv.update_index[c]);
+      const float p = grid_probability(lo);
+      __builtin_nontemporal_store(p, &P.lv.prob[c]);
+      if (SCATTER_TEXELS) {
+        float* q = reinterpret_cast<float*>(P.lv.quad);
+        const bool lastx = x == sx - 1, lasty = y == sy - 1;
+        auto put = [&](int tx, int ty, int comp) { q[4 * (size_t)quad_index(tx, ty, P.lv.tiles_x, sx) + comp] = p; };
+        put(x, y, 0);
+        if (x > 0) put(x - 1, y, 1);
+        if (lastx) put(x, y, 1);
+        if (y > 0) put(x, y - 1, 2);
+        if (lasty) put(x, y, 2);
+        if (x > 0 && y > 0) put(x - 1, y - 1, 3);
+        if (lastx && y > 0) put(x, y - 1, 3);
+        if (lasty && x > 0) put(x - 1, y, 3);
+        if (lastx && lasty) put(x, y, 3);
+      }
+    }
+  }
+}
+#endif
 
 // dense over the box grown by one cell towards -x/-y: texel (x,y) holds P of (x..x+1, y..y+1)
 __global__ void __launch_bounds__(256) update_texels_kernel(const UpdateBatch B) {
