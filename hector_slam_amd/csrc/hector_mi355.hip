@@ -561,7 +561,7 @@ struct LevelPrep {
 // a mark pass is outstanding; the next update on it then clears both mark planes first and widens the rows the key-wrap
 // clear covers to the whole level (the failed update's keys carry an older generation and are ignored as such).
 int scrub_marks(hsm_ctx* h, Level& L) {
-  HIP_TRY(hipMemsetAsync(L.d_free_bytes, 0, mark_bytes(L.sx, L.sy) + 256, h->stream));
+  HIP_TRY(hipMemsetAsync(L.d_free_bytes, 0, mark_plane_bytes(L.sx, L.sy), h->stream));
   HIP_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((L.cells() + 31) / 32 + 1) * sizeof(unsigned int), h->stream));
   L.key_rows[0] = 0;
   L.key_rows[1] = L.sy - 1;
@@ -984,8 +984,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     CREATE_TRY(hipMemsetAsync(L.d_key_occ, 0, n * sizeof(unsigned int), h->stream));
     CREATE_TRY(hipMalloc((void**)&L.d_occ_bits, ((n + 31) / 32 + 1) * sizeof(unsigned int)));
     CREATE_TRY(hipMemsetAsync(L.d_occ_bits, 0, ((n + 31) / 32 + 1) * sizeof(unsigned int), h->stream));
-    CREATE_TRY(hipMalloc((void**)&L.d_free_bytes, mark_bytes(L.sx, L.sy) + 256));
-    CREATE_TRY(hipMemsetAsync(L.d_free_bytes, 0, mark_bytes(L.sx, L.sy) + 256, h->stream));
+    CREATE_TRY(hipMalloc((void**)&L.d_free_bytes, mark_plane_bytes(L.sx, L.sy)));
+    CREATE_TRY(hipMemsetAsync(L.d_free_bytes, 0, mark_plane_bytes(L.sx, L.sy), h->stream));
     if (fill_level(h, L) != HSM_OK) {
       hsm_destroy(h);
       return HSM_ERR_HIP;
@@ -2546,7 +2546,7 @@ int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]) {
   HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
   hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), h->stream);
   if (e == hipSuccess) {
-    const size_t nb = (mark_bytes(L.sx, L.sy) + 256) / 4, nw = (L.cells() + 31) / 32 + 1;
+    const size_t nb = (mark_plane_bytes(L.sx, L.sy)) / 4, nw = (L.cells() + 31) / 32 + 1;
     hipLaunchKernelGGL(count_nonzero_words_kernel, dim3(grid_for(nb)), dim3(256), 0, h->stream,
                        reinterpret_cast<const unsigned int*>(L.d_free_bytes), nb, d);
     hipLaunchKernelGGL(count_nonzero_words_kernel, dim3(grid_for(nw)), dim3(256), 0, h->stream, L.d_occ_bits, nw, d + 1);

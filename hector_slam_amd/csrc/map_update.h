@@ -100,6 +100,23 @@ __host__ __device__ __forceinline__ size_t mark_bytes(int sx, int sy) {
   return key_free_cells(sx, sy);
 #endif
 }
+// One byte per 16 x 8 mark TILE behind the mark bytes: "a beam of the current scan ends in this tile" (set by the end-cell pass,
+// cleared by the apply pass; HSM_MARK_TILE_END=1, the default since the end of round 4).  The line walk had to read every mark
+// byte before storing to it -- to learn whether a beam ends in the cell (then the keyed atomicMax decides the revert artefact),
+// and to skip marks already set; that load, ~10 lines of a 67 MB plane per iteration, was a third of the walk.  Now it reads the
+// TILE's byte -- a 128 x smaller, cache-resident map, 1-4 lines per iteration -- and only in the ~1/6 of the tiles where it is set
+// the cell's own byte; everywhere else it stores its mark unread (an already set mark is stored again: same value).
+// configs[4]: line walk 57.5 -> 50.0 us, update 0.135 -> 0.127 ms (profiles/r04/README.md 21).
+#ifndef HSM_MARK_TILE_END
+#define HSM_MARK_TILE_END 1
+#endif
+#if HSM_MARK_TILE_END && !HSM_MARK_TILE16
+#error "the tile flags index the 16 x 8 mark tiles"
+#endif
+__host__ __device__ __forceinline__ size_t mark_tile_end_offset(int sx, int sy) { return mark_bytes(sx, sy) + 256; }
+__host__ __device__ __forceinline__ size_t mark_plane_bytes(int sx, int sy) {
+  return mark_bytes(sx, sy) + 256 + (HSM_MARK_TILE_END ? ((mark_bytes(sx, sy) / 128 + 3) & ~(size_t)3) + 256 : 0);
+}
 __device__ __forceinline__ unsigned int mark_index(const LevelRW& L, unsigned int x, unsigned int y) {
 #if HSM_MARK_TILE16
   return ((((y >> 3) * (unsigned int)mark_tiles_x(L.sx)) + (x >> 4)) << 7) | ((y & 7u) << 4) | (x & 15u);
@@ -291,6 +308,9 @@ __global__ void __launch_bounds__(256) update_mark_occ_dense_kernel(const Update
   if (valid && (lane == 0 || c_prev != c)) {  // of a run of adjacent lanes with the same end cell the first = lowest beam index
     atomicMax(&P.lv.key_occ[c], (P.serial << kBeamBits) | (kBeamMask - (unsigned int)beam));
     P.lv.free_bytes[kc] = kMarkEnd;
+#if HSM_MARK_TILE_END
+    P.lv.free_bytes[mark_tile_end_offset(P.lv.sx, P.lv.sy) + (kc >> 7)] = 1;
+#endif
   }
 }
 
@@ -624,11 +644,22 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
     touch(kc_b, m_b, kk_b);
   }
 #else
+#if HSM_MARK_TILE_END
+  const unsigned char* const tile_end = pinned_sgpr(P.lv.free_bytes + mark_tile_end_offset(P.lv.sx, P.lv.sy));
+#endif
   for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
       const unsigned int kc = cell_index();
+#if HSM_MARK_TILE_END
+      if (tile_end[kc >> 7] == 0) {
+        marks[kc] = kMarkCrossed;  // no beam ends in this tile: nothing to look at (an already set mark is stored again)
+      } else {
+        touch(kc, marks[kc], key_index());
+      }
+#else
       // one byte load from the line the store goes to (the row-major end-cell bitmap cost a y-major beam 64 lines per access)
       touch(kc, marks[kc], HSM_MARK_TILE16 ? key_index() : kc);
+#endif
     }
     advance();
   }
@@ -804,6 +835,12 @@ __global__ void __launch_bounds__(256) update_apply_dense_kernel(const UpdateBat
     const int X0 = bx0 + ((blk % nbx) << 5), Y0 = by0 + ((blk / nbx) << 3);
     const int x = X0 + xl;
     if (fw != 0u) *marks_of(blk) = 0u;
+#if HSM_MARK_TILE_END
+    if (lane < 2) {
+      const unsigned int t0 = (((unsigned int)(Y0 >> 3) * mtx) + (unsigned int)(X0 >> 4));
+      P.lv.free_bytes[mark_tile_end_offset(sx, sy) + t0 + lane] = 0;
+    }
+#endif
     bool fre[4], occ[4];
     float l[4];
     unsigned int ko[4], kf[4];
