@@ -580,8 +580,12 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   int cx = P.bx + ax * lane + mx * (int)q, cy = P.by + ay * lane + my * (int)q;
   const int dx64 = 64 * ax + mx * (int)q64, dy64 = 64 * ay + my * (int)q64;  // per iteration, before the remainder's carry
   const unsigned int tiles_x = pinned_sgpr((unsigned int)P.lv.kf_tiles_x);
-  unsigned char* const marks = pinned_sgpr(P.lv.free_bytes);
-  unsigned int* const keys = pinned_sgpr(P.lv.key_free);
+  // (global address space spelled out: a pointer that went through pinned_sgpr's asm is a generic one to the compiler, and the
+  // walk's byte accesses became flat_load / flat_store with 64-bit per-lane addresses instead of global_* on an SGPR base)
+  typedef __attribute__((address_space(1))) unsigned char gbyte;
+  typedef __attribute__((address_space(1))) unsigned int gword;
+  gbyte* const marks = (gbyte*)pinned_sgpr(P.lv.free_bytes);
+  gword* const keys = (gword*)pinned_sgpr(P.lv.key_free);
 #if HSM_MARK_TILE16
   const unsigned int mtiles_x = pinned_sgpr((unsigned int)mark_tiles_x(P.lv.sx));
 #endif
@@ -621,7 +625,7 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   };
   auto touch = [&](unsigned int kc, unsigned char m, unsigned int kkey) {  // kkey: the cell's index in the free-key plane
     if (m & kMarkEnd) {
-      atomicMax(&keys[kkey], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
+      atomicMax((unsigned int*)&keys[kkey], key);  // a beam ends here: the lowest crossing beam index matters (revert artefact)
     } else if (m == 0) {            // (a stale 0 only repeats the store)
       marks[kc] = kMarkCrossed;
     }
@@ -645,7 +649,7 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
   }
 #else
 #if HSM_MARK_TILE_END
-  const unsigned char* const tile_end = pinned_sgpr(P.lv.free_bytes + mark_tile_end_offset(P.lv.sx, P.lv.sy));
+  const gbyte* const tile_end = (const gbyte*)pinned_sgpr(P.lv.free_bytes + mark_tile_end_offset(P.lv.sx, P.lv.sy));
 #endif
   for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
