@@ -143,6 +143,17 @@ struct hsm_ctx {
   float2* d_retained = nullptr;
   size_t d_retained_cap = 0;
   bool d_retained_current = false;
+  // the upload of a dense scan for matchData runs on its own stream, into the OTHER of two device buffers, from a pinned
+  // staging block: it overlaps the update kernels still queued on `stream` (which read the buffer of the scan before)
+  // instead of waiting behind them; the match kernel waits for the copy's event (stage_scan_overlapped)
+  float2* d_retained_alt = nullptr;
+  size_t d_retained_alt_cap = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_evt = nullptr;
+  float2* h_copy_pinned = nullptr;
+  size_t h_copy_pinned_cap = 0;
+  bool overlap_upload = true;  // env HSM_OVERLAP_UPLOAD=0: the copy is queued on `stream` as before
+  bool queued_update = false;  // an asynchronous updateByScan was queued on `stream` since the host last saw it drained
   // batch staging for the host-pointer convenience entry
   void* d_batch = nullptr;
   size_t d_batch_cap = 0;
@@ -901,6 +912,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_COOP_TAGGED")) h->coop_tagged = atoi(env) != 0;
   if (const char* env = getenv("HSM_SPIN_WAIT")) h->spin_wait = atoi(env) != 0;
   if (const char* env = getenv("HSM_ASYNC_UPDATE")) h->async_update = atoi(env) != 0;
+  if (const char* env = getenv("HSM_OVERLAP_UPLOAD")) h->overlap_upload = atoi(env) != 0;
   if (const char* env = getenv("HSM_TEXEL_CACHE")) h->texel_cache = atoi(env) != 0;
   if (const char* env = getenv("HSM_UPDATE_ZEROCOPY_MAX")) h->update_zero_copy_max = atoi(env);
   if (const char* env = getenv("HSM_PARITY")) {
@@ -1008,6 +1020,11 @@ void hsm_destroy(hsm_ctx* h) {
   (void)hipFree(h->d_scan);
   (void)hipFree(h->d_beam_recs);
   (void)hipFree(h->d_retained);
+  (void)hipFree(h->d_retained_alt);
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  if (h->copy_evt) (void)hipEventDestroy(h->copy_evt);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->h_copy_pinned) (void)hipHostFree(h->h_copy_pinned);
   (void)hipFree(h->d_small);
   (void)hipFree(h->d_batch);
   (void)hipFree(h->d_cells);
@@ -1322,6 +1339,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     return rc;
   }
   if (int rc = wait_single_scan(h, seq)) return rc;
+  h->queued_update = false;  // the match kernel was the last thing on `stream`, and it has completed
   if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq)
     return fail(HSM_ERR_HIP, "hsm_match: the cooperative matcher's inter-workgroup exchange timed out (a workgroup never published its partial sums); no pose");
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
@@ -1357,6 +1375,38 @@ static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, si
   if (int rc = ensure_scan_capacity(d_buf, d_cap, (size_t)n)) return rc;
   if (n > 0) HIP_TRY(hipMemcpyAsync(d_buf, pts_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
   *out = d_buf;
+  return HSM_OK;
+}
+
+// The retained scan of matchData when it has to live in device memory (dense scans, exact order): uploaded on the copy
+// stream into the buffer the update kernels of the scan BEFORE are not reading, so that the copy runs while those kernels
+// still occupy `stream` (in a match + update loop the upload of scan t + 1 used to wait behind the update of scan t: ~10 us of
+// every configs[4] step).  Safe with two buffers: the kernels that read buffer A (match t, update t) are all ordered before
+// match t + 1 on `stream`, and hsm_match returns only when match t + 1 has completed -- so when the upload of scan t + 2 is
+// issued into A nothing reads it any more.  The staging block is pinned (a pageable hipMemcpyAsync would block the host
+// until everything queued on its stream has completed) and free again for the same reason.
+static int stage_scan_overlapped(hsm_ctx* h, const float* pts_xy, int n, const float2** out) {
+  if (!h->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->copy_evt, hipEventDisableTiming));
+  }
+  std::swap(h->d_retained, h->d_retained_alt);
+  std::swap(h->d_retained_cap, h->d_retained_alt_cap);
+  if (int rc = ensure_scan_capacity(h->d_retained, h->d_retained_cap, (size_t)n)) return rc;
+  if ((size_t)n > h->h_copy_pinned_cap) {
+    HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    if (h->h_copy_pinned) HIP_TRY(hipHostFree(h->h_copy_pinned));
+    h->h_copy_pinned = nullptr;
+    h->h_copy_pinned_cap = 0;
+    const size_t want = (size_t)n + (size_t)n / 2;
+    HIP_TRY(hipHostMalloc((void**)&h->h_copy_pinned, want * sizeof(float2), hipHostMallocDefault));
+    h->h_copy_pinned_cap = want;
+  }
+  memcpy(h->h_copy_pinned, pts_xy, (size_t)n * sizeof(float2));
+  HIP_TRY(hipMemcpyAsync(h->d_retained, h->h_copy_pinned, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->copy_stream));
+  HIP_TRY(hipEventRecord(h->copy_evt, h->copy_stream));
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_evt, 0));
+  *out = h->d_retained;
   return HSM_OK;
 }
 
@@ -1396,8 +1446,19 @@ static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_x
     h->retained_valid = true;
   }
   const float2* pts = d_prestaged;
-  if (!pts)
-    if (int rc = stage_scan(h, pts_xy, n, h->d_retained, h->d_retained_cap, &pts)) return rc;
+  if (!pts) {
+    // (the same rule as stage_scan's: scans the matcher reads once stay in pinned host memory)
+    const bool to_device = !(n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !h->exact &&
+                             (n < h->coop_min_beams || h->wps_override != 0));
+    // ... and only behind an update that was queued and not waited for (the match + update loop): on an idle stream the
+    // extra hop through the copy stream's event costs ~10 us of latency and hides nothing (asking the runtime with
+    // hipStreamQuery costs half of what the overlap gains: 0.1855 against 0.179 ms per configs[4] step)
+    if (to_device && h->overlap_upload && n > 0 && h->queued_update) {
+      if (int rc = stage_scan_overlapped(h, pts_xy, n, &pts)) return rc;
+    } else if (int rc = stage_scan(h, pts_xy, n, h->d_retained, h->d_retained_cap, &pts)) {
+      return rc;
+    }
+  }
   // the device copy of the retained scan is (re)uploaded lazily by the next update when the
   // matcher read the scan from pinned host memory
   h->d_retained_current = h->levels.size() > 1 && pts == h->d_retained;
@@ -1530,6 +1591,7 @@ static int update_impl(hsm_ctx* h, const float pose_world[3], const float* pts_x
   }
   if (int rc = launch_update_apply(h, batch)) return rc;
   for (size_t l = 0; l < h->levels.size(); ++l) update_applied(h, batch, prep[l]);
+  h->queued_update = h->async_update;
   if (slot >= 0) {
     HIP_TRY(hipEventRecord(h->upd_evt[slot], h->stream));
     h->upd_busy[slot] = true;
@@ -1544,6 +1606,7 @@ int hsm_synchronize(hsm_ctx* h) {
   if (int rc = select_device(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->upd_busy[0] = h->upd_busy[1] = false;
+  h->queued_update = false;
   return HSM_OK;
 }
 
