@@ -99,6 +99,97 @@ def algorithmic_bytes_per_iteration(n_beams: int) -> int:
     return 24 * n_beams + 60  # 8 B endpoint + 4 x 4 B samples per beam; 12 B pose in + 48 B H,dTr out
 
 
+# ---- the ONE line the driver parses ------------------------------------------------------------------------------------------
+# Round 4's line had grown to 24.6 KB (five configs, three parity modes, counter dumps) and the driver could not parse it.  The
+# last stdout line is now a compact record (< 4 KB, checked by tests/test_bench_line.py); everything else goes to a details
+# file next to it.
+LINE_LIMIT = 4096
+_ROOF_KEYS = ("kernel", "kernel_ms", "bound", "unit", "achieved", "peak", "frac", "traffic")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "bit_identical_pose_fraction", "max_abs_dxy_m", "max_abs_dtheta_rad",
+             "parity_sample", "host_cpu", "ms_per_step", "max_abs_dxy_m_vs_gpu", "max_abs_dev_vs_gpu", "latency_us")
+_CFG_KEYS = ("workload", "batch_per_gpu", "global_batch", "beams", "map", "levels", "gn_iterations_per_scan", "parallelism", "parity_mode")
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def compact_line(out: dict, details_path) -> str:
+    """The driver's record: the contract keys + roofline + cpu_baseline, nothing nested deeper than one level, < LINE_LIMIT bytes."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = {k: _short(cfg[k], 220) for k in _CFG_KEYS if k in cfg}
+    kern = cfg.get("kernel")
+    if isinstance(kern, dict):
+        line["config"]["parity_effective"] = kern.get("parity_effective")
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        r = {k: rf.get(k) for k in _ROOF_KEYS if k in rf}
+        hbm = rf.get("hbm") or {}
+        if hbm.get("frac") is not None:
+            r["hbm_frac"] = hbm["frac"]
+            r["traffic_over_algorithmic"] = hbm.get("traffic_over_algorithmic")
+        con = rf.get("contract") or {}
+        if con.get("frac") is not None:
+            r["contract_8d"] = {"bound": "hbm", "achieved": con.get("achieved"), "peak": con.get("peak"), "unit": con.get("unit"), "frac": con["frac"]}
+        if rf.get("counter_source"):
+            r["counter_source"] = _short(rf["counter_source"], 120)
+        line["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: _short(cb[k], 200) for k in _CPU_KEYS if k in cb}
+    for k in ("matchdata_per_s", "match_ms", "update_ms"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    ur = out.get("update_roofline")
+    if isinstance(ur, dict):
+        line["update_roofline"] = {k: ur.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel_time_us") if k in ur}
+    fm = out.get("fast_mode")
+    if isinstance(fm, dict) and fm.get("value") is not None:
+        line["fast_mode_value"] = fm["value"]
+    line["details"] = details_path
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT:  # never exceed the limit: shed the optional blocks, longest first
+        for k in ("update_roofline", "fast_mode_value", "matchdata_per_s"):
+            line.pop(k, None)
+        line["config"] = {k: _short(v, 80) for k, v in line["config"].items()}
+        if "cpu_baseline" in line:
+            line["cpu_baseline"] = {k: _short(v, 80) for k, v in line["cpu_baseline"].items() if k in ("value", "unit", "cores", "kind", "sample")}
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
+
+
+def details_file(out: dict):
+    """where the full record goes: gpurun_out/ on the GPU box (merged back by gpurun), overridable with HSM_BENCH_DETAILS"""
+    path = os.environ.get("HSM_BENCH_DETAILS")
+    if not path:
+        n = out.get("n_gpus", 1)
+        tag = (os.environ.get("HSM_BENCH_TAG") or "").strip()
+        path = os.path.join(ROOT, "gpurun_out", f"bench_details{('_' + tag) if tag else ''}{('_n%d' % n) if n and n > 1 else ''}.json")
+    return path
+
+
+def emit(out: dict):
+    """Top-level result: full record -> details file, compact record -> the LAST stdout line.  A child leg of another bench.py
+    (run_child sets HSM_BENCH_CHILD=1) prints its full record for the parent to embed."""
+    if os.environ.get("HSM_BENCH_CHILD") == "1":
+        print(json.dumps(out))
+        return
+    path = details_file(out)
+    rel = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError as e:
+        rel = f"(not written: {e})"
+    sys.stdout.flush()
+    print(compact_line(out, rel), flush=True)
+
+
 def make_inputs(rank: int, batch: int, n_build: int = 200):
     """Deterministic world, map-building scans and this rank's query batch (distinct per rank).  The child legs of one run
     (counter passes, pyramid, pipelined) re-use what the parent generated: HSM_BENCH_INPUT_CACHE names a directory the parent
@@ -434,7 +525,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
                                    "sample": f"{n_cpu} match+update steps of the same trajectory, {dtc:.1f} s",
                                    "ms_per_step": dtc / n_cpu * 1e3, "max_abs_dxy_m_vs_gpu": dmax}
-        print(json.dumps(out))
+        emit(out)
         return
 
     # map built from ground-truth posed scans by the product's own update kernels
@@ -571,7 +662,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
                                    "sample": f"{n_cpu} matchData calls, warm cache, {dtc:.1f} s",
                                    "latency_us": dtc / n_cpu * 1e6, "max_abs_dev_vs_gpu": d}
-        print(json.dumps(out))
+        emit(out)
         return
 
     # batched workloads (config3pyr, config4); N > 1: weak scaling, one all-gather of the [B,3] poses per launch
@@ -713,7 +804,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             da = np.abs(cpu_pose.astype(np.float64) - auto_pose[:n_cpu])
             out["cpu_baseline"]["default_mode_frac_within_1e-4"] = float((da[:, :2].max(1) <= 1e-4).mean())
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 # ---- in-run counters: bench.py re-executes itself (`--leg pmc`) under rocprofv3, one pass per counter group -------------
@@ -758,6 +849,7 @@ def run_child(extra_args, timeout_s=300, env=None):
     """a leg of this script in a child process; returns the dict it printed as its last stdout line"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + extra_args
+    env = dict(os.environ if env is None else env, HSM_BENCH_CHILD="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
@@ -911,12 +1003,6 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
                                 "frac_at_measured_clock": rf["achieved"] / (1024 * sclk_hz / 2 / 1e9),
                                 "source": "s_memtime vs the 100 MHz wall clock over the lifetime of the wave of scan 0 in the last "
                                           "timed launch (hsm_set_clock_probe)"}
-    if rf.get("achieved"):
-        # what a stream of NOTHING BUT independent v_mul_f32 / v_add_f32 sustains on this part with the kernel's occupancy
-        # (tools/ubench_valu.hip, 4 wavefronts per SIMD, 30 back-to-back launches): 1.9 shader cycles per instruction, but the
-        # engine clock settles at 1.5-1.7 GHz under that load, so the chip issues 875-917 G wave64 instr/s, not 1228.8.
-        rf["sustained_valu_stream"] = {"G_wave64_instr_per_s": 900.0, "frac": rf["achieved"] / 900.0,
-                                       "source": "profiles/r03/ubench_valu.jsonl (measured once on MI355X; not re-measured in this run)"}
     return rf
 
 
@@ -993,7 +1079,7 @@ def group_leg(args):
            "timing": "host wall clock around K asynchronous hsm_group_match_batch_device calls + hsm_group_synchronize (includes the hand-off to the "
                      "group's persistent worker threads)"}
     grp.close()
-    print(json.dumps(out))
+    emit(out)
 
 
 def group_child_from_rank0(args, world, dist):
@@ -1044,7 +1130,10 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream leg")
     ap.add_argument("--compact", action="store_true",
                     help="extra workloads: the short form the default run embeds (fewer steps, smaller CPU samples)")
-    ap.add_argument("--no-configs", action="store_true", help="skip the legs for the other BASELINE configs")
+    ap.add_argument("--no-configs", action="store_true", help="(--all-configs) skip the legs for the other BASELINE configs")
+    ap.add_argument("--all-configs", "--full", dest="all_configs", action="store_true",
+                    help="the long run: 8(d)-start leg, relaxed leg, all-cores CPU leg, pyramid, pipelined and the other BASELINE configs, all into "
+                         "the details file (the default run keeps the headline, its counters, the fast-mode leg and the 1-thread CPU baseline: ~45 s)")
     ap.add_argument("--no-relaxed", action="store_true", help="skip the HSM_PARITY_RELAXED leg")
     ap.add_argument("--leg", default=None, choices=["pmc", "pyramid", "pipelined", "8d"],
                     help="internal: a leg of the default run executed in a child process")
@@ -1314,6 +1403,28 @@ def main():
 
     pmc_all = pmc_err = None
     want_pmc = rank == 0 and world == 1 and not args.no_pmc and B == BATCH_PER_GPU and args.levels == 1
+    single = rank == 0 and world == 1
+    fast_leg = None
+    if single and not args.no_exact:
+        # the fast tree (HSM_PARITY_FAST): the throughput form of rounds 1-3, opt-in since round 4 (timed BEFORE the CPU thread starts)
+        matcher.set_parity(capi.PARITY_FAST)
+        dtf, kf, _ = run(matcher, d_in, args.steps, 3, repeats=min(args.repeats, 3))
+        fast_leg = (dtf, kf, d_pose.cpu().numpy().copy(), matcher.last_launch_config(), getattr(run, "regions", None), getattr(run, "sclk_hz", None))
+        matcher.set_parity(capi.PARITY_AUTO)
+    # the 1-thread CPU baseline runs on a host thread WHILE the counter passes run in child processes (the C loop releases the
+    # GIL; the box has far more cores than the two need): the default run stays within ~45 s of wall clock
+    cpu_box = {}
+    cpu_thread = None
+    if single and not args.no_cpu:
+        import threading
+
+        def _cpu():
+            try:
+                cpu_box["v"] = cpu_baseline(build_poses, build_scans, h_in, pts, offs, gpu_pose, args.levels)
+            except Exception as e:  # never lose the line to the baseline leg
+                cpu_box["v"] = {"error": str(e)[:300]}
+        cpu_thread = threading.Thread(target=_cpu)
+        cpu_thread.start()
     if want_pmc:
         if under_profiler():
             pmc_err = "this process already runs under a profiler"
@@ -1321,6 +1432,8 @@ def main():
             pmc_all, pmc_err = pmc_leg(["gn_match_exact_cached_kernel", "gn_match_exact_batch_kernel", fast_name, "gn_match_kernel"])
             pmc_dump(args.pmc_dump, "headline", pmc_all, pmc_err, "configs[2] headline batch (4096 x 1081 beams, 2048^2, level 0, 6 GN it), "
                      "start errors +-0.04 m / +-0.01 rad: default mode (exact order) and HSM_PARITY_FAST launches of the same child")
+    if cpu_thread is not None:
+        cpu_thread.join()
     pmc = (pmc_all or {}).get(kernel_name)
     rf = roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
                         sclk_hz=headline_sclk, committed_profile="r04")
@@ -1348,7 +1461,7 @@ def main():
     }
     if world > 1:
         out["ranks"] = getattr(run, "ranks", None)
-        if not args.no_group and os.environ.get("HSM_BENCH_SHARE_GPU") != "1":
+        if args.all_configs and not args.no_group and os.environ.get("HSM_BENCH_SHARE_GPU") != "1":
             # the C++ single-process group over the same devices, RCCL gather and peer gather (child of rank 0)
             rec = group_child_from_rank0(args, world, dist)
             if rank == 0:
@@ -1357,25 +1470,22 @@ def main():
     out["convergence"] = {"median_abs_err_xy_m": float(np.median(conv[:, :2])),
                           "median_abs_err_theta_rad": float(np.median(conv[:, 2]))}
 
-    single = rank == 0 and world == 1
     exact_pose = gpu_pose if cfg.get("parity_effective") == "exact" else None
-    if single and not args.no_exact:
-        # the fast tree (HSM_PARITY_FAST): the throughput form of rounds 1-3, now opt-in
-        matcher.set_parity(capi.PARITY_FAST)
-        dtf, kf, _ = run(matcher, d_in, args.steps, 3, repeats=min(args.repeats, 3))
-        fast_pose = d_pose.cpu().numpy().copy()
-        fcfg = matcher.last_launch_config()
-        frf = roofline_block(kernel_of(fcfg), kf, bytes_per_launch, N_BEAMS, its, B, (pmc_all or {}).get(kernel_of(fcfg)), None, clock_hz,
-                             sclk_hz=getattr(run, "sclk_hz", None))
+    full = bool(args.all_configs)
+    if fast_leg is not None:
+        dtf, kf, fast_pose, fcfg, fregions, fsclk = fast_leg
+        frf = roofline_block(kernel_of(fcfg), kf, bytes_per_launch, N_BEAMS, its, B, (pmc_all or {}).get(kernel_of(fcfg)), None, clock_hz, sclk_hz=fsclk)
         out["fast_mode"] = {"mode": "HSM_PARITY_FAST: lane-strided partial sums + folded wave tree (per-beam terms bit-exact, summation "
                                     "order differs); opt-in since round 4", "value": B * its * args.steps / dtf, "unit": "GN it/s",
-                            "kernel_ms": kf, "ms_per_step": dtf / args.steps * 1e3, "kernel": kernel_of(fcfg), "timed_regions": getattr(run, "regions", None),
+                            "kernel_ms": kf, "ms_per_step": dtf / args.steps * 1e3, "kernel": kernel_of(fcfg), "timed_regions": fregions,
                             "roofline": {k: v for k, v in frf.items() if k in ("kernel", "kernel_ms", "bound", "unit", "achieved", "peak", "frac", "traffic",
-                                                                               "hbm", "valu", "clock_measured", "sustained_valu_stream", "counter_source")}}
+                                                                               "hbm", "valu", "clock_measured", "counter_source")}}
         if exact_pose is not None:
             out["fast_mode"]["fast_vs_default_all_scans"] = pose_stats(fast_pose, exact_pose)
-        matcher.set_parity(capi.PARITY_AUTO)
-    if single and not args.no_exact and args.levels == 1 and B == BATCH_PER_GPU:
+    if "v" in cpu_box:
+        out["cpu_baseline"] = cpu_box["v"]
+        out["cpu_baseline"]["concurrent_with"] = "the rocprofv3 counter passes of this run (child processes on other cores)" if want_pmc and not under_profiler() else None
+    if full and single and not args.no_exact and args.levels == 1 and B == BATCH_PER_GPU:
         # the same batch from SURVEY 8(d)'s start errors (child process: `--leg 8d`), with the counters of its launches
         leg = run_child(["--leg", "8d", "--steps", str(max(10, args.steps // 2)), "--batch", str(B), "--repeats", str(args.repeats)] +
                         (["--no-cpu"] if args.no_cpu else []))
@@ -1390,7 +1500,7 @@ def main():
             if e8:
                 leg["pmc_errors"] = e8
         out["headline_8d_starts"] = leg
-    if single and not args.no_relaxed and args.levels == 1:
+    if full and single and not args.no_relaxed and args.levels == 1:
         # HSM_PARITY_RELAXED (opt-in): multiply-add pairs of the per-beam arithmetic contracted; bar = 1e-4 m / 1e-4 rad
         matcher.set_parity(capi.PARITY_RELAXED)
         steps_r = max(10, args.steps // 4)
@@ -1406,17 +1516,16 @@ def main():
             out["relaxed"]["vs_default_all_scans"] = pose_stats(relaxed_pose, exact_pose)
         if not args.no_cpu:
             out["relaxed"]["parity_vs_cpu"] = cpu_baseline(build_poses, build_scans, init, pts, offs, relaxed_pose, 1, budget_s=0.0, n_par=512)
-    if single and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(build_poses, build_scans, h_in, pts, offs, gpu_pose, args.levels)
+    if full and single and not args.no_cpu:
         out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(build_poses, build_scans, h_in, pts, offs, args.levels)
-    if single and not args.no_pyramid and args.levels == 1:
+    if full and single and not args.no_pyramid and args.levels == 1:
         out["pyramid"] = run_child(["--leg", "pyramid", "--steps", str(max(10, args.steps // 4)), "--batch", str(B)] +
                                    (["--no-cpu"] if args.no_cpu else []))
-    if single and not args.no_pipelined and args.levels == 1:
+    if full and single and not args.no_pipelined and args.levels == 1:
         out["pipelined"] = run_child(["--leg", "pipelined", "--steps", str(max(40, args.steps)), "--batch", str(B),
                                       "--streams", str(args.streams)])
-    if single and not args.no_configs and args.levels == 1 and B == BATCH_PER_GPU:
-        # the other BASELINE configs in the same line: compact child runs, each with its own counter passes
+    if full and single and not args.no_configs and args.levels == 1 and B == BATCH_PER_GPU:
+        # the other BASELINE configs in the details file: compact child runs, each with its own counter passes
         matcher.close()
         del matcher
         torch.cuda.empty_cache()
@@ -1426,11 +1535,13 @@ def main():
         for key, wl in (("configs[1]", "config2"), ("configs[3] (one GPU's share)", "config4"), ("configs[4] (one replica)", "config5")):
             cf[key] = run_child(["--workload", wl] + extra, timeout_s=400)
         out["configs"] = cf
+    if not full and single:
+        out["not_run"] = "the 8(d)-start, relaxed, all-cores, pyramid, pipelined and other-config legs: `bench.py --all-configs` (details file)"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def config1_plumbing(capi):

@@ -104,6 +104,8 @@ SIGNATURES = {
     "hsm_match_level": (_i, [_vp, _i, _f32p, _vp, _i, _i, _f32p, _f32p]),
     "hsm_debug_set_update_serial": (_i, [_vp, _i, C.c_uint]),
     "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
+    "hsm_debug_set_coop_mute": (_i, [_vp, _i]),
+    "hsm_debug_coop_fallbacks": (_i, [_vp]),
     "hsm_debug_marks_nonzero": (_i, [_vp, _i, _vp]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
@@ -533,6 +535,12 @@ class MapRepMultiMap:
 
     def debug_set_coop_barrier(self, value):
         _check(self._lib.hsm_debug_set_coop_barrier(self._h, int(value) & 0xffffffff), "hsm_debug_set_coop_barrier")
+
+    def debug_set_coop_mute(self, block_plus_one):
+        _check(self._lib.hsm_debug_set_coop_mute(self._h, int(block_plus_one)), "hsm_debug_set_coop_mute")
+
+    def debug_coop_fallbacks(self):
+        return int(self._lib.hsm_debug_coop_fallbacks(self._h))
 
     def match_level(self, level, begin_world, pts_level, max_iter, cov=None):
         a, p, n = _pts(pts_level)

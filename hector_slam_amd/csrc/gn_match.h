@@ -110,6 +110,8 @@ struct MatchParams {
   int xcd_chunk;             // workgroup -> scan mapping (xcd_block): 0 = one contiguous eighth of the batch per XCD,
                              // c > 0 = chunks of c workgroups dealt to the XCDs in turn
   int wg_sync;               // texel-cache form: the waves of a workgroup meet at a barrier before every beam (L1 sharing)
+  int coop_mute_block;       // test hook (hsm_debug_set_coop_mute): 1 + the workgroup of the multi-workgroup matcher that never
+                             // publishes its records, 0 = none -- how the suite provokes the exchange timeout
   unsigned long long* clock_probe;  // nullptr, or four words the wave of scan 0 fills: shader-clock counter (s_memtime)
                                     // and 100 MHz wall clock at its first GN step [0,1] and at its end [2,3]
 };
@@ -717,8 +719,12 @@ __device__ __forceinline__ void rotate_wave_priority(int step) {
 // independent and issue back to back (latency hiding by ILP, not only by occupancy).  The
 // per-lane summation order (ascending beam index) is the same as the memory loop's, so both
 // forms produce identical bits.  Longer scans (or BPL == 0) take the memory loop.
+// Occupancy the kernel is BUILT for (and test_kernel_resources.py asserts): four waves per SIMD, except the exact-order teams
+// of two and four wavefronts -- they keep a whole group of rounds alive at once (five endpoints, five texels, five rotated
+// points per lane: ~150 VGPRs) and stage it in 23 / 46 KB of LDS, and they are latency launches (one team per scan, chosen only
+// when the batch cannot fill the chip), so three waves per SIMD is what they get and what they ask for.
 template <int WPS, int SPB, int LAYOUT, int BPL, bool EXACT = false>
-__global__ void __launch_bounds__(64 * WPS * SPB, 4) gn_match_kernel(const MatchParams P) {
+__global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS == 2 || WPS == 4)) ? 3 : 4)) gn_match_kernel(const MatchParams P) {
   static_assert(WPS == 1 || SPB == 1, "barrier-synchronised teams own their workgroup");
   static_assert(!EXACT || BPL == 0, "the exact-order form streams the endpoints");
   constexpr int T = 64 * WPS;  // lanes per team
@@ -1621,6 +1627,8 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
 #endif
   __shared__ float red[4][9];
   __shared__ float tot[9];
+  __shared__ int gave_up;  // the exchange timed out in this workgroup: leave (ordered by the barriers of the step)
+  if (threadIdx.x == 0) gave_up = 0;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int K = (int)gridDim.x;
@@ -1668,7 +1676,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
       // it has read every workgroup's step-(s + 1) record, which that workgroup published after it finished reading step s.
       const unsigned tag = bar_base + (unsigned)step + 1u;
       f4v* const recs = reinterpret_cast<f4v*>(partials) + (size_t)(step & 1) * 64 * 3;
-      if (threadIdx.x < 3) {
+      if (threadIdx.x < 3 && P.coop_mute_block != (int)blockIdx.x + 1) {
         const int t0 = 3 * (int)threadIdx.x;
         f4v g;
         g.x = ((red[0][t0] + red[1][t0]) + red[2][t0]) + red[3][t0];
@@ -1699,6 +1707,9 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
               __hip_atomic_store(P.err_flag, P.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               __threadfence_system();
             }
+            // ... and leave: every other workgroup times out on this one's missing records in turn, so the launch ends after
+            // ONE bounded wait instead of one per remaining GN step (the host re-runs the scan on the one-workgroup matcher)
+            if (lane == 0) gave_up = 1;
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -1742,6 +1753,7 @@ __global__ void __launch_bounds__(256) gn_match_coop_kernel(const MatchParams P,
       }
       }
       __syncthreads();
+      if (TAGGED && gave_up) return;  // (workgroup-uniform)
       acc.d01 = f2{tot[0], tot[1]}; acc.d2 = tot[2];
       acc.hd = f2{tot[3], tot[4]}; acc.h22 = tot[5];
       acc.h01 = tot[6]; acc.hr = f2{tot[7], tot[8]};

@@ -11,7 +11,27 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <rccl/rccl.h>  // declarations only: librccl is dlopen'ed by the group entry points (rccl_api), never linked
+// RCCL: declarations only -- librccl is dlopen'ed by the group entry points (rccl_api), never linked.  A ROCm install without
+// the RCCL development headers still builds the library: the handful of prototypes the group gather uses are then declared
+// here (the stable NCCL 2.x C API; values as in nccl.h).
+#if __has_include(<rccl/rccl.h>) && !defined(HSM_NO_RCCL_HEADER)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int* version);
+}
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -192,9 +212,11 @@ struct hsm_ctx {
   bool dense_bits = true;        // env HSM_DENSE_BITS=0: dense scans keep the keyed update (map_update.h)
   bool exact_cached = true;      // env HSM_EXACT_CACHED=0: exact-mode batches keep round 2's producer / chain-wavefront form (gn_match.h)
   bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
-  bool auto_parity = true;  // HSM_PARITY_AUTO (default): batched matches on maps above 2^23 cells run in HSM_PARITY_EXACT, the rest FAST
+  bool auto_parity = true;  // HSM_PARITY_AUTO (default): every entry point in the reference's summation order (auto_wants_exact)
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
+  int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
+  unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
   int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
 };
 
@@ -450,20 +472,21 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   return HSM_OK;
 }
 
-// HSM_PARITY_AUTO (the default): every BATCHED match takes the reference's summation order.  Round 3's rule -- exact only on
-// maps of more than 2^23 cells -- was fitted to BASELINE's own scenes; the scene sweep of round 4 (tools/parity_scene_sweep.py,
-// profiles/r04/parity_scene_sweep.jsonl: six scene families on maps of up to 2^23 cells, 4096 scans each, three start / level
-// set-ups) finds the fast tree beyond 1e-4 m of the reference in every family for some set-up -- 0.02 % .. 0.3 % of the scans
-// with level-0-only matching from SURVEY 8(d)'s start errors, one scan in 4096 on 0.025 m cells from the headline's starts,
-// half the scans of a corridor (near-singular H) -- wherever the reference's own Gauss-Newton iteration has not settled.
-// No property of the map or the batch that the host knows at launch separates those scans, so the default does not try:
-// exact order for every batch (bit-identical to the reference on 100 % of the scans of every family), HSM_PARITY_FAST /
-// _RELAXED for callers who trade the guarantee for 34 % / 45 % more throughput (headline batch, profiles/r04).  Single scans
-// keep the fast tree: 256 / 256 within 1e-4 m in five of the six families and over a 5 000-scan node loop, at a quarter of
-// the exact single-scan form's latency.
-bool auto_wants_exact(const hsm_ctx* h, const MatchParams& P) {
-  return h->auto_parity && !h->relaxed && P.begin_world && !P.trace;
-}
+// HSM_PARITY_AUTO (the default): EVERY match -- batched, single scan, dense scan, and the likelihood / covariance / Hessian
+// entry points -- takes the reference's summation order: bit-identical to the reference CPU matcher on every entry point.
+// History: round 3 chose exact order only on maps of more than 2^23 cells (a rule fitted to BASELINE's own scenes); round 4's scene
+// sweep (tools/parity_scene_sweep.py, profiles/r04/parity_scene_sweep.jsonl) found the fast tree beyond 1e-4 m of the reference in
+// every scene family for some set-up -- wherever the reference's own Gauss-Newton iteration has not settled -- and no property of
+// the map or the batch known at launch separates those scans, so every batch went exact; single scans kept the tree on the evidence
+// of 256 scans per family, of which the corridor family already failed (0.83 within 1e-4 m).  Round 5: the same argument holds for
+// one scan as for 4096, so the default does not try there either.  HSM_PARITY_FAST / _RELAXED stay opt-in for callers who trade
+// the guarantee for speed (profiles/r05/README.md has the prices: batch +34 % / +45 %, single 1081-beam scan ~35 vs ~95 us).
+// AUTO differs from HSM_PARITY_EXACT in one respect only: AUTO may pick ANY form that is bit-identical to the reference's chain
+// (the serial chain today; a faster exact form when one exists), HSM_PARITY_EXACT always runs the literal serial chains.
+bool auto_wants_exact(const hsm_ctx* h, const MatchParams&) { return h->auto_parity; }
+// the effective summation order of the entry points that do not go through launch_match (staging decisions, likelihood,
+// covariance, Hessian probes)
+bool wants_exact(const hsm_ctx* h) { return h->exact || h->auto_parity; }
 
 template <int WPS, int SPB>
 int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
@@ -824,13 +847,17 @@ int launch_update_apply(hsm_ctx* h, const UpdateBatch& batch) {
 }
 
 // the apply pass of this level is queued behind its mark pass: its marks will be cleared.  A level whose box the host found
-// empty has no apply pass; by construction the device marked nothing there either (beam_line and level_bbox evaluate the
-// same fp32 expressions), but nothing checks that on the device, so such a level stays "pending" and is scrubbed before
-// its next update (two memsets, only after a scan that had no end point inside the map)
+// EMPTY has no apply pass and needs none: the box is the hull of every in-map end cell, computed by level_bbox() from the same
+// fp32 expressions the mark kernels evaluate (beam_line), and a beam whose end cell -- or the begin cell -- lies outside the map
+// is dropped whole on the device as in the reference (OccGridMapBase.h:176-188); the non-empty case already relies on that
+// equality (a mark outside the host's box would never be applied either).  Until round 4 such a level stayed "pending" and the
+// NEXT update scrubbed both mark planes and widened the key rows to the whole level -- tens of MB of memset per level and update
+// for as long as the robot stood outside a coarse level, or every scan was empty (round-4 advisor).  What remains pending is the
+// case the flag exists for: a HIP error between the mark launch and the apply launch (the caller sees the error; the next
+// update on the level scrubs first).
 void update_applied(hsm_ctx* h, const UpdateBatch& batch, const LevelPrep& prep) {
   if (prep.slot < 0) return;
-  const UpdateParams& P = batch.lv[prep.slot];
-  if (P.x1 >= P.x0) h->levels[prep.level].marks_pending = false;
+  h->levels[prep.level].marks_pending = false;
 }
 
 int select_device(const hsm_ctx* h) {
@@ -1285,7 +1312,8 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.done_flag = h->spin_wait ? reinterpret_cast<unsigned*>(hs_dev + kDoneFlagOff) : nullptr;
   P.done_seq = seq;
   P.err_flag = reinterpret_cast<unsigned*>(hs_dev + kErrFlagOff);
-  if (n >= h->coop_min_beams && h->wps_override == 0 && !h->exact) {
+  P.coop_mute_block = h->coop_mute_block;
+  if (n >= h->coop_min_beams && h->wps_override == 0 && !wants_exact(h)) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
     // one beam per lane.  16 k beams, matchData us for K = 16 / 24 / 32 / 64 workgroups: 79.8 / 71 / 66-70 / 64 with round 2's grid
@@ -1340,8 +1368,20 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   }
   if (int rc = wait_single_scan(h, seq)) return rc;
   h->queued_update = false;  // the match kernel was the last thing on `stream`, and it has completed
-  if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq)
-    return fail(HSM_ERR_HIP, "hsm_match: the cooperative matcher's inter-workgroup exchange timed out (a workgroup never published its partial sums); no pose");
+  if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq) {
+    // The multi-workgroup matcher's tagged exchange gave up waiting for a record: its K workgroups were not co-resident for
+    // ~2^22 polls (a device shared with another process, or a long kernel of another stream holding the CUs -- an ordinary
+    // launch carries no co-residency guarantee).  No pose was written.  The scan is matched again by the one-workgroup
+    // matcher, which needs no other workgroup to make progress -- same sums in a different tree, so the caller gets a pose
+    // within the fast mode's bar instead of an error (round-4 advisor); hsm_last_launch_config() then reports that form.
+    const unsigned seq2 = ++h->done_seq;
+    P.done_seq = seq2;
+    if (int rc = launch_match(h, P, n, h->stream)) return rc;
+    if (int rc = wait_single_scan(h, seq2)) return rc;
+    ++h->coop_fallbacks;
+    if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq2)
+      return fail(HSM_ERR_HIP, "hsm_match: exchange timeout flagged by the one-workgroup matcher (cannot happen: it has no exchange)");
+  }
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
   out_pose_world[1] = hs[4];
@@ -1356,7 +1396,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
 static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, size_t& d_cap, const float2** out) {
   // (a dense scan for the multi-workgroup matcher is re-read every GN step: it must live in device memory)
   // (and so does the exact-order form)
-  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !h->exact &&
+  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !wants_exact(h) &&
       (n < h->coop_min_beams || h->wps_override != 0)) {
     if ((size_t)n > h->h_scan_pinned_cap) {
       if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
@@ -1448,7 +1488,7 @@ static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_x
   const float2* pts = d_prestaged;
   if (!pts) {
     // (the same rule as stage_scan's: scans the matcher reads once stay in pinned host memory)
-    const bool to_device = !(n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !h->exact &&
+    const bool to_device = !(n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !wants_exact(h) &&
                              (n < h->coop_min_beams || h->wps_override != 0));
     // ... and only behind an update that was queued and not waited for (the match + update loop): on an idle stream the
     // extra hop through the copy stream's event costs ~10 us of latency and hides nothing (asking the runtime with
@@ -1833,9 +1873,9 @@ static int score_states(hsm_ctx* h, int level, int batch, const float* states_ma
   hipLaunchKernelGGL((likelihood_kernel<LAY, EX>), dim3(grid), dim3(256), 0, h->stream, v, d_states, batch, h->d_scan, \
                      n, factor, out_lh ? d_lh : nullptr, out_residual ? d_res : nullptr)
   if (h->layout == kLayoutPlane) {
-    if (h->exact) HSM_LAUNCH_LH(kLayoutPlane, true); else HSM_LAUNCH_LH(kLayoutPlane, false);
+    if (wants_exact(h)) HSM_LAUNCH_LH(kLayoutPlane, true); else HSM_LAUNCH_LH(kLayoutPlane, false);
   } else {
-    if (h->exact) HSM_LAUNCH_LH(kLayoutQuad, true); else HSM_LAUNCH_LH(kLayoutQuad, false);
+    if (wants_exact(h)) HSM_LAUNCH_LH(kLayoutQuad, true); else HSM_LAUNCH_LH(kLayoutQuad, false);
   }
 #undef HSM_LAUNCH_LH
   HIP_TRY(hipGetLastError());
@@ -1881,9 +1921,9 @@ int hsm_covariance_for_poses(hsm_ctx* h, int level, int batch, const float* pose
   hipLaunchKernelGGL((pose_covariance_kernel<LAY, EX>), dim3(batch), dim3(448), 0, h->stream, v, d_poses, batch, \
                      h->d_scan, n, factor, Lv.cell_length, d_map, d_world, d_lh7)
   if (h->layout == kLayoutPlane) {
-    if (h->exact) HSM_LAUNCH_COV(kLayoutPlane, true); else HSM_LAUNCH_COV(kLayoutPlane, false);
+    if (wants_exact(h)) HSM_LAUNCH_COV(kLayoutPlane, true); else HSM_LAUNCH_COV(kLayoutPlane, false);
   } else {
-    if (h->exact) HSM_LAUNCH_COV(kLayoutQuad, true); else HSM_LAUNCH_COV(kLayoutQuad, false);
+    if (wants_exact(h)) HSM_LAUNCH_COV(kLayoutQuad, true); else HSM_LAUNCH_COV(kLayoutQuad, false);
   }
 #undef HSM_LAUNCH_COV
   HIP_TRY(hipGetLastError());
@@ -2545,7 +2585,7 @@ int hsm_hessian_derivs(hsm_ctx* h, int level, const float pose_map[3], const flo
   if (n > 0) HIP_TRY(hipMemcpyAsync(h->d_scan, pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
   const LevelView v = level_view(h->levels[level], 1.0f, 1);
   float* d_out = h->d_small + 16;
-  if (h->exact) {
+  if (wants_exact(h)) {
     if (h->layout == kLayoutPlane)
       hipLaunchKernelGGL((gn_eval_kernel<kLayoutPlane, true>), dim3(1), dim3(1024), 0, h->stream, v, h->d_scan, n,
                          pose_map[0], pose_map[1], pose_map[2], d_out);
@@ -2597,6 +2637,19 @@ int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value) {
   HIP_TRY(hipMemcpy(h->d_partials + 2 * 64 * 12, &value, sizeof value, hipMemcpyHostToDevice));
   h->coop_bar_base = value;
   return HSM_OK;
+}
+
+int hsm_debug_set_coop_mute(hsm_ctx* h, int block_plus_one) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->coop_mute_block = block_plus_one;
+  return HSM_OK;
+}
+
+int hsm_debug_coop_fallbacks(hsm_ctx* h) {
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk(h->mu);
+  return (int)h->coop_fallbacks;
 }
 
 int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]) {

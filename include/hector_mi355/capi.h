@@ -326,6 +326,12 @@ int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]);
 /* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by
  * workgroups x GN steps per dense match and wraps at 2^32) */
 int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value);
+/* test hook: workgroup `block_plus_one - 1` of the multi-workgroup dense matcher (HSM_PARITY_FAST / _RELAXED, >= 4096 beams)
+ * never publishes its partial sums (0 = off) -- the exchange of every workgroup then times out, which is what a device that
+ * cannot keep the K workgroups co-resident looks like.  hsm_match handles that by matching the scan again on the
+ * one-workgroup matcher; hsm_debug_coop_fallbacks() counts how often it had to. */
+int hsm_debug_set_coop_mute(hsm_ctx* h, int block_plus_one);
+int hsm_debug_coop_fallbacks(hsm_ctx* h);
 /* device sincosf of n angles (glibc's algorithm, csrc/libm_exact.h) -- numerics test hook */
 int hsm_debug_sincos(hsm_ctx* h, int n, const float* x, float* s, float* c);
 /* device expf(x) and getGridProbability(x) = e/(e+1) of n values -- numerics test hook */

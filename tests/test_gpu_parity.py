@@ -695,10 +695,11 @@ def test_dense_scan_cooperative_matcher(capi, oracle_mod, pyramid_scene, kind):
             assert np.array_equal(bits(pq), bits(ref[q][0])) and np.array_equal(bits(cq), bits(ref[q][1])), (rep, q)
 
 
-def test_default_parity_mode_is_exact_for_batches_and_fast_for_single_scans(capi, oracle_mod, pyramid_scene, kind, monkeypatch):
-    """HSM_PARITY_AUTO (what a context starts in): every batched match runs in the reference's summation order -- poses and
-    covariances bit-identical to the reference, whatever the map size --, single scans keep the fast tree (within 1e-4);
-    hsm_last_launch_parity says which one ran; HSM_PARITY accepts its four words only"""
+def test_default_parity_mode_is_the_reference_order_on_every_entry_point(capi, oracle_mod, pyramid_scene, kind, monkeypatch):
+    """HSM_PARITY_AUTO (what a context starts in): batched matches, single-scan matchData (with and without the hook trace),
+    single-level matches and the Hessian probe all run in the reference's summation order -- poses, covariances, H and dTr
+    bit-identical to the reference (round 5; until round 4 single scans kept the tree); hsm_last_launch_parity says which
+    order ran; HSM_PARITY accepts its four words only"""
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
@@ -712,14 +713,33 @@ def test_default_parity_mode_is_exact_for_batches_and_fast_for_single_scans(capi
     pb, cb = g.match_batch(sc.query_init, pts, offs)
     cfg = g.last_launch_config()
     assert cfg["parity"] == "auto" and cfg["parity_effective"] == "exact", cfg
-    for q in range(len(sc.query_scans)):
-        po, co = o.match(sc.query_init[q], sc.query_scans[q])
+    ref = [o.match(sc.query_init[q], sc.query_scans[q]) for q in range(len(sc.query_scans))]
+    for q, (po, co) in enumerate(ref):
         assert np.array_equal(bits(pb[q]), bits(po)) and np.array_equal(bits(cb[q]), bits(co)), q
     p1, _ = g.match_batch(sc.query_init[:1], *synth.pack_scans(sc.query_scans[:1]))  # a batch of one is a batch
     assert g.last_launch_config()["parity_effective"] == "exact" and np.array_equal(bits(p1[0]), bits(pb[0]))
+    for q, (po, co) in enumerate(ref):  # the reference's own entry point: one scan, MapRepMultiMap::matchData
+        ps, cs = g.matchData(sc.query_init[q], sc.query_scans[q])
+        assert g.last_launch_config()["parity_effective"] == "exact"
+        assert np.array_equal(bits(ps), bits(po)) and np.array_equal(bits(cs), bits(co)), ("single scan", q, ps, po)
+    import ctypes as C
+    lib = capi.load_library()
+    a = np.ascontiguousarray(sc.query_scans[0], np.float32)
+    pt, ct, trace, nst = np.zeros(3, np.float32), np.zeros(9, np.float32), np.zeros(14 * 12, np.float32), C.c_int(0)
+    capi._check(lib.hsm_match_trace(g._h, sc.query_init[0], a.ctypes.data, a.shape[0], np.zeros(2, np.float32), pt, ct, trace, 14,
+                                    C.byref(nst)), "hsm_match_trace")
+    assert np.array_equal(bits(pt), bits(ref[0][0])) and np.array_equal(bits(ct), bits(ref[0][1])), "hook-trace form"
+    pl, cl = g.match_level(0, sc.query_init[1], sc.query_scans[1], 5)
+    pol, col = o.match_level(0, sc.query_init[1], sc.query_scans[1], 5)
+    assert np.array_equal(bits(pl), bits(pol)) and np.array_equal(bits(cl), bits(col)), "single-level matchData"
+    pm = o.map_coords_pose(0, ref[0][0])
+    Hg, dg = g.hessian_derivs(0, pm, sc.query_scans[0])
+    Ho, do = o.hessian_derivs(0, pm, sc.query_scans[0])
+    assert np.array_equal(bits(Hg), bits(Ho)) and np.array_equal(bits(dg), bits(do)), "getCompleteHessianDerivs probe"
+    g.set_parity(capi.PARITY_FAST)
     ps, _ = g.matchData(sc.query_init[0], sc.query_scans[0])
     assert g.last_launch_config()["parity_effective"] == "fast"
-    assert_pose_close(ps, pb[0], "single scan (fast tree) vs the batch's exact result")
+    assert_pose_close(ps, pb[0], "single scan (fast tree, opt-in) vs the default's exact result")
     g.close()
     for word, ok in (("exact", True), ("fast", True), ("relaxed", True), ("auto", True), ("Exact", False), ("1", False)):
         monkeypatch.setenv("HSM_PARITY", word)
@@ -767,6 +787,36 @@ def test_dense_matcher_exchange_forms_agree(capi, pyramid_scene, monkeypatch):
         g.close()
     for a, b in zip(got["1"], got["0"]):
         assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_dense_matcher_exchange_timeout_falls_back_to_the_one_workgroup_matcher(capi, pyramid_scene):
+    """a workgroup of the multi-workgroup dense matcher that never publishes its records (test hook; in the field: K
+    workgroups that cannot become co-resident) makes every workgroup's exchange time out -- ONE bounded wait, then the launch
+    ends -- and hsm_match matches the scan again on the one-workgroup matcher instead of returning an error (round-4
+    advisor): a pose within the fast mode's bar, the fallback counted, and the exchange works again afterwards"""
+    import time
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    pts = synth.make_scan(sc.world, sc.query_truth[1], 8192, s, np.random.default_rng(79))
+    g = make_gpu(capi, sc)
+    p0, c0 = g.matchData(sc.query_init[1], pts)
+    assert g.last_launch_config()["waves_per_scan"] < 0 and g.debug_coop_fallbacks() == 0
+    g.debug_set_coop_mute(3)  # workgroup 2 stays silent
+    t0 = time.perf_counter()
+    p1, c1 = g.matchData(sc.query_init[1], pts)
+    dt = time.perf_counter() - t0
+    assert g.debug_coop_fallbacks() == 1
+    assert g.last_launch_config()["waves_per_scan"] == 16, g.last_launch_config()  # one workgroup of 16 wavefronts
+    assert_pose_close(p1, p0, "fallback vs the cooperative result")
+    assert np.abs(c1 - c0).max() <= 1e-4 * np.abs(c0).max()
+    assert dt < 60.0, dt  # one timeout, not one per remaining GN step
+    print(f"exchange timeout + fallback: {dt:.2f} s")
+    g.debug_set_coop_mute(0)
+    p2, c2 = g.matchData(sc.query_init[1], pts)
+    assert g.last_launch_config()["waves_per_scan"] < 0 and g.debug_coop_fallbacks() == 1
+    assert np.array_equal(bits(p2), bits(p0)) and np.array_equal(bits(c2), bits(c0))
+    g.close()
 
 
 def test_update_serial_wrap_is_bit_exact(capi, oracle_mod, pyramid_scene, kind):

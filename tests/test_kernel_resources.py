@@ -169,3 +169,48 @@ def test_no_register_of_an_inflight_gather_is_touched(device_asm):
         assert len(re.findall(r"global_load_dwordx[24]", body)) >= 5, kernel  # the gathers are there (x4 texels, x2 plane pairs)
         bad = gather_contract_violations(body)
         assert not bad, (kernel, bad[:5])
+
+
+# ---- achieved occupancy of EVERY matcher instantiation the launch helpers can reach -----------------------------------------
+# Round 4 shipped four exact single-scan instantiations that reached three waves per SIMD where their __launch_bounds__ asked
+# for four (a compiler warning nobody looked at).  Since round 5 the build fails on that warning (-Werror=pass-failed) and this
+# test states the table: what each form is built for, against the `; Occupancy:` the compiler reports for it.
+def occupancies(asm):
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"^(_ZN3hsm\w+):\s*;\s*@\1.*?; Occupancy: (\d+)", asm, re.S | re.M)}
+
+
+def designed_waves_per_simd(name):
+    m = re.search(r"15gn_match_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELb([01])E", name)
+    if m:  # gn_match.h: four, except the exact-order teams of two / four wavefronts (a group of five rounds alive: three)
+        wps, spb, exact = int(m.group(1)), int(m.group(2)), m.group(3) == "1"
+        return 3 if (exact and spb == 1 and wps in (2, 4)) else 4
+    m = re.search(r"22gn_match_cached_kernelILi\d+ELi\d+ELi\d+ELi(\d+)ELb[01]E", name)
+    if m:
+        return 5 if int(m.group(1)) > 1 else 4
+    if "28gn_match_exact_cached_kernel" in name:
+        return 4
+    if "20gn_match_coop_kernel" in name:
+        return 1  # one workgroup per CU by design (K <= 64 workgroups on 256 CUs)
+    return None
+
+
+def test_build_fails_on_a_missed_occupancy_target():
+    from hector_slam_amd import build
+    assert "-Werror=pass-failed" in build.FLAGS
+
+
+def test_every_matcher_instantiation_reaches_its_designed_occupancy(device_asm):
+    occ = occupancies(device_asm)
+    assert len(occ) > 100
+    seen = 0
+    for name, waves in occ.items():
+        want = designed_waves_per_simd(name)
+        if want is None:
+            continue
+        seen += 1
+        assert waves >= want, (name, waves, want)
+    assert seen >= 80, seen  # the team forms (6 widths x 2 layouts x BPL), the texel-cache forms, the exact forms, the dense matcher
+    # the forms the default mode launches: exact single scan on four wavefronts, the exact batch form, the exact dense team
+    for need in ("15gn_match_kernelILi4ELi1ELi1ELi0ELb1E", "15gn_match_kernelILi4ELi1ELi2ELi0ELb1E", "15gn_match_kernelILi16ELi1ELi2ELi0ELb1E",
+                 "28gn_match_exact_cached_kernelILi4ELi17ELi15E"):
+        assert any(need in n for n in occ), need

@@ -7,6 +7,8 @@ start coordinates, laser origin and a short SLAM run from an empty map.
 
 Every example is a whole match/update loop, so the number of examples is kept small; the strategies draw the
 structure (sizes, levels, seeds), the worlds and scans come from hector_slam_amd.synth."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, seed, settings
@@ -107,14 +109,20 @@ def test_restatement_equals_reference_for_random_geometries(oracle_mod, g):
     print(f"cond(H) of the last step: {cond}")
 
 
+# CI keeps 12 / 10 examples; the round-end GPU script sets HSM_HYPOTHESIS_EXAMPLES=60 (round-4 verdict: >= 50 behind a knob)
+GPU_EXAMPLES = int(os.environ.get("HSM_HYPOTHESIS_EXAMPLES", "0"))
+
+
 @pytest.mark.gpu
-@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=GPU_EXAMPLES or 12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=geometry)
-def test_gpu_exact_mode_equals_reference_for_random_geometries(oracle_mod, g):
+def test_gpu_default_mode_equals_reference_for_random_geometries(oracle_mod, g):
+    """the library DEFAULT (HSM_PARITY_AUTO; no parity argument): every pose, covariance and map of the loop bit-identical"""
     from hector_slam_amd import capi
 
     def make_gpu(res, size, levels, start, free, occ):
-        m = capi.MapRepMultiMap(res, size, size, levels, start, parity=capi.PARITY_EXACT)
+        m = capi.MapRepMultiMap(res, size, size, levels, start)
+        assert m.parity() == capi.PARITY_AUTO
         m.setUpdateFactorFree(free)
         m.setUpdateFactorOccupied(occ)
         return {"match": lambda h, sc, og: m.matchData(h, sc, None, og), "update": lambda p, sc, og: m.updateByScan(sc, p, og),
@@ -133,7 +141,7 @@ def test_restatement_equals_reference_for_dense_scans_at_the_borders(oracle_mod,
 
 @pytest.mark.gpu
 @seed(DENSE_SEED)
-@settings(max_examples=10, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=GPU_EXAMPLES or 10, deadline=None, database=None, suppress_health_check=list(HealthCheck))
 @given(g=dense_geometry)
 def test_gpu_dense_update_equals_reference_at_the_borders(oracle_mod, g):
     """exact mode: every pose, covariance and map of the loop bit-identical to the reference, and after every update the
