@@ -381,43 +381,58 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         poses, scans = allp[n_init:], alls[n_init:]
         # update-heavy single-scan use: the plane layout (4 gathers per beam, no texel plane to maintain)
         lay = capi.LAYOUT_QUAD if os.environ.get("HSM_LAYOUT") == "quad" else capi.LAYOUT_PLANE
-        m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank, layout=lay)
-        m.setUpdateFactorFree(0.4)
-        m.setUpdateFactorOccupied(0.9)
-        for k in range(n_init + 1):
-            m.matchData(allp[k], alls[k])      # retains the coarse-level containers (result unused)
-            m.updateByScan(alls[k], allp[k])
-            m.onMapUpdated()
-        pose = poses[0]
-        gpu_poses = []
         # N > 1 (configs[4] on a node): one dense scan does not shard -- every rank holds a replica of the pyramid,
         # rank 0 matches, ONE broadcast carries pose + scan, every rank replays the (deterministic) update
         sync = sharding.ReplicaSync(beams, dev) if nranks > 1 else None
         lib = capi.load_library()
-        for t in range(1, T + 1):
-            if t == args.warmup + 1:
+
+        def run_traj(parity=None):
+            """the whole trajectory on a fresh context in the given parity mode (None = the library default); -> context, poses, s"""
+            m = capi.MapRepMultiMap(res, size, size, levels, device=local_rank, layout=lay, **({} if parity is None else {"parity": parity}))
+            m.setUpdateFactorFree(0.4)
+            m.setUpdateFactorOccupied(0.9)
+            for k in range(n_init + 1):
+                m.matchData(allp[k], alls[k])      # retains the coarse-level containers (result unused)
+                m.updateByScan(alls[k], allp[k])
+                m.onMapUpdated()
+            pose = poses[0]
+            gpu_poses = []
+            for t in range(1, T + 1):
+                if t == args.warmup + 1:
+                    m.synchronize()
+                    if nranks > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                if rank == 0:
+                    hint = pose + (poses[t] - poses[t - 1])
+                    pose, _ = m.matchData(hint, scans[t])
+                    scan_t = scans[t]
+                    if sync:
+                        sync.broadcast(pose, scan_t)
+                else:
+                    pose, scan_t = sync.broadcast(None, None)
+                    a = np.ascontiguousarray(scan_t, np.float32)  # what rank 0's matchData retained for the coarse levels
+                    capi._check(lib.hsm_retain_scan(m._h, a.ctypes.data, a.shape[0], np.zeros(2, np.float32)), "hsm_retain_scan")
+                m.updateByScan(scan_t, pose)     # returns when queued; the next matchData waits behind it
+                m.onMapUpdated()
+                gpu_poses.append(pose)
+            m.synchronize()  # the last update is only queued when updateByScan returns
+            if nranks > 1:
+                dist.barrier()
+            return m, gpu_poses, time.perf_counter() - t0
+
+        def match_alone(m, gpu_poses):
+            """matchData alone on the finished map (device idle before each call): median host-call seconds"""
+            tm = []
+            for t in range(max(1, T - 9), T + 1):
                 m.synchronize()
-                if nranks > 1:
-                    dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            if rank == 0:
-                hint = pose + (poses[t] - poses[t - 1])
-                pose, _ = m.matchData(hint, scans[t])
-                scan_t = scans[t]
-                if sync:
-                    sync.broadcast(pose, scan_t)
-            else:
-                pose, scan_t = sync.broadcast(None, None)
-                a = np.ascontiguousarray(scan_t, np.float32)  # what rank 0's matchData retained for the coarse levels
-                capi._check(lib.hsm_retain_scan(m._h, a.ctypes.data, a.shape[0], np.zeros(2, np.float32)), "hsm_retain_scan")
-            m.updateByScan(scan_t, pose)     # returns when queued; the next matchData waits behind it
-            m.onMapUpdated()
-            gpu_poses.append(pose)
-        m.synchronize()  # the last update is only queued when updateByScan returns
-        if nranks > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+                a = time.perf_counter()
+                m.matchData(gpu_poses[t - 1], scans[t])
+                tm.append(time.perf_counter() - a)
+            return float(np.median(tm))
+
+        m, gpu_poses, dt = run_traj(capi.PARITY_FAST if os.environ.get("HSM_BENCH_CONFIG5_PARITY") == "fast" else None)
         if args.leg == "pmc":  # counter pass of the parent: the launches above are all it wants
             m.close()
             torch.cuda.synchronize()
@@ -439,13 +454,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             return
         # attribution: matchData alone on the finished map (device idle before each call); the update's share
         # of a step is the rest
-        tm = []
-        for t in range(max(1, T - 9), T + 1):
-            m.synchronize()
-            a = time.perf_counter()
-            m.matchData(gpu_poses[t - 1], scans[t])
-            tm.append(time.perf_counter() - a)
-        t_match = float(np.median(tm)) * args.steps
+        t_match = match_alone(m, gpu_poses) * args.steps
         t_upd = dt - t_match
         nb = float(np.mean([s_.shape[0] for s_ in scans[1:]]))
         # what one updateByScan touches (16 B per distinct touched cell + 8 B per beam): one more update,
@@ -480,7 +489,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                "time_basis": "update_ms of the step (host timed: step - matchData)", "traffic": None, "kernels": None}
         if not args.no_pmc and nranks == 1 and not under_profiler():
             names = ["update_mark_occ_dense_kernel", "update_mark_occ_kernel", "update_mark_free_dense_kernel", "update_apply_dense_kernel", "update_mark_free_kernel",
-                     "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel"]
+                     "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel", "gn_match_kernel"]
             pv, perr = pmc_collect(["--workload", "config5", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=2)
             pmc_dump(args.pmc_dump, "config5", pv, perr, "configs[4] replica: 16 k-beam scans on the 8192^2 pyramid, match + update per step (plane layout)")
             if pv:
@@ -504,6 +513,18 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             if perr:
                 upd["pmc_errors"] = perr
         out["update_roofline"] = upd
+        out["config"]["parity_mode"] = f"library default (HSM_PARITY_AUTO) -> {m.last_launch_config().get('parity_effective')} summation (single-scan entry point)"
+        if nranks == 1 and not args.no_exact and m.last_launch_config().get("parity_effective") == "exact":
+            # the opt-in tree summation beside it: the multi-workgroup dense matcher (HSM_PARITY_FAST), same trajectory, fresh context
+            m.close()
+            mf, poses_f, dtf = run_traj(capi.PARITY_FAST)
+            tmf = match_alone(mf, poses_f)
+            dd = np.abs(np.asarray(poses_f, np.float64) - np.asarray(gpu_poses, np.float64))
+            out["fast_mode"] = {"mode": "HSM_PARITY_FAST (opt-in): tree summation, K <= 64 cooperating workgroups per dense scan",
+                                "value": args.steps * its / dtf, "ms_per_step": dtf / args.steps * 1e3, "match_ms": tmf * 1e3,
+                                "update_ms": (dtf / args.steps - tmf) * 1e3, "kernel": mf.last_launch_config(),
+                                "max_abs_dxy_m_vs_default": float(dd[:, :2].max()), "max_abs_dtheta_vs_default": float(dd[:, 2].max())}
+            m = mf
         if not args.no_cpu and nranks == 1:
             o, kind = cpu_oracle()
             o.proc_set_thresholds(0.0, 0.0)
@@ -565,17 +586,21 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             pg, _ = m.matchData(init[q], scans[q])
             lat.append(time.perf_counter() - a)
         lat = np.array(lat[args.warmup:])
-        # the same call with HSM_PARITY=exact (the reference's summation order on a single scan: nine sequential chains of
-        # n additions per GN step; opt-in for single scans, AUTO keeps the fast tree there)
-        m.set_parity(capi.PARITY_EXACT)
-        lat_x = []
-        for k in range(10 + min(args.steps, 100)):
-            q = k % nq
-            a = time.perf_counter()
-            m.matchData(init[q], scans[q])
-            lat_x.append(time.perf_counter() - a)
+        default_cfg = m.last_launch_config()
+        # the same call with HSM_PARITY=fast (tree summation; opt-in since round 5 -- the default above runs the reference's
+        # summation order: nine sequential chains of n additions per GN step) and with HSM_PARITY=exact (the literal serial
+        # chains; AUTO may pick any form that is bit-identical to them)
+        for mode, key in ((capi.PARITY_FAST, "fast_single_scan_latency_us"), (capi.PARITY_EXACT, "exact_single_scan_latency_us")):
+            m.set_parity(mode)
+            lat_x = []
+            for k in range(10 + min(args.steps, 100)):
+                q = k % nq
+                a = time.perf_counter()
+                m.matchData(init[q], scans[q])
+                lat_x.append(time.perf_counter() - a)
+            out[key] = {"median": float(np.median(lat_x[10:])) * 1e6, "p90": float(np.percentile(lat_x[10:], 90)) * 1e6,
+                        "kernel": m.last_launch_config()}
         m.set_parity(capi.PARITY_AUTO)
-        out["exact_single_scan_latency_us"] = {"median": float(np.median(lat_x[10:])) * 1e6, "p90": float(np.percentile(lat_x[10:], 90)) * 1e6}
         # the other half of HectorSlamProcessor::update: updateByScan on all levels + onMapUpdated, host call
         m2 = capi.MapRepMultiMap(res, size, size, levels, device=local_rank)
         m2.setUpdateFactorFree(0.4)
@@ -621,7 +646,8 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                     "config": {"workload": f"configs[1]: ONE {beams}-beam scan, {levels}-level {size}/{size // 2}/{size // 4} "
                                            f"pyramid, hsm_match host call (H2D + 1 launch + D2H), median of {args.steps}",
                                "beams": beams, "map": size, "levels": levels, "gn_iterations_per_scan": its,
-                               "kernel": m.last_launch_config()},
+                               "parity_mode": f"library default (HSM_PARITY_AUTO) -> {default_cfg.get('parity_effective')} summation",
+                               "kernel": default_cfg},
                     "latency_us": {"median": float(np.median(lat)) * 1e6, "p90": float(np.percentile(lat, 90)) * 1e6,
                                    "min": float(lat.min()) * 1e6},
                     "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9, "traffic": None,
@@ -657,11 +683,13 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             for k in range(n_cpu):
                 o.match(init[k % nq], scans[k % nq])
             dtc = time.perf_counter() - t0
-            d = max(float(np.abs(o.match(init[q], scans[q])[0].astype(np.float64) - m.matchData(init[q], scans[q])[0]).max())
-                    for q in range(32))
+            pairs = [(o.match(init[q], scans[q])[0], m.matchData(init[q], scans[q])[0]) for q in range(min(nq, 64))]
+            d = max(float(np.abs(a.astype(np.float64) - b).max()) for a, b in pairs)
+            same = float(np.mean([bool((a.view(np.uint32) == b.view(np.uint32)).all()) for a, b in pairs]))
             out["cpu_baseline"] = {"value": n_cpu * its / dtc, "unit": "GN it/s", "cores": 1, "kind": kind,
                                    "sample": f"{n_cpu} matchData calls, warm cache, {dtc:.1f} s",
-                                   "latency_us": dtc / n_cpu * 1e6, "max_abs_dev_vs_gpu": d}
+                                   "latency_us": dtc / n_cpu * 1e6, "max_abs_dev_vs_gpu": d, "parity_sample": len(pairs),
+                                   "bit_identical_pose_fraction": same}
         emit(out)
         return
 
