@@ -83,6 +83,8 @@ SIGNATURES = {
     "hsm_group_match_batch": (_i, [_vp, _i, _f32p, _vp, _vp, _i, _f32p, _vp]),
     "hsm_group_match_batch_device": (_i, [_vp, _i32p, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hsm_group_synchronize": (_i, [_vp]),
+    "hsm_group_debug_force_p2p": (_i, [_vp, _i]),
+    "hsm_shard_bounds": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "hsm_group_set_gather": (_i, [_vp, _i]),
     "hsm_group_gather_mode": (_i, [_vp]),
     "hsm_group_gather_note": (C.c_char_p, [_vp]),
@@ -146,6 +148,13 @@ def load_library(build_if_missing: bool = True):
     lib._hsm_update_raw.restype, lib._hsm_update_raw.argtypes = _i, [_vp, _vp, _vp, _i, _vp]
     _lib = lib
     return lib
+
+
+def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
+    """[begin, end) of shard `rank` of `total` scans over `world` replicas: the library's ONE partitioning rule (hsm_shard_bounds)"""
+    b, e = C.c_int(0), C.c_int(0)
+    _check(load_library().hsm_shard_bounds(int(total), int(rank), int(world), C.byref(b), C.byref(e)), "hsm_shard_bounds")
+    return b.value, e.value
 
 
 def _check(rc: int, what: str):
@@ -624,6 +633,10 @@ class MapRepGroup:
     def set_gather(self, mode: int):
         """GATHER_AUTO / GATHER_PEER / GATHER_RCCL for match_batch_device (RCCL asked for explicitly raises if unavailable)"""
         _check(self._lib.hsm_group_set_gather(self._g, mode), "hsm_group_set_gather")
+
+    def debug_force_p2p(self, on: bool):
+        """test hook: the RCCL gather sends every shard, the root's too, through grouped ncclSend / ncclRecv"""
+        _check(self._lib.hsm_group_debug_force_p2p(self._g, 1 if on else 0), "hsm_group_debug_force_p2p")
 
     def gather_mode(self):
         """("rccl" | "peer", note): what match_batch_device gathers with (initialises the RCCL communicators if still open)"""

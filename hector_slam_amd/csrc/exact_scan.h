@@ -1,0 +1,229 @@
+// exact_scan.h -- the reference's sequential fp32 summation, evaluated a block at a time with integer wave scans.
+//
+// getCompleteHessianDerivs (OccGridMapUtil.h:76-98) adds the nine per-beam products to nine running fp32 sums in beam order;
+// the result depends on that order through the rounding of every partial sum, which is why HSM_PARITY_EXACT keeps nine
+// literal chains of dependent v_add_f32 (gn_match.h exact_chain: 8.5 cycles per beam, the floor of that form).  This header
+// holds the element arithmetic of a form that produces the SAME bits without the dependent chain (round-4 verdict, item 1(ii)):
+//
+//   While the running sum s stays inside one binade [2^e, 2^(e+1)) every float in reach is a multiple of u = 2^(e-23), s = S*u
+//   with S in [2^23, 2^24), and fl(s + x) = (S + R(x/u)) * u, where R rounds x/u to the nearest integer and a tie (fraction
+//   exactly 1/2) goes to whichever neighbour makes S + R EVEN (round-to-nearest-even on the mantissa).  So inside a binade the
+//   chain is an INTEGER prefix sum of per-element increments t_k -- associative, a wave scan -- plus a correction of +-1 at
+//   the ties, whose direction depends only on the parity of the running integer: after a tie it is even, so the parity before
+//   the next tie is the parity of the increments in between.  The prefix S_k = S_0 + T_k + C_k is checked against the binade
+//   ((2^23, 2^24) exclusive, same sign); the first element whose prefix leaves it is added with ONE real v_add_f32 to the
+//   (exact) sum before it, and the scan restarts behind it with the new exponent.  Zeros, denormals, infinities and NaNs of s
+//   take single real additions.  Every path reproduces the IEEE result of the sequential chain bit for bit; the host model
+//   (tests/cpp/exact_scan_model.cpp) runs this header's element function through the same block algorithm as the device
+//   code and checks it against the literal loop on adversarial data.
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HSM_HD __host__ __device__ __forceinline__
+#else
+#define HSM_HD inline
+#endif
+
+namespace hsm {
+namespace xscan {
+
+constexpr int kLo = (1 << 23) + 1;   // a prefix S_k is trusted iff kLo <= S_k <= kHi: strictly inside the binade, so that the
+constexpr int kHi = (1 << 24) - 1;   // exact sum S_{k-1} + x_k/u lay inside it too (see the header comment)
+
+// One element against the running sum's sign and exponent field (es in 1..254).
+//   t    signed integer increment in units of u: the rounded x/u, or for a tie the magnitude TRUNCATED (the tie's round-up,
+//        +-1 in the direction of x, is decided by the caller from the parity of the running integer)
+//   flags bit 0: tie; bit 1: the element is negative relative to s (its corrections count -1); bit 2: "big" -- |x| >= 2 |s|'s
+//        binade (or inf / NaN): the prefix leaves the binade here whatever S is
+struct Elem {
+  int t;
+  unsigned flags;
+};
+constexpr unsigned kTie = 1u, kNeg = 2u, kBig = 4u;
+
+HSM_HD Elem convert(unsigned xbits, unsigned sign_of_s, int es) {
+  const unsigned y = xbits ^ sign_of_s;             // x relative to the sign of s: the running integer stays positive
+  const unsigned neg = y >> 31;
+  const int ex = (int)((y >> 23) & 0xffu);
+  const unsigned mant = y & 0x7fffffu;
+  const unsigned m = ex ? (mant | 0x800000u) : mant;  // denormals: no hidden bit, exponent field 1
+  const int exn = ex ? ex : 1;
+  int sh = es - exn;                                 // x / u = m * 2^-sh
+  const bool big = ex == 255 || sh < 0;
+  sh = sh < 0 ? 0 : (sh > 25 ? 25 : sh);             // beyond 25 every m < 2^24 rounds to 0 without a tie, as at 25
+  const unsigned q = m >> sh;
+  const unsigned r = m & ((1u << sh) - 1u);
+  const unsigned half = (1u << sh) >> 1;             // 0 for sh == 0: then r == 0, no rounding at all
+  const unsigned up = r > half ? 1u : 0u;
+  const unsigned tie = (sh > 0 && r == half) ? 1u : 0u;
+  const int mag = (int)(q + up);
+  Elem e;
+  e.t = neg ? -mag : mag;
+  e.flags = tie | (neg << 1) | (big ? kBig : 0u);
+  return e;
+}
+
+// the float with sign bit `sign_of_s`, exponent field es and integer significand S in [2^23, 2^24)
+HSM_HD unsigned compose(unsigned sign_of_s, int es, int S) {
+  return sign_of_s | ((unsigned)es << 23) | ((unsigned)S & 0x7fffffu);
+}
+
+}  // namespace xscan
+}  // namespace hsm
+
+#if defined(__HIPCC__)
+namespace hsm {
+namespace xscan {
+
+// ---- device side: one wavefront, E consecutive elements per lane (element g = lane * E + j) -----------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_or_zero(int v) {  // the DPP source lane's value; 0 where there is none / the row is masked out
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes (wrap-around int arithmetic): Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8),
+// then the row totals travel with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += dpp_or_zero<0x111>(v);
+  v += dpp_or_zero<0x112>(v);
+  v += dpp_or_zero<0x114>(v);
+  v += dpp_or_zero<0x118>(v);
+  v += dpp_or_zero<0x142, 0xa>(v);
+  v += dpp_or_zero<0x143, 0xc>(v);
+  return v;
+}
+
+__device__ __forceinline__ int first_lane(unsigned long long mask) { return __builtin_ctzll(mask); }
+
+// The running sum after adding elements start .. 64 E - 1 of the block to s, in element order, every addition rounded as the
+// literal fp32 chain rounds it (see the header comment).  s and start are wave-uniform; the result is too.
+// `iters` (optional) counts scan iterations, `singles` the single real additions: measurement only.
+template <int E>
+__device__ __forceinline__ float block_sum(float s_in, const float (&x)[E], int start, int lane, int* iters = nullptr, int* singles = nullptr) {
+  constexpr int N = 64 * E;
+  unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s_in));
+  const int g0 = lane * E;
+  while (start < N) {
+    const int es = (int)((sb >> 23) & 0xffu);
+    if (es == 0 || es == 255) {
+      // zero, denormal, infinity, NaN: real additions.  A zero sum runs over zero elements to the first non-zero one.
+      const bool szero = (sb << 1) == 0u;
+      unsigned mybits = 0u, pluszero = 0u;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const unsigned xb = __float_as_uint(x[j]);
+        if (g0 + j >= start) {
+          if (!szero || (xb << 1) != 0u) mybits |= 1u << j;
+          if (xb == 0u) pluszero |= 1u << j;
+        }
+      }
+      const unsigned long long any = __ballot(mybits != 0u);
+      if (any == 0ull) {  // nothing but zeros behind a zero sum: (-0) + (+0) = +0, everything else leaves the sum as it is
+        if (sb == 0x80000000u && __ballot(pluszero != 0u) != 0ull) sb = 0u;
+        start = N;
+        break;
+      }
+      const int L = first_lane(any);
+      const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)mybits, L);
+      const int slot = __builtin_ctz(vb);
+      float xs = x[0];
+#pragma unroll
+      for (int j = 1; j < E; ++j) xs = slot == j ? x[j] : xs;
+      const float xg = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xs), L));
+      float s = __uint_as_float(sb);
+      s = szero ? (0.0f + xg) : (s + xg);  // (0 + x == x for x != 0)
+      sb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s));
+      start = L * E + slot + 1;
+      if (singles) ++*singles;
+      continue;
+    }
+    if (iters) ++*iters;
+    const unsigned sign = sb & 0x80000000u;
+    const int S0 = (int)((sb & 0x7fffffu) | 0x800000u);
+    // the elements against (sign, es): lane-local inclusive prefix of the increments, flags packed one bit per slot
+    int Tl[E];
+    unsigned tiebits = 0u, negbits = 0u, bigbits = 0u;
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      Elem e = convert(__float_as_uint(x[j]), sign, es);
+      if (g0 + j < start) { e.t = 0; e.flags = 0u; }
+      acc += e.t;
+      Tl[j] = acc;
+      tiebits |= (e.flags & kTie) << j;
+      negbits |= ((e.flags >> 1) & 1u) << j;
+      bigbits |= ((e.flags >> 2) & 1u) << j;
+    }
+    const int base = wave_inclusive_scan(acc) - acc;
+    // ties: +-1 in the direction of the element iff the running integer before it plus the truncated increment is odd; after a
+    // tie the integer is even, so that parity is parity(T at this tie) ^ parity(T at the previous tie), the first tie against S0
+    int cl[E];
+    int cbase = 0;
+    const unsigned long long has_tie = __ballot(tiebits != 0u);
+    if (has_tie != 0ull) {
+      unsigned taubits = 0u;
+#pragma unroll
+      for (int j = 0; j < E; ++j) taubits |= ((unsigned)(base + Tl[j]) & 1u) << j;
+      const int lastslot = 31 - __builtin_clz(tiebits | 0x80000000u * (tiebits == 0u));  // (any value where the lane has no tie)
+      const unsigned long long last_tau = __ballot(tiebits != 0u && ((taubits >> (lastslot & 31)) & 1u));
+      const unsigned long long below = has_tie & ((1ull << lane) - 1ull);
+      unsigned prev_tau = (unsigned)S0 & 1u;
+      if (below != 0ull) prev_tau = (unsigned)((last_tau >> (63 - __builtin_clzll(below))) & 1ull);
+      int cacc = 0;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const unsigned tie = (tiebits >> j) & 1u, tau = (taubits >> j) & 1u;
+        const unsigned b = tie & (tau ^ prev_tau);
+        prev_tau = tie ? tau : prev_tau;
+        cacc += b ? (((negbits >> j) & 1u) ? -1 : 1) : 0;
+        cl[j] = cacc;
+      }
+      cbase = wave_inclusive_scan(cacc) - cacc;
+    } else {
+#pragma unroll
+      for (int j = 0; j < E; ++j) cl[j] = 0;
+    }
+    // prefixes; the first one that leaves the binade (or a "big" element)
+    const int Sb = S0 + base + cbase;  // (unsigned wrap-around semantics: see the model)
+    unsigned violbits = 0u;
+    int S_last = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const int S = (int)((unsigned)Sb + (unsigned)Tl[j] + (unsigned)cl[j]);
+      const bool viol = (g0 + j >= start) && (((bigbits >> j) & 1u) || (unsigned)(S - kLo) > (unsigned)(kHi - kLo));
+      violbits |= (viol ? 1u : 0u) << j;
+      if (j == E - 1) S_last = S;
+    }
+    const unsigned long long anyv = __ballot(violbits != 0u);
+    if (anyv == 0ull) {
+      sb = compose(sign, es, __builtin_amdgcn_readlane(S_last, 63));
+      start = N;
+      break;
+    }
+    const int L = first_lane(anyv);
+    // every lane prepares "the prefix before, and the value of, my first violating element"; lane L's are the ones used
+    const int myslot = violbits ? __builtin_ctz(violbits) : 0;
+    int Sprev_my = Sb;
+    float x_my = x[0];
+#pragma unroll
+    for (int j = 1; j < E; ++j) {
+      if (myslot == j) {
+        Sprev_my = (int)((unsigned)Sb + (unsigned)Tl[j - 1] + (unsigned)cl[j - 1]);
+        x_my = x[j];
+      }
+    }
+    const int slot = __builtin_amdgcn_readlane(myslot, L);
+    const int Sprev = __builtin_amdgcn_readlane(Sprev_my, L);
+    const float xg = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x_my), L));
+    const int g = L * E + slot;
+    const float sprev = g > start ? __uint_as_float(compose(sign, es, Sprev)) : __uint_as_float(sb);
+    const float s = sprev + xg;  // the one real addition of this iteration
+    sb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s));
+    start = g + 1;
+  }
+  return __uint_as_float(sb);
+}
+
+}  // namespace xscan
+}  // namespace hsm
+#endif  // __HIPCC__

@@ -2096,6 +2096,7 @@ struct hsm_group {
   // the gather itself: RCCL over the group's devices (one communicator per replica, ncclCommInitAll on first use), or
   // peer copies.  gather_pref = what was asked for (hsm_group_set_gather / env HSM_GROUP_GATHER), gather_mode = what runs.
   int gather_pref = HSM_GATHER_AUTO, gather_mode = HSM_GATHER_AUTO;
+  bool force_p2p = false;  // hsm_group_debug_force_p2p: every shard, the root's too, through grouped ncclSend / ncclRecv
   std::vector<ncclComm_t> comms;
   std::vector<float*> d_all_pose, d_all_cov;  // all-gather receive blocks of the replicas other than the root
   std::vector<size_t> d_all_cap;              // floats of pose block (cov block: 3x)
@@ -2249,6 +2250,13 @@ int hsm_group_set_gather(hsm_group* g, int mode) {
   return mode == HSM_GATHER_RCCL ? group_ensure_gather(g) : HSM_OK;
 }
 
+int hsm_group_debug_force_p2p(hsm_group* g, int on) {
+  if (!g) return fail(HSM_ERR_INVALID, "null group");
+  std::lock_guard<std::mutex> glk(g->mu);
+  g->force_p2p = on != 0;
+  return HSM_OK;
+}
+
 int hsm_group_gather_mode(hsm_group* g) {
   if (!g) return HSM_GATHER_AUTO;
   std::lock_guard<std::mutex> glk(g->mu);
@@ -2339,6 +2347,8 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
   const size_t total = first[(size_t)R];
   bool equal = counts[0] > 0;  // ncclAllGather wants the same count from every rank
   for (int r = 1; r < R; ++r) equal = equal && counts[r] == counts[0];
+  const bool self_send = rccl && g->force_p2p;  // test hook: the send / receive form for every shard, the root's own included
+  if (self_send) equal = false;
   // every replica: match its shard on its own stream.  Peer gather: push the poses (and H) to the root's device with a peer
   // copy on the same stream -- 12 (+36) bytes per scan over xGMI, no host staging, no host wait.  RCCL gather: the
   // collective is queued below, behind the match, on the same streams.
@@ -2371,7 +2381,7 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
                                               d_scan_offsets ? d_scan_offsets[r] : nullptr, shared_n, g->d_pose[(size_t)r],
                                               d_out_cov_all ? g->d_cov[(size_t)r] : nullptr, h->stream))
         return rc2;
-      if (!rccl || (r == root && !equal)) {  // (RCCL send/recv gather: the root's own shard is a local copy)
+      if (!rccl || (r == root && !equal && !self_send)) {  // (RCCL send/recv gather: the root's own shard is a local copy)
         HIP_TRY(hipMemcpyPeerAsync(d_out_pose_all + 3 * first[(size_t)r], root_dev, g->d_pose[(size_t)r], h->device,
                                    n * 3 * sizeof(float), h->stream));
         if (d_out_cov_all)
@@ -2401,7 +2411,7 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
         if (nr == ncclSuccess && d_out_cov_all)
           nr = api->AllGather(g->d_cov[(size_t)r], r == root ? d_out_cov_all : g->d_all_cov[(size_t)r], n * 9, ncclFloat,
                               g->comms[(size_t)r], h->stream);
-      } else if (r != root && n > 0) {
+      } else if ((r != root || self_send) && n > 0) {
         hsm_ctx* hr = g->members[(size_t)root];
         nr = api->Send(g->d_pose[(size_t)r], n * 3, ncclFloat, root, g->comms[(size_t)r], h->stream);
         if (nr == ncclSuccess)
@@ -2440,6 +2450,17 @@ int hsm_group_synchronize(hsm_group* g) {
   return HSM_OK;
 }
 
+// THE partitioning of a batch over G replicas (contiguous shards): the first total % world shards hold one
+// scan more.  One rule for both transports -- hsm_group_* (one process, a worker thread per device) and
+// hector_slam_amd/sharding.py (one process per device under torch.distributed, which calls this function).
+int hsm_shard_bounds(int total, int rank, int world, int* begin, int* end) {
+  if (total < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return fail(HSM_ERR_INVALID, "hsm_shard_bounds: bad argument");
+  const int base = total / world, rem = total % world;
+  *begin = rank * base + (rank < rem ? rank : rem);
+  *end = *begin + base + (rank < rem ? 1 : 0);
+  return HSM_OK;
+}
+
 int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, const float* pts_xy,
                           const int* scan_offsets, int shared_n, float* out_pose, float* out_cov) {
   if (!g || g->members.empty()) return fail(HSM_ERR_INVALID, "null group");
@@ -2447,7 +2468,8 @@ int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, con
   const int R = (int)g->members.size();
   std::lock_guard<std::mutex> glk(g->mu);
   return group_parallel(g, [&](int r) -> int {
-    const int b = (int)((long long)batch * r / R), e = (int)((long long)batch * (r + 1) / R);
+    int b = 0, e = 0;
+    if (int rc = hsm_shard_bounds(batch, r, R, &b, &e)) return rc;
     if (e == b) return HSM_OK;
     if (!scan_offsets)  // pose hypotheses of ONE shared scan
       return hsm_match_batch(g->members[r], e - b, begin_world + 3 * (size_t)b, pts_xy, nullptr, shared_n,

@@ -12,10 +12,11 @@ import torch.distributed as dist
 
 
 def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous [begin, end) of rank's share; the first total % world ranks get one extra."""
-    base, rem = divmod(total, world)
-    begin = rank * base + min(rank, rem)
-    return begin, begin + base + (1 if rank < rem else 0)
+    """Contiguous [begin, end) of rank's share; the first total % world ranks get one extra.  The rule itself lives in the
+    native library (hsm_shard_bounds): the single-process group (hsm_group_match_batch) and this process-per-GPU path split a
+    batch identically, so results gathered by either transport line up row for row."""
+    from . import capi
+    return capi.shard_bounds(total, rank, world)
 
 
 def max_shard(total: int, world: int) -> int:

@@ -176,7 +176,15 @@ typedef struct hsm_group hsm_group;
  * (hsm_group_gather_note says why).  RCCL asked for explicitly fails instead of falling back. */
 enum { HSM_GATHER_AUTO = 0, HSM_GATHER_PEER = 1, HSM_GATHER_RCCL = 2 };
 int hsm_group_set_gather(hsm_group* g, int mode);
-/* the mode in effect (initialises the communicators if that is still open): HSM_GATHER_PEER or HSM_GATHER_RCCL */
+/* test hook: with the RCCL gather, send EVERY shard -- the root's own too (a send to self) -- through the grouped ncclSend /
+ * ncclRecv form that unequal shards take, instead of ncclAllGather.  Lets a one-device box run that form on hardware. */
+int hsm_group_debug_force_p2p(hsm_group* g, int on);
+/* The partitioning of `total` scans over `world` replicas (contiguous shards, the first total % world hold one more): [begin, end)
+ * of shard `rank`.  Used by hsm_group_match_batch and by hector_slam_amd/sharding.py -- one rule for both transports. */
+int hsm_shard_bounds(int total, int rank, int world, int* begin, int* end);
+/* the mode in effect: HSM_GATHER_PEER or HSM_GATHER_RCCL.  The decision -- dlopen of librccl and ncclCommInitAll over the group's
+ * devices, SECONDS on a multi-GPU node -- is taken on first use: by this call, by hsm_group_set_gather(RCCL), or else inside the
+ * first hsm_group_match_batch_device.  A latency-sensitive caller asks for the mode once right after hsm_group_create. */
 int hsm_group_gather_mode(hsm_group* g);
 const char* hsm_group_gather_note(const hsm_group* g);
 /* RCCL gather with equal shards is an all-gather: replica i (other than the root, which received into the caller's arrays)

@@ -935,6 +935,19 @@ def test_group_gathers_with_rccl(capi, pyramid_scene, monkeypatch):
             if mode == capi.GATHER_RCCL and not ragged and ndev > 1:  # an all-gather: every other replica holds all poses too
                 ptr = grp.gathered(0)
                 assert ptr != 0
+            if mode == capi.GATHER_RCCL:
+                # the send / receive form (what unequal shards take) for EVERY shard, the root's own included -- a send to self:
+                # the one way a single-device box runs grouped ncclSend / ncclRecv on hardware (round-4 verdict, item 6b)
+                grp.debug_force_p2p(True)
+                d_all = torch.zeros((nb, 3), dtype=torch.float32, device=rdev)
+                d_cov = torch.zeros((nb, 9), dtype=torch.float32, device=rdev)
+                torch.cuda.synchronize()
+                grp.match_batch_device([e - b for b, e in bounds], [s_[0].data_ptr() for s_ in shards], [s_[1].data_ptr() for s_ in shards],
+                                       [s_[2].data_ptr() for s_ in shards], 0, root, d_all.data_ptr(), d_cov.data_ptr())
+                grp.synchronize()
+                assert np.array_equal(bits(d_all.cpu().numpy()), bits(want_p[:nb])), ("send/recv form", ragged)
+                assert np.array_equal(bits(d_cov.cpu().numpy()), bits(want_c[:nb])), ("send/recv form", ragged)
+                grp.debug_force_p2p(False)
             got[mode] = d_all.cpu().numpy()
             grp.close()
         assert np.array_equal(bits(got[capi.GATHER_RCCL]), bits(got[capi.GATHER_PEER]))

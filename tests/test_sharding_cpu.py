@@ -113,6 +113,22 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1 and max(sizes) == sharding.max_shard(total, world)
 
 
+def test_shard_bounds_is_the_native_rule():
+    """one partitioning for both transports: sharding.shard_bounds IS hsm_shard_bounds (the rule hsm_group_match_batch splits
+    by), equal to the closed form, and a bad rank / world is refused"""
+    import pytest
+    from hector_slam_amd import capi, sharding
+    for total in (0, 1, 5, 10, 4095, 4096, 32771):
+        for world in (1, 2, 3, 4, 7, 8):
+            for r in range(world):
+                base, rem = divmod(total, world)
+                b = r * base + min(r, rem)
+                assert sharding.shard_bounds(total, r, world) == capi.shard_bounds(total, r, world) == (b, b + base + (1 if r < rem else 0))
+    for bad in ((10, 4, 4), (10, -1, 4), (10, 0, 0), (-1, 0, 2)):
+        with pytest.raises(capi.HsmError):
+            capi.shard_bounds(*bad)
+
+
 def _worker_replica(rank, world, port, q):
     """configs[4] protocol on CPU: the CPU oracle stands in for the GPU replica (same deterministic updateByScan)"""
     sys.path.insert(0, ROOT)

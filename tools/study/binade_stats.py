@@ -57,6 +57,10 @@ def main():
         for label, pose_w in (("start", sc.query_init[q]), ("converged", o.match(sc.query_init[q], pts)[0])):
             pm = o.map_coords_pose(0, pose_w)
             pr = products(o, 0, pm, pts)
+            if "--dump" in sys.argv:
+                np.ascontiguousarray(pr.T).tofile(f"/tmp/products_{n_beams}_{q}_{label}.bin")
+                print("dumped", pr.shape)
+                continue
             nrows = (len(pts) + 63) // 64
             tot_rows = np.zeros(nrows, bool)
             print(f"scan {q} ({len(pts)} beams, {nrows} rows) at {label} pose")
