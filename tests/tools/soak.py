@@ -9,7 +9,10 @@ the CPU checker; prints one JSON line.
                but the scans.  With --exact (HSM_PARITY_EXACT) poses AND maps must still be bit-identical after N steps --
                one differing bit anywhere would send the two SLAM states apart.
 
-usage: soak.py [N] [--exact] [--free-run]"""
+  --default    the context is created in the library DEFAULT (HSM_PARITY_AUTO: the reference's summation order on every entry point
+               since round 5) instead of an explicit mode; with --free-run the bit-identity bar of --exact applies
+
+usage: soak.py [N] [--exact | --default] [--free-run]"""
 import json
 import os
 import sys
@@ -24,10 +27,11 @@ from oracle import pyoracle  # noqa: E402
 pyoracle.build()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if args else 70000
-exact, free_run = "--exact" in sys.argv, "--free-run" in sys.argv
+exact, free_run = "--exact" in sys.argv or "--default" in sys.argv, "--free-run" in sys.argv
 kind = "hr" if pyoracle.available("hr") else "ho"
 sc = synth.make_scene(n_beams=1081, map_size=1024, levels=3, resolution=0.05, n_build=400, n_query=4, room=(40.0, 30.0), seed=5)
-g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, parity=capi.PARITY_EXACT if exact else capi.PARITY_FAST)
+g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels,
+                        **({} if "--default" in sys.argv else {"parity": capi.PARITY_EXACT if exact else capi.PARITY_FAST}))
 o = pyoracle.Oracle(kind, sc.resolution, sc.map_size, sc.map_size, sc.levels)
 for m in (g.setUpdateFactorFree, o.set_update_factor_free):
     m(0.4)

@@ -2,7 +2,7 @@
 //
 // getCompleteHessianDerivs (OccGridMapUtil.h:76-98) adds the nine per-beam products to nine running fp32 sums in beam order;
 // the result depends on that order through the rounding of every partial sum, which is why HSM_PARITY_EXACT keeps nine
-// literal chains of dependent v_add_f32 (gn_match.h exact_chain: 8.5 cycles per beam, the floor of that form).  This header
+// literal chains of dependent v_add_f32 (hector_slam_amd/csrc/gn_match.h exact_chain: 8.5 cycles per beam, the floor of that form).  This header
 // holds the element arithmetic of a form that produces the SAME bits without the dependent chain (round-4 verdict, item 1(ii)):
 //
 //   While the running sum s stays inside one binade [2^e, 2^(e+1)) every float in reach is a multiple of u = 2^(e-23), s = S*u
@@ -14,7 +14,7 @@
 //   ((2^23, 2^24) exclusive, same sign); the first element whose prefix leaves it is added with ONE real v_add_f32 to the
 //   (exact) sum before it, and the scan restarts behind it with the new exponent.  Zeros, denormals, infinities and NaNs of s
 //   take single real additions.  Every path reproduces the IEEE result of the sequential chain bit for bit; the host model
-//   (tests/cpp/exact_scan_model.cpp) runs this header's element function through the same block algorithm as the device
+//   (tools/study/exact_scan_model.cpp) runs this header's element function through the same block algorithm as the device
 //   code and checks it against the literal loop on adversarial data.
 #pragma once
 #if defined(__HIPCC__)

@@ -1,4 +1,4 @@
-// Host model of the block algorithm in hector_slam_amd/csrc/exact_scan.h: 64 "lanes" x E elements, the same data flow as the
+// Host model of the block algorithm in tools/study/exact_scan.h: 64 "lanes" x E elements, the same data flow as the
 // device code (per-lane prefix, cross-lane exclusive scan, tie resolution through the parity of the truncated prefix at the
 // previous tie, first-violation restart), checked against the literal sequential fp32 loop.  Built and run by
 // tests/test_exact_scan_model.py (g++ -O2 -ffp-contract=off).  Exit code 0 = every case bit-identical.

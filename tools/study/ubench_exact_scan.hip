@@ -1,8 +1,8 @@
-// The block-scan form of the reference's fp32 chains (hector_slam_amd/csrc/exact_scan.h) against the literal dependent chain,
+// The block-scan form of the reference's fp32 chains (tools/study/exact_scan.h) against the literal dependent chain,
 // one wavefront each, on REAL per-beam products (tools/study/binade_stats.py --dump: chain-major fp32, nine chains of one
 // Gauss-Newton step), staged in LDS as the matcher stages them.  Per chain: both sums (must be the same bits, and the bits of
 // the host's literal loop), shader cycles of each form, scan iterations and single additions.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I hector_slam_amd/csrc -o ubench_exact_scan tools/ubench_exact_scan.hip
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I tools/study -o tools/_bin/ubench_exact_scan tools/study/ubench_exact_scan.hip
 //   ./ubench_exact_scan /tmp/products_16384_0_converged.bin 15398
 #include <hip/hip_runtime.h>
 #include <cstdio>
