@@ -79,6 +79,12 @@ struct Level {
   int currUpdateIndex, currMarkOccIndex, currMarkFreeIndex, lastUpdateIndex;
   // ScanMatcher members (HSL/matcher/ScanMatcher.h:242-243); H column-major
   float H[9], dTr[3];
+  // TEST-HARNESS GUARD, not reference behaviour: reads with a NaN coordinate.  The reference's bounds test lets NaN through
+  // (every comparison is false), then indexes the grid with (int)NaN (OccGridMapUtil.h:295,302) -- undefined behaviour, a
+  // segmentation fault in practice, reached whenever its own Gauss-Newton step divides by a zero determinant.  The restatement
+  // returns zeros for such a read and counts it, so that property tests can discard inputs on which the reference has no
+  // defined result instead of dying with it (ho_undefined_reads).
+  long undefinedReads = 0;
 };
 
 static inline float prob_to_log_odds(float prob) {  // GridMapLogOdds.h:196-200
@@ -162,6 +168,11 @@ static inline float cached_prob(Level& L, int index) {
 
 // a1: OccGridMapUtil::interpMapValueWithDerivatives (OccGridMapUtil.h:287-347)
 static inline void interp_with_derivs(Level& L, float cx, float cy, float& M, float& gx, float& gy) {
+  if (cx != cx || cy != cy) {  // (test-harness guard, see Level::undefinedReads)
+    ++L.undefinedReads;
+    M = gx = gy = 0.0f;
+    return;
+  }
   // MapDimensionProperties::pointOutOfMapBounds (MapDimensionProperties.h:65-68)
   if ((cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy)) {
     M = 0.0f;
@@ -587,6 +598,11 @@ void ho_update_by_scan_level(void* h, int level, const float pose[3], const floa
   level_update_by_scan(((Ctx*)h)->levels[level], pts, n, origo, pose);
 }
 void ho_on_map_updated(void* h) { multimap_on_map_updated(*(Ctx*)h); }
+long ho_undefined_reads(void* h) {  // (test-harness guard, see Level::undefinedReads)
+  long n = 0;
+  for (const Level& L : ((Ctx*)h)->levels) n += L.undefinedReads;
+  return n;
+}
 
 void ho_proc_set_thresholds(void* h, float d, float a) {
   ((Ctx*)h)->paramMinDist = d;
@@ -620,6 +636,10 @@ void ho_proc_last_pose(void* h, float pose[3], float cov[9]) {
 // f3: OccGridMapUtil::interpMapValue (OccGridMapUtil.h:233-285), getResidualForState (:198-214),
 // getLikelihoodForResidual (:191-197), getLikelihoodForState (:184-189)
 static inline float interp_map_value(Level& L, float cx, float cy) {
+  if (cx != cx || cy != cy) {  // (test-harness guard, see Level::undefinedReads)
+    ++L.undefinedReads;
+    return 0.0f;
+  }
   if ((cx < 0.0f) || (cx > L.limx) || (cy < 0.0f) || (cy > L.limy)) return 0.0f;
   const int ix = (int)cx, iy = (int)cy;
   const float fx = cx - (float)ix, fy = cy - (float)iy;

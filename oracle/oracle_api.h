@@ -73,6 +73,11 @@ void ORF(update_by_scan)(void* h, const float pose_world[3], const float* pts, i
 void ORF(update_by_scan_level)(void* h, int level, const float pose_world[3],
                                const float* pts_level, int n, const float origo_level[2]);
 void ORF(on_map_updated)(void* h);                          /* MapRepMultiMap.h:107-114 */
+/* Test-harness guard.  "ho": how many map reads so far carried a NaN coordinate -- the reference's bounds test lets NaN through
+ * and it then indexes the grid with (int)NaN (OccGridMapUtil.h:295,302): undefined behaviour, a segmentation fault in practice;
+ * the restatement returns zeros for such a read and counts it, so property tests can discard inputs the reference has no defined
+ * result for.  "hr" (the reference itself): -1, it cannot tell. */
+long ORF(undefined_reads)(void* h);
 
 /* a12: HectorSlamProcessor::update (HectorSlamProcessor.h:71-113) */
 void ORF(proc_set_thresholds)(void* h, float min_dist, float min_angle);

@@ -87,6 +87,7 @@ def _load(kind: str):
         "update_by_scan": (None, [vp, _f32p, _f32p, i, _f32p]),
         "update_by_scan_level": (None, [vp, i, _f32p, _f32p, i, _f32p]),
         "on_map_updated": (None, [vp]),
+        "undefined_reads": (C.c_long, [vp]),
         "proc_set_thresholds": (None, [vp, f, f]),
         "proc_update": (None, [vp, _f32p, i, _f32p, _f32p, i]),
         "proc_last_pose": (None, [vp, _f32p, _f32p]),
@@ -293,6 +294,11 @@ class Oracle:
     def set_update_factor_free(self, v): self.f["set_update_factor_free"](self.h, v)
     def set_update_factor_occupied(self, v): self.f["set_update_factor_occupied"](self.h, v)
     def on_map_updated(self): self.f["on_map_updated"](self.h)
+
+    def undefined_reads(self) -> int:
+        """"ho": map reads with a NaN coordinate so far (where the reference would index the grid with (int)NaN and crash);
+        "hr": -1"""
+        return int(self.f["undefined_reads"](self.h))
 
     def level_info(self, level):
         sx, sy, cell, scale = C.c_int(), C.c_int(), C.c_float(), C.c_float()

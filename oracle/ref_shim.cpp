@@ -199,6 +199,7 @@ void hr_update_by_scan_level(void* h, int level, const float pose[3], const floa
   r->level(level).updateByScan(dc, v3(pose));
 }
 void hr_on_map_updated(void* h) { ((Ref*)h)->map->onMapUpdated(); }
+long hr_undefined_reads(void*) { return -1; }  // (the reference cannot tell: it crashes on such a read, oracle_api.h)
 
 void hr_proc_set_thresholds(void* h, float d, float a) {
   ((Ref*)h)->proc->setMapUpdateMinDistDiff(d);

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, seed, settings
+from hypothesis import HealthCheck, assume, given, seed, settings
 from hypothesis import strategies as st
 
 from conftest import bits, oracle_kinds
@@ -30,8 +30,18 @@ geometry = st.fixed_dictionaries({
 })
 
 
-def run_loop(g, make_a, make_b, steps=8):
-    """the same short SLAM loop on two implementations; yields (step, pose_a, cov_a, pose_b, cov_b)"""
+def reference_undefined(impl) -> bool:
+    """the restatement ("ho") counts map reads with a NaN coordinate -- where the reference's own Gauss-Newton step has divided by
+    a zero determinant and the reference then indexes the grid with (int)NaN (OccGridMapUtil.h:295,302: undefined behaviour, it
+    segfaults; hypothesis finds such geometries within ~100 examples).  An input like that has no reference result to compare with."""
+    o = impl.get("keep")
+    return hasattr(o, "undefined_reads") and o.undefined_reads() > 0
+
+
+def run_loop(g, make_a, make_b, steps=8, make_guard=None):
+    """the same short SLAM loop on two implementations; yields (step, pose_a, cov_a, pose_b, cov_b).  make_guard: a restatement
+    instance stepped AHEAD of b when b is the reference itself, so that an input on which the reference would crash is discarded
+    (hypothesis.assume) instead of taking the test process down with it"""
     from hector_slam_amd import synth
     size, levels, res = g["size"], g["levels"], g["res"]
     while (size >> (levels - 1)) < 8:
@@ -44,12 +54,18 @@ def run_loop(g, make_a, make_b, steps=8):
     scans = [synth.make_scan(world, p, g["beams"], s, noise, range_max=min(30.0, ext)) for p in poses]
     origo = np.asarray(g["origo"], np.float32)
     a, b = make_a(res, size, levels, g["start"], g["free"], g["occ"]), make_b(res, size, levels, g["start"], g["free"], g["occ"])
+    guard = make_guard(res, size, levels, g["start"], g["free"], g["occ"]) if make_guard else None
     pose = poses[0].copy()
     cond = None
     for t in range(steps):
         hint = pose + (poses[t] - poses[max(t - 1, 0)])
         pa, ca = a["match"](hint, scans[t], origo)
+        assume(not reference_undefined(a))
+        if guard is not None:
+            guard["match"](hint, scans[t], origo)
+            assume(not reference_undefined(guard))
         pb, cb = b["match"](hint, scans[t], origo)
+        assume(not reference_undefined(b))
         if not np.isfinite(pa).all():  # singular H: the reference divides by a zero determinant (NaN payloads not pinned)
             assert np.array_equal(np.isnan(pa), np.isnan(pb))
             return cond
@@ -58,6 +74,8 @@ def run_loop(g, make_a, make_b, steps=8):
         cond = float(np.linalg.cond(H)) if np.abs(H).max() > 0 else float("inf")
         a["update"](pa, scans[t], origo)
         b["update"](pa, scans[t], origo)
+        if guard is not None:
+            guard["update"](pa, scans[t], origo)
         for impl in (a, b):
             if "check" in impl:
                 impl["check"](g, t)
@@ -102,7 +120,7 @@ def oracle_impl(pyoracle, kind):
 
 
 @pytest.mark.skipif("hr" not in oracle_kinds(), reason="oracle/_ref/libhector_ref.so not built (needs /root/reference)")
-@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("HSM_HYPOTHESIS_EXAMPLES_CPU", "40")), deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(g=geometry)
 def test_restatement_equals_reference_for_random_geometries(oracle_mod, g):
     cond = run_loop(g, oracle_impl(oracle_mod, "ho"), oracle_impl(oracle_mod, "hr"))
@@ -127,7 +145,8 @@ def test_gpu_default_mode_equals_reference_for_random_geometries(oracle_mod, g):
         m.setUpdateFactorOccupied(occ)
         return {"match": lambda h, sc, og: m.matchData(h, sc, None, og), "update": lambda p, sc, og: m.updateByScan(sc, p, og),
                 "level": m.download_level, "keep": m}
-    cond = run_loop(g, make_gpu, oracle_impl(oracle_mod, oracle_kinds()[-1]))
+    kind = oracle_kinds()[-1]
+    cond = run_loop(g, make_gpu, oracle_impl(oracle_mod, kind), make_guard=oracle_impl(oracle_mod, "ho") if kind == "hr" else None)
     print(f"cond(H) of the last step: {cond}")
 
 
@@ -158,4 +177,5 @@ def test_gpu_dense_update_equals_reference_at_the_borders(oracle_mod, g):
                 assert m.debug_marks_nonzero(lvl) == (0, 0), (gg, t, lvl)
         return {"match": lambda h, sc, og: m.matchData(h, sc, None, og), "update": lambda p, sc, og: m.updateByScan(sc, p, og),
                 "level": m.download_level, "keep": m, "check": check}
-    run_loop(g, make_gpu, oracle_impl(oracle_mod, oracle_kinds()[-1]), steps=6)
+    kind = oracle_kinds()[-1]
+    run_loop(g, make_gpu, oracle_impl(oracle_mod, kind), steps=6, make_guard=oracle_impl(oracle_mod, "ho") if kind == "hr" else None)
