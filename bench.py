@@ -489,7 +489,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
                "time_basis": "update_ms of the step (host timed: step - matchData)", "traffic": None, "kernels": None}
         if not args.no_pmc and nranks == 1 and not under_profiler():
             names = ["update_mark_occ_dense_kernel", "update_mark_occ_kernel", "update_mark_free_dense_kernel", "update_apply_dense_kernel", "update_mark_free_kernel",
-                     "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel", "gn_match_kernel"]
+                     "update_mark_kernel", "update_apply_kernel", "update_texels_kernel", "gn_match_coop_kernel", "gn_match_exact_dense_kernel", "gn_match_kernel"]
             pv, perr = pmc_collect(["--workload", "config5", "--leg", "pmc", "--no-cpu", "--no-pmc"], names, warmup=2)
             pmc_dump(args.pmc_dump, "config5", pv, perr, "configs[4] replica: 16 k-beam scans on the 8192^2 pyramid, match + update per step (plane layout)")
             if pv:
@@ -1321,6 +1321,8 @@ def main():
         return dt, kern_ms, its
 
     def kernel_of(cfg):
+        if cfg.get("kernel"):  # hsm_last_launch_kernel: the library says which kernel ran
+            return cfg["kernel"].split(" ")[0]
         if cfg.get("parity_effective", cfg.get("parity")) == "exact":
             return "gn_match_exact_cached_kernel" if cfg.get("texel_cache") else "gn_match_exact_batch_kernel"
         return "gn_match_cached_kernel" if cfg.get("texel_cache") else "gn_match_kernel"

@@ -114,6 +114,7 @@ SIGNATURES = {
     "hsm_device_info": (_i, [_vp, _i32p]),
     "hsm_set_clock_probe": (_i, [_vp, _vp]),
     "hsm_gn_iterations_per_match": (_i, [_vp]),
+    "hsm_last_launch_kernel": (C.c_char_p, [_vp]),
     "hsm_last_launch_config": (_i, [_vp, _i32p]),
     "hsm_last_error": (C.c_char_p, []),
     "hsm_version": (C.c_char_p, []),
@@ -504,6 +505,7 @@ class MapRepMultiMap:
         return {"layout": {1: "quad", 2: "plane"}.get(int(cfg[0]), "?"), "waves_per_scan": int(cfg[1]),
                 "block": int(cfg[2]), "grid": int(cfg[3]), "beams_per_lane_in_vgprs": max(int(cfg[4]), 0),
                 "texel_cache": bool(cfg[4] < 0), "beams_per_lane": abs(int(cfg[4])),
+                "kernel": (self._lib.hsm_last_launch_kernel(self._h) or b"").decode(),
                 "parity": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed", PARITY_AUTO: "auto"}.get(self.parity(), "fast"),
                 "parity_effective": {PARITY_EXACT: "exact", PARITY_RELAXED: "relaxed"}.get(
                     self._lib.hsm_last_launch_parity(self._h), "fast")}

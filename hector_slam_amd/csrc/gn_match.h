@@ -971,6 +971,135 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
   }
 }
 
+// ---- one DENSE scan in the reference's summation order: producers ahead of the chain (round 5) ---------------------------------
+// The exact-order team form above runs a 16 k-beam scan as rounds of 1024 beams on 16 wavefronts: all of them compute a round's
+// products, then fifteen and a half of them wait while nine lanes add 1024 x 9 values (8.5 cycles per dependent v_add_f32: 3.6 us),
+// then everybody gathers the next round's texels (~1-2 us with nothing else to do) -- 90 us per Gauss-Newton step on configs[4],
+// of which the nine chains themselves are 16 384 x 8.5 cycles = 58 us.  This form takes the chain out of the team: wavefront 0
+// only adds, wavefronts 1..15 only produce, one round AHEAD of it (two stage buffers, one workgroup barrier per round), so a
+// round costs max(chain, production) = the chain.  Same products, same order of the additions: identical bits.  What is left
+// per step is the floor of the literal chain -- n x 8.5 cycles -- plus one round of production before the first addition.
+// (The block-scan form that would have removed the dependent chain itself is a measured negative: tools/study/exact_scan.h,
+// profiles/r05/README.md.)
+constexpr int kDenseProducers = 15;                  // wavefronts
+constexpr int kDenseRound = 64 * kDenseProducers;    // beams per round: one per producer lane
+constexpr int kDenseMinBeams = 2 * kDenseRound;      // below that the team form is as good (host: launch_match_mode)
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(1024) gn_match_exact_dense_kernel(const MatchParams P) {
+  constexpr int RL = kDenseRound;  // staged row length (a multiple of 16: exact_chain reads whole float4 groups)
+  __shared__ __attribute__((aligned(16))) float stage[2][9 * (RL + kExactPad)];
+  __shared__ float totals[9];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool chain_wave = wave == 0;
+  const int ptid = (int)threadIdx.x - 64;  // producer lane 0 .. RL-1 (negative in the chain wavefront)
+  const int scan = (int)blockIdx.x;
+  int beg = 0, n = P.shared_n;
+  if (P.offsets) {
+    beg = P.offsets[scan];
+    n = P.offsets[scan + 1] - beg;
+  }
+  float pw0, pw1, pw2;
+  if (P.begin_world) {
+    pw0 = P.begin_world[3 * scan + 0];
+    pw1 = P.begin_world[3 * scan + 1];
+    pw2 = P.begin_world[3 * scan + 2];
+  } else {
+    pw0 = P.begin_inline[0];
+    pw1 = P.begin_inline[1];
+    pw2 = P.begin_inline[2];
+  }
+  if (n == 0) {  // ScanMatcher.h:68,189
+    if (threadIdx.x == 0) {
+      P.out_pose[3 * scan + 0] = pw0;
+      P.out_pose[3 * scan + 1] = pw1;
+      P.out_pose[3 * scan + 2] = pw2;
+      if (scan == 0) publish_done(P);
+    }
+    return;
+  }
+  const float2* __restrict__ pts = P.pts + beg;
+  const int rounds = (n + RL - 1) / RL;
+  // the chain is the critical path of every round: its wavefront issues ahead of the three producers that share its SIMD
+  if (chain_wave) __builtin_amdgcn_s_setprio(3);
+  auto endpoint_of = [&](int r) -> float2 {  // padding: an endpoint outside any map -> exact +-0 products (gn_match_kernel)
+    const int i = r * RL + ptid;
+    return (ptid >= 0 && i < n) ? pts[i] : make_float2(1.0e30f, 1.0e30f);
+  };
+  Acc9 acc;
+  acc.zero();
+  int step = 0;
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<LAYOUT>(L);
+    for (int it = 0; it < gn_steps; ++it) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      // producers: the products of round r into stage[r & 1]; the endpoint of the round after it is requested meanwhile
+      float2 q_next = endpoint_of(0);
+      auto produce = [&](int r) {
+        const float2 q = q_next;
+        if (r + 1 < rounds) q_next = endpoint_of(r + 1);
+        BeamRot rot;
+        const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{q.x * ps, q.y * ps}, rot);
+        float pr[9];
+        beam_products(b, rot, pr);
+        exact_stage<RL>(pr, stage[r & 1], ptid);
+      };
+      if (!chain_wave) produce(0);
+      float run = 0.0f;
+      for (int r = 0; r < rounds; ++r) {  // workgroup-uniform trip count
+        __syncthreads();  // round r is staged; the chain has left the other buffer
+        if (chain_wave) {
+          run = exact_chain<RL, false>(stage[r & 1], lane, run, min(RL, n - r * RL));
+        } else if (r + 1 < rounds) {
+          produce(r + 1);
+        }
+      }
+      if (chain_wave && lane < 9) totals[lane] = run;
+      __syncthreads();
+      acc.d01 = f2{totals[0], totals[1]}; acc.d2 = totals[2];
+      acc.hd = f2{totals[3], totals[4]}; acc.h22 = totals[5];
+      acc.h01 = totals[6]; acc.hr = f2{totals[7], totals[8]};
+      gn_solve_and_step(acc, ex, ey, eth);
+      if (P.trace) {  // kernel-uniform; only the single-scan hook path sets it
+        if (scan == 0 && threadIdx.x == 0) {
+          float* t = P.trace + 12 * step;
+          t[0] = ex; t[1] = ey; t[2] = eth;
+          t[3] = acc.hd.x; t[4] = acc.h01; t[5] = acc.hr.x;
+          t[6] = acc.h01; t[7] = acc.hd.y; t[8] = acc.hr.y;
+          t[9] = acc.hr.x; t[10] = acc.hr.y; t[11] = acc.h22;
+        }
+        ++step;
+      }
+      // (the next step's first write of totals[] lies behind its rounds' barriers; stage[0] is rewritten by produce(0) of the
+      // next step only after every wavefront has passed the barrier above, and the chain read it last in an earlier round)
+    }
+    eth = normalize_angle(eth);
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+    pw2 = eth;
+  }
+  if (threadIdx.x == 0) {
+    P.out_pose[3 * scan + 0] = pw0;
+    P.out_pose[3 * scan + 1] = pw1;
+    P.out_pose[3 * scan + 2] = pw2;
+    if (P.out_cov) {  // covMatrix = H of the last evaluation (ScanMatcher.h:184), column major
+      float* c = P.out_cov + 9 * scan;
+      c[0] = acc.hd.x; c[1] = acc.h01; c[2] = acc.hr.x;
+      c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
+      c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
+    }
+    if (scan == 0) publish_done(P);
+  }
+}
+
 // ---- throughput form with a per-beam texel cache --------------------------------------------------
 // From the third GN step on the estimate moves by a fraction of a cell, so most beams fall into the SAME
 // map cell as in the step before (bench workload: 77 / 46 / 14 / 2 / 0.2 % of the lanes change cell in steps

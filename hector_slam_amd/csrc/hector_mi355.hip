@@ -216,6 +216,9 @@ struct hsm_ctx {
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
   int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
+  bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
+  int exact_dense_min = 4096;    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
+  const char* last_kernel = "";  // name of the matcher kernel the last launch used (hsm_last_launch_kernel)
   unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
   int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
 };
@@ -358,10 +361,12 @@ int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
       h->last_cfg[3] = grid;
       h->last_cfg[4] = BPL;
       h->last_cfg[5] = 1;
+      h->last_kernel = "gn_match_cached_kernel";
       return HSM_OK;
     }
   }
   h->last_cfg[5] = 0;
+  h->last_kernel = "gn_match_kernel";
   if (h->layout == kLayoutPlane)
     hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, BPL>), dim3(grid), dim3(block), 0, stream, P);
   else
@@ -404,6 +409,7 @@ int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   P.xcd_chunk = h->xcd_chunk_exact > 0 ? (h->xcd_chunk_exact * 4 / NS > 0 ? h->xcd_chunk_exact * 4 / NS : 1) : 0;
   hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
+  h->last_kernel = "gn_match_exact_cached_kernel";
   h->last_cfg[0] = h->layout;
   h->last_cfg[1] = 1;
   h->last_cfg[2] = block;
@@ -456,6 +462,23 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     return HSM_OK;
   }
 #endif
+  if (WPS == 16 && h->exact_dense && max_n >= h->exact_dense_min && max_n >= kDenseMinBeams) {
+    // dense scans: one wavefront adds, fifteen produce one round ahead of it (gn_match_exact_dense_kernel, gn_match.h) -- a
+    // 16 k-beam match of configs[4] in 0.9 instead of 1.2 ms, the nine chains' own 16 384 x 14 x 8.5 cycles being 0.8
+    if (h->layout == kLayoutPlane)
+      hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutPlane>), dim3(P.batch), dim3(1024), 0, stream, P);
+    else
+      hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutQuad>), dim3(P.batch), dim3(1024), 0, stream, P);
+    HIP_TRY(hipGetLastError());
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = 16;
+    h->last_cfg[2] = 1024;
+    h->last_cfg[3] = P.batch;
+    h->last_cfg[4] = 0;
+    h->last_cfg[5] = 0;
+    h->last_kernel = "gn_match_exact_dense_kernel";
+    return HSM_OK;
+  }
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
   if (h->layout == kLayoutPlane)
@@ -469,6 +492,7 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   h->last_cfg[3] = grid;
   h->last_cfg[4] = 0;
   h->last_cfg[5] = 0;
+  h->last_kernel = "gn_match_kernel (exact order)";
   return HSM_OK;
 }
 
@@ -958,6 +982,8 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_DENSE_BITS")) h->dense_bits = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_DENSE")) h->exact_dense = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_DENSE_MIN")) h->exact_dense_min = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
 #if defined(HSM_EXPERIMENTS)  // switches of forms that only an experiment build holds
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);
@@ -1142,6 +1168,7 @@ int hsm_device_info(const hsm_ctx* h, int info[4]) {
 int hsm_gn_iterations_per_match(const hsm_ctx* h) {
   return h ? 6 + 4 * ((int)h->levels.size() - 1) : 0;
 }
+const char* hsm_last_launch_kernel(const hsm_ctx* h) { return h ? h->last_kernel : ""; }
 int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]) {
   if (!h || !cfg) return fail(HSM_ERR_INVALID, "null argument");
   for (int i = 0; i < 5; ++i) cfg[i] = h->last_cfg[i];
@@ -1356,6 +1383,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
       h->last_cfg[2] = 256;
       h->last_cfg[3] = K;
       h->last_cfg[4] = 0;
+      h->last_kernel = "gn_match_coop_kernel";
       h->last_parity = HSM_PARITY_FAST;
     } else {
       // the runtime could not guarantee co-residency (device busy with other work): the one-workgroup

@@ -361,6 +361,9 @@ int hsm_gn_iterations_per_match(const hsm_ctx* h);
  * the texel-cache form: that many beams per lane with endpoints in LDS and the last texel of every beam
  * kept in VGPRs)} */
 int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]);
+/* name of the matcher kernel of the last match launch ("gn_match_exact_cached_kernel", "gn_match_exact_dense_kernel", ...): what
+ * bench.py looks up in the rocprofv3 kernel trace; a static string */
+const char* hsm_last_launch_kernel(const hsm_ctx* h);
 
 const char* hsm_last_error(void);
 const char* hsm_version(void);

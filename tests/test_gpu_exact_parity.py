@@ -198,6 +198,70 @@ def test_dense_scan_bit_identical(capi, oracle_mod, pyramid_scene, kind):
             assert same(pg, po) and same(cg, co), (n_beams, q)
 
 
+@pytest.mark.parametrize("layout", ["quad", "plane"])
+def test_dense_scan_producers_ahead_of_the_chain_form(capi, oracle_mod, pyramid_scene, kind, layout, monkeypatch):
+    """round 5: dense scans in the reference's order run gn_match_exact_dense_kernel -- one wavefront adds, fifteen produce
+    one 960-beam round ahead of it.  Same products, same order of the additions as the 16-wavefront team form
+    (HSM_EXACT_DENSE=0): pose, covariance and every hook-trace record bit-identical to it and to the reference, for scan
+    lengths on both sides of the round boundaries (3 .. 19 rounds, ragged last rounds), in the explicit EXACT mode and in the
+    library default; a batch of dense scans takes the same form"""
+    import ctypes as C
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    lay = capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE
+    monkeypatch.setenv("HSM_EXACT_DENSE_MIN", "1920")
+    g = exact_gpu(capi, sc, o, layout=lay)
+    monkeypatch.setenv("HSM_EXACT_DENSE", "0")
+    team = exact_gpu(capi, sc, o, layout=lay)
+    monkeypatch.delenv("HSM_EXACT_DENSE")
+    auto = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, layout=lay)  # the library default
+    for lvl in range(sc.levels):
+        auto.upload_level(lvl, *o.download_level(lvl))
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    rng = np.random.default_rng(79)
+    lib = capi.load_library()
+    scans = []
+    for n_beams in (2561, 2880, 2881, 4096, 5000, 8192, 16384, 17290):  # (up to 2560 beams a single scan runs on 8 wavefronts)
+        q = n_beams % 3
+        pts = synth.make_scan(sc.world, sc.query_truth[q], n_beams, s, rng, pad_to_full=True)  # exactly n_beams endpoints
+        assert pts.shape[0] == n_beams
+        scans.append((q, pts))
+        pg, cg = g.matchData(sc.query_init[q], pts)
+        cfg = g.last_launch_config()
+        assert cfg["kernel"] == "gn_match_exact_dense_kernel" and cfg["block"] == 1024 and cfg["waves_per_scan"] == 16, (n_beams, pts.shape, cfg)
+        pt, ct = team.matchData(sc.query_init[q], pts)
+        assert team.last_launch_config()["kernel"].startswith("gn_match_kernel"), team.last_launch_config()
+        po, co = o.match(sc.query_init[q], pts)
+        assert same(pg, po) and same(cg, co), (n_beams, "vs the reference")
+        assert same(pg, pt) and same(cg, ct), (n_beams, "vs the team form")
+        pa, ca = auto.matchData(sc.query_init[q], pts)
+        assert same(pa, po) and same(ca, co), (n_beams, "library default")
+        if pts.shape[0] >= 4096:
+            assert auto.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel"
+        # the hook trace (draw / debug interfaces of the facade): 14 records, each the reference's step
+        a = np.ascontiguousarray(pts, np.float32)
+        tr = {}
+        for name, ctx in (("dense", g), ("team", team)):
+            pose, cov, trace, nst = np.zeros(3, np.float32), np.zeros(9, np.float32), np.zeros(14 * 12, np.float32), C.c_int(0)
+            capi._check(lib.hsm_match_trace(ctx._h, sc.query_init[q], a.ctypes.data, a.shape[0], np.zeros(2, np.float32), pose, cov, trace, 14,
+                                            C.byref(nst)), "hsm_match_trace")
+            assert nst.value == 14 and same(pose, po) and same(cov, co), (name, n_beams)
+            tr[name] = trace
+        assert same(tr["dense"], tr["team"]), n_beams
+    # a batch of dense scans: one workgroup per scan
+    sel = [sc_ for sc_ in scans if sc_[1].shape[0] >= 4000][:4]
+    pts, offs = synth.pack_scans([p for _, p in sel])
+    init = np.stack([sc.query_init[q] for q, _ in sel])
+    pb, cb = g.match_batch(init, pts, offs)
+    assert g.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel" and g.last_launch_config()["grid"] == len(sel)
+    for k, (q, p) in enumerate(sel):
+        po, co = o.match(sc.query_init[q], p)
+        assert same(pb[k], po) and same(cb[k], co), k
+    for ctx in (g, team, auto):
+        ctx.close()
+
+
 def test_slam_loop_from_empty_map_bit_identical(capi, oracle_mod, pyramid_scene, kind):
     """HectorSlamProcessor::update from an EMPTY map, 30 scans: identical poses at every step, hence identical update
     decisions and bit-identical maps on all levels at the end -- the whole SLAM state, not just one match"""
