@@ -171,6 +171,14 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
     dth = ang_diff(r["pose"][:, 2], g["pose"][:, 2]).max()
     assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
     assert np.abs(r["cov"] - g["cov"]).max() <= 1e-3 * np.abs(r["cov"]).max()
+    # the library default (round 5: the reference's summation order on the single-scan entry point too): not a bit differs
+    # anywhere -- poses, covariances, the batched extension, every grid, every record the hooks saw
+    exact_default = os.environ.get("HSM_PARITY", "auto") in ("auto", "exact")
+    if exact_default:
+        same = lambda a, b: np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))  # noqa: E731
+        assert same(r["pose"], g["pose"]) and same(r["cov"], g["cov"]) and same(r["batch"], g["batch"])
+        for a, b in zip(r["grids"], g["grids"]):
+            assert same(a["val"], b["val"]) and np.array_equal(a["occ"], b["occ"])
     # the facade's batched extension (one launch) == the reference's per-scan matchData calls
     assert g["batch"].shape == r["batch"].shape == (8, 3)
     assert np.abs(r["batch"][:, :2].astype(np.float64) - g["batch"][:, :2]).max() <= 1e-4
@@ -194,7 +202,9 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
     if hooks == 1:
         assert len(ca) > 1000
         for (t, x), (_, y) in zip(ca, cb):
-            if t == 8:    # Hessians
+            if exact_default:
+                assert np.array_equal(x, y), (t, x, y)
+            elif t == 8:    # Hessians
                 assert np.abs(x - y).max() <= 1e-3 * max(np.abs(x).max(), 1.0)
             elif t in (1, 2):  # drawn points / arrows, world frame
                 assert np.abs(x[:2] - y[:2]).max() <= 2e-4
@@ -203,9 +213,10 @@ def test_dropin_matches_reference_node_loop(tmp_path, pyramid_scene, hooks):
 
 
 @pytest.mark.gpu
-def test_dropin_dense_scans_take_the_cooperative_matcher(tmp_path):
-    """8192-beam scans through the C++ facade: the library switches to the multi-workgroup cooperative matcher
-    (and the standalone driver runs on the system HIP runtime, not torch's) -- same comparison as above"""
+def test_dropin_dense_scans(tmp_path):
+    """8192-beam scans through the C++ facade (the standalone driver runs on the system HIP runtime, not torch's): in the
+    library default they take the exact-order dense matcher -- poses, the batched extension and every grid bit-identical; with
+    HSM_PARITY=fast in the environment the multi-workgroup cooperative matcher, within 1e-4"""
     if not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)):
         pytest.skip("oracle/_ref drivers not prebuilt")
     from hector_slam_amd import synth
@@ -220,6 +231,9 @@ def test_dropin_dense_scans_take_the_cooperative_matcher(tmp_path):
     assert np.abs(r["pose"][:, :2].astype(np.float64) - g["pose"][:, :2]).max() <= 1e-4
     assert ang_diff(r["pose"][:, 2], g["pose"][:, 2]).max() <= 1e-4
     assert np.abs(r["batch"].astype(np.float64) - g["batch"]).max() <= 1e-4
+    exact_default = os.environ.get("HSM_PARITY", "auto") in ("auto", "exact")
+    if exact_default:
+        assert np.array_equal(r["pose"].view(np.uint32), g["pose"].view(np.uint32)) and np.array_equal(r["batch"].view(np.uint32), g["batch"].view(np.uint32))
     for a, b in zip(r["grids"], g["grids"]):
         touched = (a["val"] != 0).sum()
-        assert touched > 1000 and (a["val"].view(np.uint32) != b["val"].view(np.uint32)).sum() <= 0.002 * touched
+        assert touched > 1000 and (a["val"].view(np.uint32) != b["val"].view(np.uint32)).sum() <= (0 if exact_default else 0.002 * touched)

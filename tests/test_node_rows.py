@@ -229,12 +229,13 @@ def capi():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tf_path", [False, True], ids=["laser-scan path", "tf path (node default)"])
-@pytest.mark.parametrize("parity", ["auto", "exact"])
+@pytest.mark.parametrize("parity", ["auto", "exact", "fast"])
 def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, oracle_mod, monkeypatch, parity, tf_path):
     """THE drop-in: hector_mapping/src/HectorMappingRos.cpp, unmodified, compiled once against the reference's include tree and
     once against the tree in which only slam_main/MapRepMultiMap.h is ours (+ libhector_mi355.so).  60 raw LaserScan messages
-    through scanCallback on both: default mode -- every pose within 1e-4 m / 1e-4 rad; HSM_PARITY=exact -- every pose, every
-    covariance, the published occupancy grid and the log-odds of the node's map bit-identical"""
+    through scanCallback on both: the library default (and HSM_PARITY=exact) -- every pose, every covariance, the published
+    occupancy grid and the log-odds of the node's map bit-identical (round 5: the default takes the reference's summation order
+    on the single-scan entry point too); HSM_PARITY=fast -- every pose within 1e-4 m / 1e-4 rad"""
     if not (oracle_mod.available("node") and oracle_mod.available("node_mi355")):
         pytest.skip("oracle/_ref/libhector_node_{ref,mi355}.so not prebuilt (run __graft_entry__.build() where /root/reference exists)")
     monkeypatch.setenv("HSM_PARITY", parity)
@@ -251,12 +252,12 @@ def test_ros_node_source_runs_unchanged_on_the_mi355_map_representation(capi, or
         d = np.abs(pr.astype(np.float64) - pg)
         worst = max(worst, float(d[:2].max()))
         assert d[0] <= 1e-4 and d[1] <= 1e-4 and d[2] <= 1e-4, (parity, t, pr, pg)
-        if parity == "exact":
-            assert np.array_equal(bits(pr), bits(pg)) and np.array_equal(bits(cr), bits(cg)), t
+        if parity != "fast":
+            assert np.array_equal(bits(pr), bits(pg)) and np.array_equal(bits(cr), bits(cg)), (parity, t)
     cells_r, lo_r, ui_r = ref.node_map()
     cells_g, lo_g, ui_g = gpu.node_map()
     assert ui_r == ui_g and (cells_r == 100).sum() > 200
-    if parity == "exact":
+    if parity != "fast":
         assert np.array_equal(cells_r, cells_g) and np.array_equal(bits(lo_r), bits(lo_g))
     else:
         assert (cells_r != cells_g).sum() <= 0.002 * (cells_r != -1).sum()
