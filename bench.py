@@ -4,35 +4,37 @@
 A "step" is one batched matchData over B = 4096 independent 1081-beam scans per GPU on a 2048^2 map
 (BASELINE.json configs[2]: "batch=4096 concurrent 1081-beam scans, 2048^2 map, 1 GPU"), i.e. B x 6 Gauss-Newton
 iterations (1 + 5, ScanMatcher.h:74,94-97) in ONE kernel launch, with scans, start poses and the map already
-resident in HBM.  With --gpus N every rank holds a replica of the map and its own 4096 scans (weak scaling); the
-one collective of the path -- an RCCL all-gather of the [B,3] poses -- is double buffered and asynchronous.  Rank 0
-prints ONE JSON line (see the driver contract in the task description).
+resident in HBM, in the library's DEFAULT parity mode (the reference's summation order: poses bit-identical to the
+reference CPU matcher).  With --gpus N every rank holds a replica of the map and its own 4096 scans (weak scaling); the
+one collective of the path -- an RCCL all-gather of the [B,3] poses -- is double buffered and asynchronous.
 
-Extra evidence in the same line (N = 1 only):
-  roofline      dominant kernel, one HIP event pair on its stream around the timed region.  `bound` names what binds
+OUTPUT.  The LAST stdout line of rank 0 is ONE compact JSON object (< 4 KB, `compact_line`; tests/test_bench_line.py): the
+driver's contract keys, `roofline` and `cpu_baseline`, and `details` = the path of the file that holds the full record
+(gpurun_out/bench_details*.json, or $HSM_BENCH_DETAILS).  Round 4 printed the full record as the line -- 24.6 KB -- and the
+driver could not parse it.
+
+  roofline      the dominant kernel, one HIP event pair on its stream around the timed region.  `bound` names what binds
                 it -- VALU instruction issue -- and achieved / peak / frac are wave64 VALU instructions per second
-                against 1024 SIMDs x clock / 2 cycles, from counters collected IN THIS RUN: bench.py re-executes itself
-                (`--leg pmc`) under `rocprofv3 --pmc`, one pass per counter group.  `traffic` / `hbm` = HBM bytes per
-                launch from the same passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction).  `contract`
-                keeps SURVEY.md 8(d)'s figure (algorithmic bytes / time against 8 TB/s), labelled: it exceeds 1 because
-                endpoints and texels are served on chip, i.e. it is not a utilisation of anything.
-  exact_parity  the same launch in HSM_PARITY_EXACT (reference summation order): throughput, and the fraction of poses
-                bit-identical to the reference on the parity sample (1.0)
-  pyramid       the same batch through the full 3-level 2048/1024/512 schedule (14 iterations, SURVEY.md 8(d)'s start
-                errors +-0.15 m / +-0.05 rad), fast and exact mode, parity fractions vs the reference -- measured in a
-                child process (`--leg pyramid`), so that a kernel trace of this process holds the headline launches only
-  pipelined     independent 4096-scan batches round-robin on 4 caller-owned HIP streams (child process): the throughput when
-                launches overlap -- one launch is one generation of wavefronts, so its tail and its gather-heavy first GN
-                steps leave issue slots that the next batch fills.  The headline `value` stays one launch at a time.
-  cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and scans, single
-                thread (the reference is single threaded), bounded sample, plus the GPU-vs-CPU pose deviation on
-                that sample (parity evidence, tolerance 1e-4) and the fraction of bit-identical poses;
-                cpu_baseline_all_cores: the same on up to 64 host threads
+                against 1024 SIMDs x 2.4 GHz / 2 cycles, from counters collected IN THIS RUN: bench.py re-executes itself
+                (`--leg pmc`) under `rocprofv3 --pmc`, one pass per counter group (N > 1 or --no-pmc: the committed
+                profile profiles/r05/traffic.json, labelled).  `traffic` / `hbm_frac` = HBM bytes per launch from the same
+                passes (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction).  `contract_8d` keeps SURVEY.md
+                8(d)'s figure (algorithmic bytes / time against 8 TB/s), labelled: it exceeds 1 because endpoints and
+                texels are served on chip, i.e. it is not a utilisation of anything.
+  cpu_baseline  the reference CPU matcher (oracle/_ref, else the oracle port) on the SAME map and scans, single thread
+                (the reference is single threaded), ~12 s of matching, plus the GPU-vs-CPU pose deviation on a 512-scan
+                sample and the fraction of bit-identical poses.  Runs on a host thread WHILE the counter passes run in
+                child processes, so the default run takes ~15 s on the GPU box.
+  fast_mode     (details file; `fast_mode_value` in the line) the same launch with HSM_PARITY_FAST (tree summation, opt-in)
 
---workload config2|config3pyr|config4|config5 measures the other BASELINE configs (latency of a single scan, 3-level
-batch, 4096^2 pyramid, dense 16k-beam match+update loop), same JSON schema.  config3pyr / config4 / config5 also run
-with --gpus N: config4 is configs[3] itself at N = 8 (4096 scans per GPU on the 3-level 4096^2 pyramid, all-gather of
-the poses); config5 is configs[4] (replicated pyramid: rank 0 matches, pose + scan are broadcast, every rank replays the
+--all-configs adds to the DETAILS file: the same batch from SURVEY 8(d)'s start errors, HSM_PARITY_RELAXED, the all-cores CPU
+leg, the 3-level pyramid leg, independent batches on 4 streams, and compact child runs of the other BASELINE configs
+(configs[0], [1], [3] share, [4] replica), each with its own counter passes (~80 s).
+
+--workload config2|config3pyr|config4|config5 measures one of the other BASELINE configs (latency of a single scan, 3-level
+batch, 4096^2 pyramid, dense 16k-beam match+update loop) on its own, same output convention.  config3pyr / config4 / config5
+also run with --gpus N: config4 is configs[3] itself at N = 8 (4096 scans per GPU on the 3-level 4096^2 pyramid, all-gather
+of the poses); config5 is configs[4] (replicated pyramid: rank 0 matches, pose + scan are broadcast, every rank replays the
 update, the maps are compared across ranks at the end).
 """
 from __future__ import annotations
@@ -1466,7 +1468,7 @@ def main():
         cpu_thread.join()
     pmc = (pmc_all or {}).get(kernel_name)
     rf = roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
-                        sclk_hz=headline_sclk, committed_profile="r04")
+                        sclk_hz=headline_sclk, committed_profile="r05")
     if cfg.get("parity_effective") == "exact":
         rf["what_binds"] = ("VALU instruction issue plus the serial chain jobs of the reference's summation order (gn_match_exact.h): one "
                             "workgroup barrier per 64-beam round, a 64-deep dependent fp32 chain behind it; texels and endpoints "
