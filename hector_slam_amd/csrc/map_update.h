@@ -651,6 +651,21 @@ __global__ void __launch_bounds__(256) update_mark_free_dense_kernel(const Updat
 #if HSM_MARK_TILE_END
   const gbyte* const tile_end = (const gbyte*)pinned_sgpr(P.lv.free_bytes + mark_tile_end_offset(P.lv.sx, P.lv.sy));
 #endif
+#if defined(HSM_EXPERIMENTS) && defined(HSM_WHATIF_WALK)
+  // TIMING EXPERIMENTS ONLY (wrong maps): what a binned LDS tile rasteriser could gain on the walk (round-4 verdict, item 3).
+  //   1: no memory operation at all -- the walk's arithmetic alone;  2: the marks go to LDS bytes (ds_write_b8) instead of HBM
+  __shared__ unsigned char lds_marks[16384];
+  unsigned int sink = 0u;
+  for (unsigned int i = lane; i < da; i += 64) {
+    if (!(i < pda && pq == q)) {
+      const unsigned int kc = cell_index();
+      if (HSM_WHATIF_WALK == 2) lds_marks[kc & 16383u] = kMarkCrossed; else sink ^= kc;
+    }
+    advance();
+  }
+  if (sink == 0x9e3779b9u || (HSM_WHATIF_WALK == 2 && lds_marks[lane] == 77)) marks[0] = 1;  // (keeps the loop alive)
+  return;
+#endif
   for (unsigned int i = lane; i < da; i += 64) {  // abs_da free cells: steps 0 .. abs_da-1
     if (!(i < pda && pq == q)) {
       const unsigned int kc = cell_index();
