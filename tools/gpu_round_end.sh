@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, call H: the round's final build -- suite (60 hypothesis examples), smoke, the driver's bench command + the same under
+# Round-end validation of the current build on one MI355X box (gpurun): suite (60 hypothesis examples), smoke, the driver's bench command + the same under
 # rocprofv3 --kernel-trace --stats, the long bench run, node loop + soaks in the default mode, ThreadSanitizer over the facade
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/r05h
+OUT=$ROOT/gpurun_out/${HSM_ROUND_TAG:-round_end}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 S=$(date +%s)
