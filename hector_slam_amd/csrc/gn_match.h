@@ -983,7 +983,6 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
 // profiles/r05/README.md.)
 constexpr int kDenseProducers = 15;                  // wavefronts
 constexpr int kDenseRound = 64 * kDenseProducers;    // beams per round: one per producer lane
-constexpr int kDenseMinBeams = 2 * kDenseRound;      // below that the team form is as good (host: launch_match_mode)
 
 template <int LAYOUT>
 __global__ void __launch_bounds__(1024) gn_match_exact_dense_kernel(const MatchParams P) {
@@ -1023,10 +1022,19 @@ __global__ void __launch_bounds__(1024) gn_match_exact_dense_kernel(const MatchP
   const int rounds = (n + RL - 1) / RL;
   // the chain is the critical path of every round: its wavefront issues ahead of the three producers that share its SIMD
   if (chain_wave) __builtin_amdgcn_s_setprio(3);
-  auto endpoint_of = [&](int r) -> float2 {  // padding: an endpoint outside any map -> exact +-0 products (gn_match_kernel)
+  auto endpoint_load = [&](int r) -> float2 {  // padding: an endpoint outside any map -> exact +-0 products (gn_match_kernel)
     const int i = r * RL + ptid;
     return (ptid >= 0 && i < n) ? pts[i] : make_float2(1.0e30f, 1.0e30f);
   };
+  // a scan of one or two rounds (the node's 1081 beams) keeps its endpoints in registers across all levels and GN steps: one
+  // dependent memory round trip per step -- the texel gather -- before the chain can start, instead of two
+  const bool resident = rounds <= 2;  // (workgroup-uniform)
+  float2 xq0 = make_float2(1.0e30f, 1.0e30f), xq1 = xq0;
+  if (resident) {
+    xq0 = endpoint_load(0);
+    if (rounds > 1) xq1 = endpoint_load(1);
+  }
+  auto endpoint_of = [&](int r) -> float2 { return resident ? (r == 0 ? xq0 : xq1) : endpoint_load(r); };
   Acc9 acc;
   acc.zero();
   int step = 0;

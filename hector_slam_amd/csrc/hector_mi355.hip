@@ -462,23 +462,6 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     return HSM_OK;
   }
 #endif
-  if (WPS == 16 && h->exact_dense && max_n >= h->exact_dense_min && max_n >= kDenseMinBeams) {
-    // dense scans: one wavefront adds, fifteen produce one round ahead of it (gn_match_exact_dense_kernel, gn_match.h) -- a
-    // 16 k-beam match of configs[4] in 0.9 instead of 1.2 ms, the nine chains' own 16 384 x 14 x 8.5 cycles being 0.8
-    if (h->layout == kLayoutPlane)
-      hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutPlane>), dim3(P.batch), dim3(1024), 0, stream, P);
-    else
-      hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutQuad>), dim3(P.batch), dim3(1024), 0, stream, P);
-    HIP_TRY(hipGetLastError());
-    h->last_cfg[0] = h->layout;
-    h->last_cfg[1] = 16;
-    h->last_cfg[2] = 1024;
-    h->last_cfg[3] = P.batch;
-    h->last_cfg[4] = 0;
-    h->last_cfg[5] = 0;
-    h->last_kernel = "gn_match_exact_dense_kernel";
-    return HSM_OK;
-  }
   const int block = 64 * WPS * SPB;
   const int grid = (P.batch + SPB - 1) / SPB;
   if (h->layout == kLayoutPlane)
@@ -539,8 +522,29 @@ int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream
   return rc;
 }
 
+// reference order, launches that cannot fill the chip with one wavefront per scan (single scans, small batches): one wavefront
+// adds, fifteen produce one round ahead of it (gn_match_exact_dense_kernel, gn_match.h) -- a 16 k-beam match of configs[4] in
+// 0.9 instead of 1.2 ms, the nine chains' own 16 384 x 14 x 8.5 cycles being 0.8
+int launch_match_exact_dense(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutPlane>), dim3(P.batch), dim3(1024), 0, stream, P);
+  else
+    hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutQuad>), dim3(P.batch), dim3(1024), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = 16;
+  h->last_cfg[2] = 1024;
+  h->last_cfg[3] = P.batch;
+  h->last_cfg[4] = 0;
+  h->last_cfg[5] = 0;
+  h->last_kernel = "gn_match_exact_dense_kernel";
+  return HSM_OK;
+}
+
 int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
-  switch (choose_wps(h, P.batch, max_n)) {
+  const int wps = choose_wps(h, P.batch, max_n);
+  if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, stream);
+  switch (wps) {
     case 1: {
       // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
       // per-beam workgroup barrier (MatchParams::wg_sync) eight waves share the texel lines in the CU's L1 (4096^2
