@@ -1029,12 +1029,19 @@ __global__ void __launch_bounds__(1024) gn_match_exact_dense_kernel(const MatchP
   // a scan of one or two rounds (the node's 1081 beams) keeps its endpoints in registers across all levels and GN steps: one
   // dependent memory round trip per step -- the texel gather -- before the chain can start, instead of two
   const bool resident = rounds <= 2;  // (workgroup-uniform)
-  float2 xq0 = make_float2(1.0e30f, 1.0e30f), xq1 = xq0;
+  float xq0x = 1.0e30f, xq0y = 1.0e30f, xq1x = 1.0e30f, xq1y = 1.0e30f;  // (scalars: a float2 selected through a lambda went to scratch)
   if (resident) {
-    xq0 = endpoint_load(0);
-    if (rounds > 1) xq1 = endpoint_load(1);
+    const float2 a = endpoint_load(0);
+    xq0x = a.x, xq0y = a.y;
+    if (rounds > 1) {
+      const float2 b = endpoint_load(1);
+      xq1x = b.x, xq1y = b.y;
+    }
   }
-  auto endpoint_of = [&](int r) -> float2 { return resident ? (r == 0 ? xq0 : xq1) : endpoint_load(r); };
+  auto endpoint_of = [&](int r) -> float2 {
+    if (!resident) return endpoint_load(r);
+    return make_float2(r == 0 ? xq0x : xq1x, r == 0 ? xq0y : xq1y);
+  };
   Acc9 acc;
   acc.zero();
   int step = 0;
