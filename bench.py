@@ -173,9 +173,27 @@ def details_file(out: dict):
     return path
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner ("RCCL version : ...", "Librccl path : ...") with printf; piped, that sits in libc's stdout
+    buffer until the process exits -- i.e. it would land BEHIND the JSON line.  Flushing libc's streams first puts it in front."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+_DEFER_EMIT = False  # N > 1: the line is held back until the process group is gone and the other ranks have exited (main)
+_PENDING = []
+
+
 def emit(out: dict):
     """Top-level result: full record -> details file, compact record -> the LAST stdout line.  A child leg of another bench.py
     (run_child sets HSM_BENCH_CHILD=1) prints its full record for the parent to embed."""
+    if _DEFER_EMIT:
+        _PENDING.append(out)
+        return
+    flush_c_stdio()
     if os.environ.get("HSM_BENCH_CHILD") == "1":
         print(json.dumps(out))
         return
@@ -1216,10 +1234,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.workload != "config3":
         assert world == 1 or args.workload != "config2", "config2 is the single-scan latency measurement"
+        global _DEFER_EMIT
+        _DEFER_EMIT = world > 1
         extra_workload(args.workload, args, local_rank, rank, world)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+            flush_c_stdio()
+            _DEFER_EMIT = False
+            if _PENDING:
+                time.sleep(1.0)  # (see the end of main: the line comes last)
+                emit(_PENDING.pop())
         return
 
     B = args.batch
@@ -1572,6 +1597,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
+        if rank == 0:
+            time.sleep(1.0)  # the other ranks exit now (and flush whatever their libraries still hold): the line comes last
     if rank == 0:
         emit(out)
 
