@@ -71,3 +71,20 @@ def test_child_legs_keep_the_full_record(monkeypatch):
     with redirect_stdout(buf):
         bench.emit(rec)
     assert json.loads(buf.getvalue().strip().splitlines()[-1]) == rec
+
+
+def test_deferred_emit_holds_the_line_back(monkeypatch, tmp_path):
+    """N > 1: the line of an extra workload is held until the process group is destroyed and the other ranks have exited
+    (RCCL's printf banner would otherwise land behind it); emit() then prints it"""
+    rec = canned()
+    monkeypatch.setenv("HSM_BENCH_DETAILS", str(tmp_path / "d.json"))
+    monkeypatch.delenv("HSM_BENCH_CHILD", raising=False)
+    monkeypatch.setattr(bench, "_DEFER_EMIT", True)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(rec)
+    assert buf.getvalue() == "" and bench._PENDING and bench._PENDING[-1] is rec
+    monkeypatch.setattr(bench, "_DEFER_EMIT", False)
+    with redirect_stdout(buf):
+        bench.emit(bench._PENDING.pop())
+    assert json.loads(buf.getvalue().strip().splitlines()[-1])["value"] == rec["value"]

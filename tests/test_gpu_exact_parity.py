@@ -249,6 +249,13 @@ def test_dense_scan_producers_ahead_of_the_chain_form(capi, oracle_mod, pyramid_
             assert nst.value == 14 and same(pose, po) and same(cov, co), (name, n_beams)
             tr[name] = trace
         assert same(tr["dense"], tr["team"]), n_beams
+    # single-level matchData (ScanMatcher::matchData with an explicit iteration count) on a dense scan, library default
+    q, pts = scans[-2]
+    lvl_pts = pts * np.float32(0.5)
+    pl, cl = auto.match_level(1, sc.query_init[q], lvl_pts, 7)
+    assert auto.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel"
+    pol, col = o.match_level(1, sc.query_init[q], lvl_pts, 7)
+    assert same(pl, pol) and same(cl, col), "single-level dense match"
     # a batch of dense scans: one workgroup per scan
     sel = [sc_ for sc_ in scans if sc_[1].shape[0] >= 4000][:4]
     pts, offs = synth.pack_scans([p for _, p in sel])
