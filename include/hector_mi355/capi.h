@@ -64,11 +64,15 @@ typedef struct hsm_opts {
  *   RELAXED  FAST with the multiply-add pairs of the per-beam arithmetic contracted to fused operations (32 instead of
  *          51 fp32 operations per beam) in the batched throughput kernel; everything else runs as FAST.  Per-beam terms
  *          are no longer bit-exact; the bar is north_star's 1e-4 m / 1e-4 rad on the pose, measured at full size.
- *   AUTO   (default) every BATCHED match (hsm_match_batch*, hsm_group_match_batch*) runs EXACT, single scans run FAST.  Round 4's
- *          scene sweep (profiles/r04/parity_scene_sweep.jsonl: six scene families on maps of up to 2^23 cells, three start /
- *          level set-ups, 4096 scans each) finds the fast tree beyond 1e-4 m of the reference on some scans of every family
- *          wherever the reference's own iteration has not settled; single scans were within on 100 % in five families and
- *          over a 5 000-scan node loop (the exact single-scan form costs 4x the latency).  hsm_last_launch_parity() tells.
+ *   AUTO   (default) the reference's order on EVERY entry point -- hsm_match (with and without the hook trace), hsm_match_level,
+ *          hsm_match_batch*, hsm_group_match_batch*, the likelihood / covariance / Hessian probes: results bit-identical to the
+ *          reference CPU matcher.  AUTO may pick any kernel form that is bit-identical to the reference's chains (today the
+ *          same forms EXACT pins).  Why the default does not use the tree anywhere (rounds 4 and 5): the scene sweeps
+ *          (profiles/r04/parity_scene_sweep.jsonl, profiles/r05/parity_scene_sweep_single_default.jsonl: seven scene families,
+ *          three start / level set-ups, 4096 scans each) find the fast tree beyond 1e-4 m of the reference on some scans of every
+ *          family wherever the reference's own iteration has not settled, and nothing known at launch separates those scans --
+ *          for one scan no more than for a batch.  Price: a 1081-beam hsm_match takes 104 us instead of 33, a batch 1.3x the
+ *          tree's time.  hsm_last_launch_parity() tells which order the last launch ran in.
  * env HSM_PARITY=fast|exact|relaxed|auto selects a mode at hsm_create (any other word: hsm_create fails), hsm_set_parity
  * switches at run time. */
 enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2, HSM_PARITY_AUTO = 3 };
@@ -99,8 +103,8 @@ int hsm_on_map_updated(hsm_ctx* h);
 /* no reference counterpart: selects HSM_PARITY_FAST / _EXACT / _RELAXED / _AUTO for all later matches of the context */
 int hsm_set_parity(hsm_ctx* h, int mode);
 int hsm_parity(const hsm_ctx* h);
-/* the mode the LAST match launch of this context actually ran in (HSM_PARITY_FAST / EXACT / RELAXED): under
- * HSM_PARITY_AUTO the library picks per launch */
+/* the order the LAST match launch of this context actually ran in (HSM_PARITY_FAST / EXACT / RELAXED); under HSM_PARITY_AUTO:
+ * EXACT */
 int hsm_last_launch_parity(const hsm_ctx* h);
 
 /* ---- the hot path -----------------------------------------------------------
