@@ -30,19 +30,21 @@
 //     last texel of every beam stays in VGPRs, endpoints in LDS, gathers only in the
 //     lanes whose cell changed, issued one beam ahead with counted s_waitcnt (inline
 //     asm), first GN step peeled so that it runs while the endpoints stream in;
-//   * a single DENSE scan (>= 4096 beams) is spread over up to 64 workgroups of one
-//     cooperative launch instead (gn_match_coop_kernel, one grid sync per GN step).
+//   * a single DENSE scan (>= 4096 beams): in the default mode one workgroup whose first wavefront
+//     adds while fifteen produce one round ahead of it (gn_match_exact_dense_kernel); with
+//     HSM_PARITY_FAST up to 64 workgroups that exchange tagged partial sums (gn_match_coop_kernel).
 //   No MFMA: this is a bilinear gather plus a 9-term reduction, not a contraction.
 //   Measured limits (profiles/r02/README.md): VALU issue (61 instructions per beam) and
 //   the texture path of the divergent 16-byte gathers -- not HBM.
 //
 // Numerics: built with -ffp-contract=off.  Every per-beam value (M, dM/dx, dM/dy,
 // rotDeriv and the nine products) is the same IEEE fp32 expression, in the same
-// order, as the reference; only the ORDER of the beam summation differs (strided
-// partial sums + tree instead of one sequential chain) -- and with HSM_PARITY_EXACT not
-// even that: the nine per-beam products are staged through LDS and summed by nine lanes
-// in beam order, i = 0 .. n-1, exactly the reference's fp32 chains.  sinf/cosf/expf are
-// glibc's algorithms operation for operation (libm_exact.h): identical bits.
+// order, as the reference.  In the DEFAULT mode (HSM_PARITY_AUTO, and HSM_PARITY_EXACT) the
+// nine per-beam products are staged through LDS and summed by nine lanes in beam order,
+// i = 0 .. n-1, exactly the reference's fp32 chains: identical bits on every entry point.
+// The opt-in HSM_PARITY_FAST changes only the ORDER of the beam summation (strided partial
+// sums + tree instead of one sequential chain).  sinf/cosf/expf are glibc's algorithms
+// operation for operation (libm_exact.h): identical bits.
 #pragma once
 // Measured variants that are not shipped (the two-wave texel-cache form, per-wave time stamps) only compile with
 // -DHSM_EXPERIMENTS; the default library holds the shipped forms alone.
