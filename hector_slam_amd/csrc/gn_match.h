@@ -456,6 +456,8 @@ __device__ __forceinline__ float beam_accumulate(const LevelRegs& L, float ex, f
 // The nine chains run side by side in nine lanes; a round costs 64 dependent v_add_f32 per 64 beams on
 // top of the beam arithmetic (about 2.5x the instruction count of the fast form).  Padding lanes and
 // out-of-map beams contribute +-0, which leaves a running sum that started at +0 unchanged bit for bit.
+constexpr int kExactGroupRounds = 5;  // rounds the exact-order team form fetches, stages and sums together; a scan of at most that
+                                      // many rounds keeps its endpoints in registers (xq_resident): it is read from memory ONCE
 constexpr int kExactPad = 4;  // row stride T + 4 floats: rows stay 16-byte aligned, the nine chain lanes hit distinct banks
 
 // the nine products with the reference's signs (g = -G): dTr[0..2], H(0,0), H(1,1), H(2,2), H(0,1), H(0,2), H(1,2)
@@ -733,7 +735,7 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
   __shared__ __attribute__((aligned(16))) float red[2][9][WPS < 4 ? 4 : WPS];
   // exact order: [team][term][beam]; single-scan teams of up to four wavefronts stage a whole GROUP of rounds (kXGroup x T beams,
   // 46 KB at four wavefronts) and sum it in one go, the others round by round
-  constexpr int kXGroup = 5;
+  constexpr int kXGroup = kExactGroupRounds;
   constexpr int kXStaged = (EXACT && SPB == 1 && T <= 256) ? kXGroup : 1;  // rounds staged together
   constexpr int kXRowLen = kXStaged * T;
   __shared__ float stage[EXACT ? SPB * 9 * (kXRowLen + kExactPad) : 1];

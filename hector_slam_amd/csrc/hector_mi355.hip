@@ -1423,13 +1423,26 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   return HSM_OK;
 }
 
+// Does the matcher read the endpoints of a single n-beam scan exactly ONCE?  Then they can stay in pinned, device-mapped host
+// memory (no H2D copy command in front of the kernel); otherwise -- re-read in every GN step -- they must live in device memory.
+//   tree summation: the register-resident forms (BPL > 0), unless the multi-workgroup dense matcher takes the scan;
+//   reference order (round 5): the team form keeps a scan of at most kExactGroupRounds rounds in registers across all levels and
+//     steps (gn_match_kernel: xq_resident) -- every single scan below the dense threshold --, the producers-ahead form a scan of
+//     at most two of its rounds
+static bool scan_is_read_once(const hsm_ctx* h, int n) {
+  if (!wants_exact(h))
+    return n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && (n < h->coop_min_beams || h->wps_override != 0);
+  const int wps = choose_wps(h, 1, n);
+  if (wps > 1 && h->wps_override == 0 && h->exact_dense && n >= h->exact_dense_min) return n <= 2 * kDenseRound;
+  return n <= kExactGroupRounds * 64 * wps;
+}
+
 // stage a host scan where the matcher can read it: pinned mapped host memory when it will be read
 // once (register resident), device memory otherwise
 static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, size_t& d_cap, const float2** out) {
   // (a dense scan for the multi-workgroup matcher is re-read every GN step: it must live in device memory)
   // (and so does the exact-order form)
-  if (n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !wants_exact(h) &&
-      (n < h->coop_min_beams || h->wps_override != 0)) {
+  if (scan_is_read_once(h, n)) {
     if ((size_t)n > h->h_scan_pinned_cap) {
       if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
       h->h_scan_pinned = nullptr;
@@ -1520,8 +1533,7 @@ static int match_impl(hsm_ctx* h, const float begin_world[3], const float* pts_x
   const float2* pts = d_prestaged;
   if (!pts) {
     // (the same rule as stage_scan's: scans the matcher reads once stay in pinned host memory)
-    const bool to_device = !(n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && !wants_exact(h) &&
-                             (n < h->coop_min_beams || h->wps_override != 0));
+    const bool to_device = !scan_is_read_once(h, n);
     // ... and only behind an update that was queued and not waited for (the match + update loop): on an idle stream the
     // extra hop through the copy stream's event costs ~10 us of latency and hides nothing (asking the runtime with
     // hipStreamQuery costs half of what the overlap gains: 0.1855 against 0.179 ms per configs[4] step)

@@ -71,7 +71,7 @@ typedef struct hsm_opts {
  *          (profiles/r04/parity_scene_sweep.jsonl, profiles/r05/parity_scene_sweep_single_default.jsonl: seven scene families,
  *          three start / level set-ups, 4096 scans each) find the fast tree beyond 1e-4 m of the reference on some scans of every
  *          family wherever the reference's own iteration has not settled, and nothing known at launch separates those scans --
- *          for one scan no more than for a batch.  Price: a 1081-beam hsm_match takes 104 us instead of 33, a batch 1.3x the
+ *          for one scan no more than for a batch.  Price: a 1081-beam hsm_match takes 99 us instead of 33, a batch 1.3x the
  *          tree's time.  hsm_last_launch_parity() tells which order the last launch ran in.
  * env HSM_PARITY=fast|exact|relaxed|auto selects a mode at hsm_create (any other word: hsm_create fails), hsm_set_parity
  * switches at run time. */
