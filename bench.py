@@ -723,7 +723,7 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
 
     def timed(steps, warmup):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        gatherer = sharding.AsyncRowGather(B, 3, dev) if nranks > 1 else None
+        gatherer = sharding.BucketedRowGather(B, 3, dev, bucket=args.gather_bucket) if nranks > 1 else None
 
         def step():
             pose_buf = gatherer.next_local() if gatherer else d_pose
@@ -750,13 +750,14 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
             step()
         ev1.record(stream)
         if gatherer:
+            gatherer.flush()
             gatherer.wait_all()
         if nranks > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if gatherer:
-            allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
+            allp = gatherer.last_result()
             d_pose.copy_(allp[rank * B:(rank + 1) * B])
         if nranks > 1:
             timed.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
@@ -1175,6 +1176,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-exact", action="store_true", help="skip the HSM_PARITY_EXACT leg")
     ap.add_argument("--streams", type=int, default=4, help="caller-owned streams of the `pipelined` leg")
+    ap.add_argument("--gather-bucket", type=int, default=32,
+                    help="N > 1: batched matches whose poses travel in ONE all-gather (1 = a collective per match).  Enqueueing a "
+                         "torch.distributed collective costs the host ~45 us, and an RCCL kernel that runs beside a matcher launch takes "
+                         "CUs from its one generation of workgroups (+45 us for that launch): measured with the real nccl backend, us per "
+                         "step = 103 / 65.5 / 62.0 for buckets of 1 / 8 / >= the region's steps, 59.6 without any gather, 58.5 at N = 1")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the multi-stream leg")
     ap.add_argument("--compact", action="store_true",
                     help="extra workloads: the short form the default run embeds (fewer steps, smaller CPU samples)")
@@ -1225,8 +1231,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HSM_BENCH_FORCE_DIST=1: a process group even for ONE rank -- the double-buffered RCCL all-gather, the barriers and the
+    # rank records of the N > 1 path run on a 1-GPU box through the real "nccl" backend (a gather of one shard)
+    multi = world > 1 or os.environ.get("HSM_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         if os.environ.get("HSM_BENCH_SHARE_GPU") == "1":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -1284,7 +1294,10 @@ def main():
         # consecutive kernels; the overlapped all-gather of N > 1 runs on RCCL's own stream)
         # N > 1: the one collective of the path -- an all-gather of the [B,3] poses -- is double buffered and
         # asynchronous, so RCCL moves batch k's poses while the matcher already works on batch k+1
-        gatherer = sharding.AsyncRowGather(B, 3, dev) if (world > 1 and gather) else None
+        # (bucketed: enqueueing one torch.distributed all-gather costs the host ~45 us, and its kernel beside a matcher launch
+        # breaks that launch's single generation of workgroups -- measured with the real nccl backend, profiles/r05/README.md 7 --
+        # so the poses of `--gather-bucket` consecutive batches travel in one collective)
+        gatherer = sharding.BucketedRowGather(B, 3, dev, bucket=args.gather_bucket) if (multi and gather and os.environ.get("HSM_BENCH_NO_GATHER") != "1") else None
 
         def step():
             pose_buf = gatherer.next_local() if gatherer else d_pose
@@ -1309,10 +1322,12 @@ def main():
                 torch.cuda.synchronize()
         for _ in range(warmup):
             step()
+        if gatherer:
+            gatherer.flush()
         regions = []
         for rep in range(max(1, repeats)):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -1321,20 +1336,27 @@ def main():
                 step()
             ev1.record(stream)
             if gatherer:
+                gatherer.flush()  # the last, partially filled bucket travels inside the timed region
                 gatherer.wait_all()
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            if gatherer:  # every rank holds all poses; keep this rank's own rows for the checks below
-                allp = gatherer.result((gatherer.k - 1) % gatherer.depth)
-                d_pose.copy_(allp[rank * B:(rank + 1) * B])
-            if world > 1:
-                run.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
+            dt_local = dt
+            if multi:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             regions.append((dt, ev0.elapsed_time(ev1) / steps))
+        # (after the LAST region only: the digest arithmetic and host copies of the rank record are milliseconds of other work, and
+        # a 20-launch region that follows them runs on a decayed engine clock -- 66-69 instead of 58 us per launch, measured)
+        if gatherer:  # every rank holds all poses; keep this rank's own rows for the checks below
+            allp = gatherer.last_result()
+            d_pose.copy_(allp[rank * B:(rank + 1) * B])
+        if multi:
+            run.ranks = multi_rank_record(dt_local, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
+            if gatherer:
+                run.ranks.update({"gather_bucket": gatherer.bucket, "collectives_total": gatherer.collectives})
         order = sorted(range(len(regions)), key=lambda i: regions[i][0])
         dt, kern_ms = regions[order[len(order) // 2]]
         run.regions = {"repeats": len(regions), "steps_each": steps, "prewarm_ms": args.prewarm_ms, "ms_per_step": [r[0] / steps * 1e3 for r in regions],
@@ -1516,7 +1538,7 @@ def main():
         "timed_regions": regions,
         "roofline": rf,
     }
-    if world > 1:
+    if multi:
         out["ranks"] = getattr(run, "ranks", None)
         if args.all_configs and not args.no_group and os.environ.get("HSM_BENCH_SHARE_GPU") != "1":
             # the C++ single-process group over the same devices, RCCL gather and peer gather (child of rank 0)
@@ -1594,7 +1616,7 @@ def main():
         out["configs"] = cf
     if not full and single:
         out["not_run"] = "the 8(d)-start, relaxed, all-cores, pyramid, pipelined and other-config legs: `bench.py --all-configs` (details file)"
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
         flush_c_stdio()

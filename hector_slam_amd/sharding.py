@@ -1,7 +1,8 @@
 """Multi-GPU data parallelism for batched matching: one process per GPU, the pyramid replicated,
-the batch of independent (pose hypothesis, scan) pairs split contiguously across ranks, and ONE
-collective per batched match -- an all-gather of the [B/G, 3] fp32 poses (optionally the
-[B/G, 9] Hessians).  With backend "nccl" this is RCCL over xGMI; the payload is tens of KiB per
+the batch of independent (pose hypothesis, scan) pairs split contiguously across ranks, and ONE kind of
+collective -- an all-gather of the [B/G, 3] fp32 poses (optionally the [B/G, 9] Hessians), per batched match
+(AsyncRowGather) or, for a stream of batches, per bucket of batches (BucketedRowGather: the host cost of
+enqueueing a collective is as large as a whole matcher launch).  With backend "nccl" this is RCCL over xGMI; the payload is tens of KiB per
 rank, i.e. latency-bound, so a single un-bucketed all-gather is the right shape.
 The reference has no distributed path at all; nothing here translates reference code.
 """
@@ -104,6 +105,82 @@ class AsyncRowGather:
             if self.work[s] is not None:
                 self.work[s].wait()
                 self.work[s] = None
+
+
+class BucketedRowGather:
+    """The same gather, BUCKETED: the rows of ``bucket`` consecutive batches travel in ONE all-gather.
+
+    Measured on MI355X with the real "nccl" backend (bench.py, HSM_BENCH_FORCE_DIST=1, profiles/r05/README.md 7): enqueueing one
+    asynchronous torch.distributed all-gather costs the host ~45 us -- as much as the 58 us matcher launch it is supposed to hide
+    behind -- and the RCCL kernel, running beside a matcher launch, takes CUs from that launch's single generation of workgroups
+    (+45 us for it).  A loop that gathers after EVERY batched match runs at 103 us per step instead of 58.5 (238 M instead of 418 M GN
+    it/s per GPU); buckets of 8: 65.5 us; one collective behind the last match of a stream of batches: 62.0 us (59.6 with no gather at
+    all).  The payload is tiny (48 KiB per rank and batch), so nothing is lost by sending ``bucket`` batches at once: the poses of
+    batch k go into slot k % bucket of a [bucket, rows, cols] block, a full block is all-gathered asynchronously (RCCL's own stream,
+    ordered behind the compute stream at enqueue time) while the next block fills; ``depth`` blocks rotate.  ``flush()`` sends a
+    partially filled block (end of a stream of batches).  Every rank ends up with every rank's rows of every batch.
+    With no process group initialised it degenerates to handing local buffers back.
+    """
+
+    def __init__(self, rows_per_rank: int, cols: int, device, dtype=torch.float32, bucket: int = 8, depth: int = 2, group=None):
+        self.group = group
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rows, self.cols, self.bucket, self.depth = rows_per_rank, cols, max(1, bucket), max(2, depth)
+        self.local = [torch.zeros((self.bucket, rows_per_rank, cols), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.out = [torch.empty((self.world, self.bucket, rows_per_rank, cols), dtype=dtype, device=device) if self.dist else None
+                    for _ in range(self.depth)]
+        self.work = [None] * self.depth
+        self.block = 0      # block being filled
+        self.fill = 0       # batches already in it
+        self.collectives = 0
+        self.last = None    # (block, slot) of the most recent batch
+
+    def next_local(self) -> torch.Tensor:
+        """[rows, cols] view the next batch's results go into (entering a block waits, on the stream, for the collective that last
+        used it)"""
+        if self.fill == 0 and self.work[self.block] is not None:
+            self.work[self.block].wait()
+            self.work[self.block] = None
+        return self.local[self.block][self.fill]
+
+    def launch(self) -> None:
+        """the batch handed out by the last next_local() has been queued on the compute stream; a full block is sent"""
+        self.last = (self.block, self.fill)
+        self.fill += 1
+        if self.fill == self.bucket:
+            self.flush()
+
+    def flush(self) -> None:
+        """send the block being filled (all ``bucket`` slots travel; the unfilled ones carry stale rows nobody reads)"""
+        if self.fill == 0:
+            return
+        if self.dist:
+            self.work[self.block] = dist.all_gather_into_tensor(self.out[self.block].view(-1, self.cols),
+                                                                self.local[self.block].view(-1, self.cols), group=self.group, async_op=True)
+            self.collectives += 1
+        self.block = (self.block + 1) % self.depth
+        self.fill = 0
+
+    def wait_all(self) -> None:
+        for b in range(self.depth):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+
+    def last_result(self) -> torch.Tensor:
+        """[world * rows, cols]: every rank's rows of the most recent batch (flushes and waits for its block)"""
+        if self.last is None:
+            raise RuntimeError("BucketedRowGather.last_result: no batch yet")
+        b, slot = self.last
+        if b == self.block and self.fill > 0:
+            self.flush()
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        if not self.dist:
+            return self.local[b][slot]
+        return self.out[b][:, slot].reshape(self.world * self.rows, self.cols)
 
 
 class ReplicaSync:

@@ -76,6 +76,60 @@ def test_two_rank_async_gather_double_buffered():
     assert all(ok for _, ok in res)
 
 
+def _worker_bucketed(rank, world, port, rows, q):
+    sys.path.insert(0, ROOT)
+    from hector_slam_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sharding.BucketedRowGather(rows, 3, "cpu", bucket=4, depth=2)
+        ok = True
+        seen = {}
+        for k in range(23):  # 5 full buckets + a partial one: every block is reused, batches must never mix
+            buf = g.next_local()
+            buf.copy_(torch.full((rows, 3), float(100 * k + rank)))  # "the matcher wrote batch k"
+            g.launch()
+            if k % 5 == 2:  # look at the most recent batch now and then (flushes a partial bucket early)
+                out = g.last_result()
+                exp = torch.cat([torch.full((rows, 3), float(100 * k + r)) for r in range(world)])
+                ok = ok and bool(torch.equal(out, exp))
+                seen[k] = True
+        g.flush()
+        g.wait_all()
+        out = g.last_result()
+        exp = torch.cat([torch.full((rows, 3), float(100 * 22 + r)) for r in range(world)])
+        ok = ok and bool(torch.equal(out, exp))
+        q.put((rank, ok, g.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_gather():
+    """one all-gather per bucket of batches (what bench.py's N > 1 loop uses): blocks rotate, partial buckets flush, the most
+    recent batch is always retrievable, and fewer collectives run than batches"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, 257, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(5 <= n < 23 for _, _, n in res), res
+
+
+def test_bucketed_gather_without_process_group_is_identity():
+    from hector_slam_amd import sharding
+    g = sharding.BucketedRowGather(5, 3, "cpu", bucket=3)
+    for k in range(5):
+        g.next_local().fill_(float(k))
+        g.launch()
+    assert torch.equal(g.last_result(), torch.full((5, 3), 4.0)) and g.collectives == 0
+
+
 def test_async_gather_without_process_group_is_identity():
     from hector_slam_amd import sharding
     g = sharding.AsyncRowGather(5, 3, "cpu")
