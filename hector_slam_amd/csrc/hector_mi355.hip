@@ -318,15 +318,32 @@ int rebuild_probability(hsm_ctx* h, Level& L) {
   return HSM_OK;
 }
 
-void free_level(Level& L) {
-  (void)hipFree(L.d_logodds);
-  (void)hipFree(L.d_update_index);
-  (void)hipFree(L.d_prob);
-  (void)hipFree(L.d_quad);
-  (void)hipFree(L.d_key_free);
-  (void)hipFree(L.d_key_occ);
-  (void)hipFree(L.d_occ_bits);
-  (void)hipFree(L.d_free_bytes);
+// Teardown never stops at a failing call (everything else still has to be released), but it must not swallow one either: HIP
+// keeps the last failure per thread, and the next hipGetLastError() of an unrelated call -- the launch check of the next
+// hsm_create on this thread -- would report it as its own.  The first failing call is kept for hsm_last_error(), the runtime's
+// per-thread state is cleared at the end (hsm_destroy).
+struct TeardownLog {
+  std::string first;
+  void note(const char* what, hipError_t e) {
+    if (e == hipSuccess || !first.empty()) return;
+    first = std::string(what) + ": " + hipGetErrorString(e);
+  }
+};
+#define TEARDOWN(log, expr) \
+  do {                      \
+    hipError_t e__ = (expr); \
+    if (log) (log)->note(#expr, e__); \
+  } while (0)
+
+void free_level(Level& L, TeardownLog* log = nullptr) {
+  TEARDOWN(log, hipFree(L.d_logodds));
+  TEARDOWN(log, hipFree(L.d_update_index));
+  TEARDOWN(log, hipFree(L.d_prob));
+  TEARDOWN(log, hipFree(L.d_quad));
+  TEARDOWN(log, hipFree(L.d_key_free));
+  TEARDOWN(log, hipFree(L.d_key_occ));
+  TEARDOWN(log, hipFree(L.d_occ_bits));
+  TEARDOWN(log, hipFree(L.d_free_bytes));
   L = Level();
 }
 
@@ -1071,35 +1088,40 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
 
 void hsm_destroy(hsm_ctx* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (Level& L : h->levels) free_level(L);
-  (void)hipFree(h->d_scan);
-  (void)hipFree(h->d_beam_recs);
-  (void)hipFree(h->d_retained);
-  (void)hipFree(h->d_retained_alt);
-  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-  if (h->copy_evt) (void)hipEventDestroy(h->copy_evt);
-  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-  if (h->h_copy_pinned) (void)hipHostFree(h->h_copy_pinned);
-  (void)hipFree(h->d_small);
-  (void)hipFree(h->d_batch);
-  (void)hipFree(h->d_cells);
-  (void)hipFree(h->d_partials);
-  (void)hipFree(h->d_ranges);
-  (void)hipFree(h->d_trig);
-  (void)hipFree(h->d_ingest);
-  (void)hipFree(h->d_occ);
-  if (h->h_scan_pinned) (void)hipHostFree(h->h_scan_pinned);
-  if (h->evt_updates) (void)hipEventDestroy(h->evt_updates);
-  if (h->evt_foreign) (void)hipEventDestroy(h->evt_foreign);
-  if (h->h_small) (void)hipHostFree(h->h_small);
+  TeardownLog log_, *log = &log_;
+  TEARDOWN(log, hipSetDevice(h->device));
+  if (h->stream) TEARDOWN(log, hipStreamSynchronize(h->stream));
+  if (h->copy_stream) TEARDOWN(log, hipStreamSynchronize(h->copy_stream));
+  for (Level& L : h->levels) free_level(L, log);
+  TEARDOWN(log, hipFree(h->d_scan));
+  TEARDOWN(log, hipFree(h->d_beam_recs));
+  TEARDOWN(log, hipFree(h->d_retained));
+  TEARDOWN(log, hipFree(h->d_retained_alt));
+  if (h->copy_evt) TEARDOWN(log, hipEventDestroy(h->copy_evt));
+  if (h->copy_stream) TEARDOWN(log, hipStreamDestroy(h->copy_stream));
+  if (h->h_copy_pinned) TEARDOWN(log, hipHostFree(h->h_copy_pinned));
+  TEARDOWN(log, hipFree(h->d_small));
+  TEARDOWN(log, hipFree(h->d_batch));
+  TEARDOWN(log, hipFree(h->d_cells));
+  TEARDOWN(log, hipFree(h->d_partials));
+  TEARDOWN(log, hipFree(h->d_ranges));
+  TEARDOWN(log, hipFree(h->d_trig));
+  TEARDOWN(log, hipFree(h->d_ingest));
+  TEARDOWN(log, hipFree(h->d_occ));
+  if (h->h_scan_pinned) TEARDOWN(log, hipHostFree(h->h_scan_pinned));
+  if (h->evt_updates) TEARDOWN(log, hipEventDestroy(h->evt_updates));
+  if (h->evt_foreign) TEARDOWN(log, hipEventDestroy(h->evt_foreign));
+  if (h->h_small) TEARDOWN(log, hipHostFree(h->h_small));
   for (int k = 0; k < 2; ++k) {
-    if (h->h_upd_pinned[k]) (void)hipHostFree(h->h_upd_pinned[k]);
-    if (h->upd_evt[k]) (void)hipEventDestroy(h->upd_evt[k]);
+    if (h->h_upd_pinned[k]) TEARDOWN(log, hipHostFree(h->h_upd_pinned[k]));
+    if (h->upd_evt[k]) TEARDOWN(log, hipEventDestroy(h->upd_evt[k]));
   }
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream) TEARDOWN(log, hipStreamDestroy(h->stream));
   delete h;
+  if (!log_.first.empty()) {
+    g_last_error = "hsm_destroy: " + log_.first;
+    (void)hipGetLastError();  // consumed here, not by the next caller's launch check
+  }
 }
 
 int hsm_reset(hsm_ctx* h) {
@@ -1443,7 +1465,7 @@ static int stage_scan(hsm_ctx* h, const float* pts_xy, int n, float2*& d_buf, si
   // (a dense scan for the multi-workgroup matcher is re-read every GN step: it must live in device memory)
   // (and so does the exact-order form)
   if (scan_is_read_once(h, n)) {
-    if ((size_t)n > h->h_scan_pinned_cap) {
+    if (!h->h_scan_pinned || (size_t)n > h->h_scan_pinned_cap) {  // (also the empty first scan of a fresh context)
       if (h->h_scan_pinned) HIP_TRY(hipHostFree(h->h_scan_pinned));
       h->h_scan_pinned = nullptr;
       h->h_scan_pinned_cap = 0;
