@@ -39,6 +39,9 @@ constexpr int kXRow = 64 + kExactPad;  // floats per staged row: 16-byte aligned
 #ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
 #define HSM_XBPC 15
 #endif
+#ifndef HSM_XBPC_CW  // ... of the chain-wavefront form (five wavefronts per SIMD: 96 VGPRs)
+#define HSM_XBPC_CW 6
+#endif
 #ifndef HSM_XLDS_AHEAD
 #define HSM_XLDS_AHEAD 1
 #endif
@@ -66,10 +69,16 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
 // BPL rows of beams per lane, the first BPC of them with a cached texel (5 VGPRs per row; a chain job needs 16 VGPRs for
 // the LDS rows it keeps in flight and 7 endpoint rows live in VGPRs, which 17 cached rows do not leave at 128);
 // rows BPC .. BPL-1 gather in every step.
-template <int NS, int BPL, int BPC = BPL>
-__global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const MatchParams P) {
+//
+// CW (round 5): a CHAIN WAVEFRONT.  The workgroup gets one more wavefront (index NS) that produces nothing: it runs every
+// round's chain job, the running sums never leave its registers inside a GN step, and no producer carries a job on top of
+// its own row any more -- the round's critical path is max(job, production) instead of the owner's job + production.
+// Five wavefronts per SIMD (4 workgroups x 5 per CU) need <= 96 VGPRs, so fewer rows keep a cached texel (BPC).
+template <int NS, int BPL, int BPC = BPL, bool CW = false>
+__global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
   constexpr int NC = 9 * NS;  // chains per workgroup
+  static_assert(!CW || NC <= 64, "the chain wavefront runs one job per round: lane = chain");
   // unit stride of a round.  A chain must not appear twice in one job (its rounds are sequential), so workgroups with
   // fewer than 64 chains pad the round to 64 units: one job per round, the lanes beyond NC idle.
   constexpr int NCP = NC >= 64 ? NC : 64;
@@ -81,7 +90,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   constexpr int kRowsFit = (kLdsShare - NB * NS * kXRows * kXRow * 4 - NC * 4 - 64) / (NS * 512);
   constexpr int RV = BPL <= kRowsFit ? 0 : BPL - kRowsFit;
   static_assert(RV < BPL && RV <= 8, "endpoint rows kept in VGPRs");
-  static_assert(64 * NS <= 1024, "one workgroup");
+  static_assert(64 * (NS + (CW ? 1 : 0)) <= 1024, "one workgroup");
   // ONE shared object with the stage first: its LDS address must fit M0[15:0] (ds_write_addtid_b32 below)
   struct alignas(16) Smem {
     float stage[NB][NS][kXRows][kXRow];
@@ -99,7 +108,8 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * NS + wave);
-  const bool active = scan < P.batch;  // inactive wavefronts (batch tail) run along with an empty scan: barriers, jobs
+  const bool chain_wave = CW && wave == NS;   // wave-uniform
+  const bool active = scan < P.batch && !chain_wave;  // inactive wavefronts (batch tail) run along with an empty scan: barriers, jobs
   int beg = 0, n = 0;
   float pw0 = 0.0f, pw1 = 0.0f, pw2 = 0.0f;
   if (active) {
@@ -132,6 +142,43 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
   // rounds for scans longer than the host's length hint
   const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
   const int units = rounds * NCP;
+  if (CW && chain_wave) {
+    // every barrier of the producers' schedule, a job behind each round's: lane c = chain c, its row streams through two
+    // 32-byte halves (see chain_job below), the running sum stays in a register until the step's last round
+    __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+    const int c = lane < NC ? lane : 0;
+    for (int l = P.first_level; l >= P.last_level; --l) {
+      const int gn_steps = __builtin_amdgcn_readfirstlane(P.lv[l].gn_steps);
+      for (int it = 0; it < gn_steps; ++it) {
+        float run = 0.0f;
+        for (int k = 0; k < rounds; ++k) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          const f4v* pa = reinterpret_cast<const f4v*>(&stage[0][0][0][0] + ((k % NB) * NC + c) * kXRow);
+          f4v a[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = pa[q];
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const f4v p0 = a[2 * (h & 1)], p1 = a[2 * (h & 1) + 1];
+            run += p0.x;
+            run += p0.y;
+            run += p0.z;
+            run += p0.w;
+            run += p1.x;
+            run += p1.y;
+            run += p1.z;
+            run += p1.w;
+            asm volatile("" : "+v"(run) : : "memory");
+            if (h + 2 < 8) a[2 * (h & 1)] = pa[2 * h + 4], a[2 * (h & 1) + 1] = pa[2 * h + 5];
+            asm volatile("" ::: "memory");
+          }
+        }
+        if (lane < NC) runs[lane] = run;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the totals are published
+      }
+    }
+    return;
+  }
   const float2* __restrict__ pts = P.pts + (n > 0 ? beg : 0);  // an empty scan's loads (clamped to element 0) stay inside the array
   f2(*mine)[64] = lds_pts[wave];
   f2 pv[RV > 0 ? RV : 1];
@@ -376,6 +423,7 @@ __global__ void __launch_bounds__(64 * NS, 4) gn_match_exact_cached_kernel(const
       auto round_done = [&](int k, bool last_round) {
         if (HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (CW) return;  // the chain wavefront runs the job
         const int j_lo = (k * NCP) >> 6;
         const int j_hi = last_round ? (units + 63) >> 6 : ((k + 1) * NCP) >> 6;
         if (j_lo >= j_hi) return;

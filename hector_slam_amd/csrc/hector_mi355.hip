@@ -217,7 +217,8 @@ struct hsm_ctx {
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
   int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
   bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
-  int exact_dense_min = 4096;    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
+  int exact_dense_min = 4096;
+  int exact_chain_wave = 1;  // env HSM_EXACT_CHAIN_WAVE=0: no chain-only wavefront, teams of wavefronts for batches below 4096 scans (rounds 3-4)    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
   const char* last_kernel = "";  // name of the matcher kernel the last launch used (hsm_last_launch_kernel)
   unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
   int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
@@ -412,21 +413,23 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   return wps < lat ? wps : lat;
 }
 
+constexpr int kComputeUnits = 256;  // MI355X
+
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
-template <int NS, int BPL, int BPC = BPL>
+template <int NS, int BPL, int BPC = BPL, bool CW = false>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
-  const int grid = (P.batch + NS - 1) / NS, block = 64 * NS;
+  const int grid = (P.batch + NS - 1) / NS, block = 64 * (NS + (CW ? 1 : 0));
   // workgroup -> XCD mapping: this form runs best with one contiguous eighth of the batch per XCD on every map size (2048^2
   // headline: 57.5 us against 58.3 with the fast form's chunks of 16 workgroups dealt in turn; chunks of 8 / 32: 58.4;
   // profiles/r04/exact_kernel_param_sweep.txt) -- its rounds are paced by barriers and chain jobs, not by how long a scan's
   // gathers take, so the load balancing the chunks buy the fast form is not needed and the compacter L2 footprint wins.
   // env HSM_XCD_CHUNK_EXACT=n restores chunks of n workgroups.
   P.xcd_chunk = h->xcd_chunk_exact > 0 ? (h->xcd_chunk_exact * 4 / NS > 0 ? h->xcd_chunk_exact * 4 / NS : 1) : 0;
-  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC>), dim3(grid), dim3(block), 0, stream, P);
+  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, CW>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
-  h->last_kernel = "gn_match_exact_cached_kernel";
+  h->last_kernel = CW ? "gn_match_exact_cached_kernel (chain wavefront)" : "gn_match_exact_cached_kernel";
   h->last_cfg[0] = h->layout;
   h->last_cfg[1] = 1;
   h->last_cfg[2] = block;
@@ -444,8 +447,16 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  Scans longer than 17 beams per lane stream their tail rows.
   if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
     const int per_lane = (max_n + 63) / 64;
-    if (per_lane <= 5) return launch_match_exact_cached<4, 5>(h, P, stream);
-    if (per_lane <= 9) return launch_match_exact_cached<4, 9>(h, P, stream);
+    // A launch that leaves every CU at most THREE workgroups takes the chain-wavefront form (gn_match_exact.h, CW): a fifth
+    // wavefront per workgroup runs the chain jobs, so a round lasts max(job, production) instead of job + production --
+    // 36 us against 52 for a level-0 batch of up to 2048 scans, 49 against 57 at 3072 (profiles/r05/README.md 9).  Not
+    // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
+    // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
+    // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
+    const bool cw = h->exact_chain_wave && (P.batch + 3) / 4 <= 3 * kComputeUnits;
+    if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
+    if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
+    if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
     return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
   }
 #if defined(HSM_EXPERIMENTS)
@@ -559,7 +570,15 @@ int launch_match_exact_dense(hsm_ctx* h, const MatchParams& P, hipStream_t strea
 }
 
 int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
-  const int wps = choose_wps(h, P.batch, max_n);
+  int wps = choose_wps(h, P.batch, max_n);
+  // reference order, batches of scans of up to 17 beams per lane: ALWAYS one wavefront per scan with the texel cache
+  // (launch_match_exact).  Teams of wavefronts per scan -- what choose_wps picks below 4096 scans to fill the chip -- only
+  // produce faster, and production is not what bounds this form: the nine chains are.  Measured (tools/batch_size_sweep.py,
+  // level-0 batch of 1081-beam scans, us per launch, teams -> one wavefront per scan + chain wavefront): 16 scans 46.7 -> 36.3,
+  // 1024: 80.3 -> 37.1, 2048: 92.4 -> 39.3, 3072: 134.5 -> 48.6, 3584: 135.9 -> 60.7 (without the chain wavefront).
+  if (exact && wps > 1 && h->wps_override == 0 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 &&
+      h->exact_cached && h->exact_chain_wave && max_n <= 17 * 64)
+    wps = 1;
   if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, stream);
   switch (wps) {
     case 1: {
@@ -1005,6 +1024,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE")) h->exact_dense = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE_MIN")) h->exact_dense_min = atoi(env);
+  if (const char* env = getenv("HSM_EXACT_CHAIN_WAVE")) h->exact_chain_wave = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
 #if defined(HSM_EXPERIMENTS)  // switches of forms that only an experiment build holds
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);

@@ -124,17 +124,23 @@ def test_far_starts_and_out_of_map_beams(pyr, pyramid_scene):
 
 
 @pytest.mark.parametrize("form", ["auto", "cached", "cached-tail", "cached-long", "cached-9rows", "cached-5rows", "plane-layout",
-                                  "one-wave-per-scan"])
+                                  "one-wave-per-scan", "cached/rotating-owner", "cached-tail/rotating-owner",
+                                  "cached-9rows/rotating-owner", "cached-5rows/rotating-owner"])
 def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form, monkeypatch):
     """the batched entry: ragged CSR batch with empty, tiny, regular and over-long scans -- through the team kernel
     a small batch picks by itself ("auto"), the texel-cache exact form every quad-layout batch takes (gn_match_exact.h: every
     wavefront a producer, packed rotating chain jobs; 17 scans = two full workgroups and a partial one; "cached-tail" /
     "cached-long": scans four / nine rows longer than the 17 cached ones stream their tail rows), the plane layout (which has
     no texel-cache exact form) and the one-wavefront-per-scan form (HSM_EXACT_CACHED=0).  Round 2's producer / chain-wavefront
-    form left the default library in round 4 (-DHSM_EXPERIMENTS)"""
+    form left the default library in round 4 (-DHSM_EXPERIMENTS).  Since round 5 a launch of at most 3072 scans -- this one --
+    takes the texel-cache form WITH a chain-only fifth wavefront per workgroup (block 320); ".../rotating-owner" switches it
+    off (HSM_EXACT_CHAIN_WAVE=0): the form larger launches take, whose producers run the chain jobs in turn (block 256)"""
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
+    rotating = form.endswith("/rotating-owner")
+    form = form.split("/")[0]
+    monkeypatch.setenv("HSM_EXACT_CHAIN_WAVE", "0" if rotating else "1")
     monkeypatch.setenv("HSM_EXACT_CACHED", "0" if form == "one-wave-per-scan" else "1")
     kw = {} if form == "auto" else {"waves_per_scan": 1}
     if form == "plane-layout":
@@ -165,7 +171,8 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         assert not g.last_launch_config()["texel_cache"], g.last_launch_config()
     if form.startswith("cached"):
         cfg = g.last_launch_config()
-        assert cfg["texel_cache"] and cfg["block"] == 256, cfg
+        assert cfg["texel_cache"] and cfg["block"] == (256 if rotating else 320), cfg
+        assert ("chain wavefront" in cfg["kernel"]) == (not rotating), cfg
         if form.endswith("rows"):
             assert cfg["beams_per_lane"] == int(form.split("-")[1][0]), cfg
     for q, sq in enumerate(scans):
