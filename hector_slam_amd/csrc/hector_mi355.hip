@@ -456,6 +456,9 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     const bool cw = h->exact_chain_wave && (P.batch + 3) / 4 <= 3 * kComputeUnits;
     if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
     if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
+    // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
+    // exit edges --; a 13-row instantiation costs compile time only: a batch of 720-beam scans runs 13 rounds instead of 17)
+    if (per_lane <= 13) return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
     if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
     return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
   }
@@ -576,6 +579,8 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
   // produce faster, and production is not what bounds this form: the nine chains are.  Measured (tools/batch_size_sweep.py,
   // level-0 batch of 1081-beam scans, us per launch, teams -> one wavefront per scan + chain wavefront): 16 scans 46.7 -> 36.3,
   // 1024: 80.3 -> 37.1, 2048: 92.4 -> 39.3, 3072: 134.5 -> 48.6, 3584: 135.9 -> 60.7 (without the chain wavefront).
+  // (hsm_match's single scans stay on the team form: it stops its chain at the scan's last beam and keeps the endpoints in
+  // registers -- 1081 beams 94 vs 92 us per call, 720 beams 74 vs 90, 360 beams 51 vs 59 through the chain-wavefront form)
   if (exact && wps > 1 && h->wps_override == 0 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 &&
       h->exact_cached && h->exact_chain_wave && max_n <= 17 * 64)
     wps = 1;
