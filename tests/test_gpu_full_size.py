@@ -155,6 +155,34 @@ def test_config3_batch4096_2048map(capi, oracle_mod):
     assert np.median(err[:, :2]) < 0.02  # it converges to the ground truth, too
 
 
+def test_batches_below_4096_scans_take_the_chain_wavefront_form(capi, oracle_mod):
+    """round 5: a default-mode (reference-order) batch of up to 3072 scans runs one wavefront per scan plus a chain-only fifth
+    wavefront per workgroup (gn_match_exact.h, CW) -- 1 / 5 / 1024 / 3072 scans: that kernel, EVERY pose and covariance equal
+    to the reference's, bit for bit; 3073 scans: round 3's rotating-owner form, the same bits for the scans they share"""
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1081, map_size=2048, levels=3, resolution=0.05, n_build=120, n_query=3073,
+                          room=(40.0, 30.0), seed=4321)
+    g, o = build_pair(capi, oracle_mod, sc)
+    assert g.parity() == capi.PARITY_AUTO
+    pts, offs = synth.pack_scans(sc.query_scans)
+    cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
+    full = None
+    for B in (3073, 3072, 1024, 5, 1):
+        p_b, o_b = synth.pack_scans(sc.query_scans[:B])
+        pose, cov = g.match_batch(sc.query_init[:B], p_b, o_b)
+        cfg = g.last_launch_config()
+        assert cfg["parity_effective"] == "exact" and cfg["texel_cache"], cfg
+        if B > 3072:
+            assert cfg["block"] == 256 and "chain wavefront" not in cfg["kernel"], cfg
+            full = (pose, cov)
+        else:
+            assert cfg["block"] == 320 and "chain wavefront" in cfg["kernel"] and cfg["grid"] == (B + 3) // 4, cfg
+            assert np.array_equal(bits(pose), bits(full[0][:B])) and np.array_equal(bits(cov), bits(full[1][:B]))
+        same = (bits(pose) == bits(cpu[:B])).all(1)
+        assert same.all(), f"B={B}: {(~same).sum()} poses differ from the reference ({KIND})"
+        record(test="chain_wavefront_form", batch=B, checker=KIND, bit_identical_to_reference=int(same.sum()), kernel=cfg)
+
+
 def test_config4_share_4096map_pyramid(capi, oracle_mod):
     """configs[3], one GPU's share: 4096 of the 32768 scans, 3-level 4096/2048/1024 pyramid.  0.05 m cells, the
     room scaled to 160 m x 120 m and a 120 m sensor so that the 204.8 m map is actually used.
