@@ -218,6 +218,7 @@ struct hsm_ctx {
   int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
   bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
   int exact_dense_min = 4096;
+  int compute_units = 256;   // of this device (hsm_create)
   int exact_chain_wave = 1;  // env HSM_EXACT_CHAIN_WAVE=0: no chain-only wavefront, teams of wavefronts for batches below 4096 scans (rounds 3-4)    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
   const char* last_kernel = "";  // name of the matcher kernel the last launch used (hsm_last_launch_kernel)
   unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
@@ -413,8 +414,6 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   return wps < lat ? wps : lat;
 }
 
-constexpr int kComputeUnits = 256;  // MI355X
-
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
@@ -453,7 +452,7 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
     // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
     // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
-    const bool cw = h->exact_chain_wave && (P.batch + 3) / 4 <= 3 * kComputeUnits;
+    const bool cw = h->exact_chain_wave && (P.batch + 3) / 4 <= 3 * h->compute_units;
     if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
     if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
     // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
@@ -986,6 +985,10 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (h->device >= ndev) {
     delete h;
     return fail(HSM_ERR_INVALID, "hsm_create: device ordinal out of range");
+  }
+  {  // (a partition of the device -- CPX mode -- reports its own CU count; 256 on a whole MI355X)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->compute_units = cus;
   }
   int layout = opts ? opts->layout : HSM_LAYOUT_AUTO;
   if (layout == HSM_LAYOUT_AUTO) {
@@ -2373,20 +2376,25 @@ void hsm_group_destroy(hsm_group* g) {
     for (ncclComm_t c : g->comms)
       if (c && api->CommDestroy) (void)api->CommDestroy(c);
   }
+  TeardownLog log_, *log = &log_;  // (as hsm_destroy: name the first failing call, leave no error behind for the next caller)
   for (size_t r = 0; r < g->members.size(); ++r) {
-    if (g->members[r]) (void)hipSetDevice(g->members[r]->device);
+    if (g->members[r]) TEARDOWN(log, hipSetDevice(g->members[r]->device));
     if (r < g->d_all_pose.size()) {
-      (void)hipFree(g->d_all_pose[r]);
-      (void)hipFree(g->d_all_cov[r]);
+      TEARDOWN(log, hipFree(g->d_all_pose[r]));
+      TEARDOWN(log, hipFree(g->d_all_cov[r]));
     }
     if (r < g->d_pose.size()) {
-      (void)hipFree(g->d_pose[r]);
-      (void)hipFree(g->d_cov[r]);
-      if (g->evt[r]) (void)hipEventDestroy(g->evt[r]);
+      TEARDOWN(log, hipFree(g->d_pose[r]));
+      TEARDOWN(log, hipFree(g->d_cov[r]));
+      if (g->evt[r]) TEARDOWN(log, hipEventDestroy(g->evt[r]));
     }
   }
   for (hsm_ctx* h : g->members) hsm_destroy(h);
   delete g;
+  if (!log_.first.empty()) {
+    g_last_error = "hsm_group_destroy: " + log_.first;
+    (void)hipGetLastError();
+  }
 }
 
 int hsm_group_size(const hsm_group* g) { return g ? (int)g->members.size() : 0; }
