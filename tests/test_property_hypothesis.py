@@ -179,3 +179,81 @@ def test_gpu_dense_update_equals_reference_at_the_borders(oracle_mod, g):
                 "level": m.download_level, "keep": m, "check": check}
     kind = oracle_kinds()[-1]
     run_loop(g, make_gpu, oracle_impl(oracle_mod, kind), steps=6, make_guard=oracle_impl(oracle_mod, "ho") if kind == "hr" else None)
+
+
+# Round 5: the BATCHED entry in the default mode.  A batch of up to 3072 scans of up to 1088 beams runs one wavefront per scan
+# plus a chain-only fifth wavefront per workgroup (gn_match_exact.h, CW; the 5- / 9- / 13- / 17-row instantiations by the
+# longest scan); this property draws the map, the pyramid, the fan, the batch size and a ragged set of scan lengths (empty
+# scans and fragments included) and holds every pose and covariance of the batch to the reference's bits.
+batch_geometry = st.fixed_dictionaries({
+    "size": st.sampled_from([64, 128, 200, 256, 512]),
+    "levels": st.integers(1, 3),
+    "res": st.sampled_from([0.05, 0.1]),
+    "start": st.tuples(st.floats(0.3, 0.7), st.floats(0.3, 0.7)),
+    "free": st.floats(0.3, 0.49),
+    "occ": st.floats(0.55, 0.95),
+    "beams": st.sampled_from([90, 181, 300, 400, 560, 720, 1081]),
+    "grow": st.sampled_from([0.6, 0.9, 1.15]),
+    "seed": st.integers(0, 2 ** 20),
+    "batch": st.integers(1, 48),
+    "ragged": st.booleans(),
+})
+
+
+@pytest.mark.gpu
+@settings(max_examples=GPU_EXAMPLES or 12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(g=batch_geometry)
+def test_gpu_default_mode_batches_equal_reference_for_random_geometries(oracle_mod, g):
+    from hector_slam_amd import capi, synth
+    size, levels, res = g["size"], g["levels"], g["res"]
+    while (size >> (levels - 1)) < 8:
+        levels -= 1
+    ext = size * res
+    world = synth.World.make(ext * g["grow"], ext * g["grow"] * 0.75, n_boxes=3, seed=g["seed"], keep_clear=0.5)
+    s = float(np.float32(1.0) / np.float32(res))
+    B, n_build = g["batch"], 6
+    poses = synth.loop_trajectory(world, n_build + B, frac=0.25).astype(np.float32)
+    rng = np.random.default_rng(g["seed"])
+    scans = [synth.make_scan(world, p, g["beams"], s, rng, range_max=min(30.0, ext)) for p in poses]
+    m = capi.MapRepMultiMap(res, size, size, levels, g["start"])
+    assert m.parity() == capi.PARITY_AUTO
+    kind = oracle_kinds()[-1]
+    impls = [oracle_impl(oracle_mod, kind)(res, size, levels, g["start"], g["free"], g["occ"])]
+    if kind == "hr":  # the restatement runs ahead of the reference and says where the reference would crash
+        impls.insert(0, oracle_impl(oracle_mod, "ho")(res, size, levels, g["start"], g["free"], g["occ"]))
+    m.setUpdateFactorFree(g["free"])
+    m.setUpdateFactorOccupied(g["occ"])
+    zero = np.zeros(2, np.float32)
+    for t in range(n_build):
+        m.updateByScan(scans[t], poses[t])
+        for o in impls:
+            o["update"](poses[t], scans[t], zero)
+    for lvl in range(levels):
+        la, lb = m.download_level(lvl), impls[-1]["level"](lvl)
+        assert np.array_equal(bits(la[0]), bits(lb[0])) and np.array_equal(la[1], lb[1]), (g, lvl)
+    query, init = [], []
+    for q in range(B):
+        sc = scans[n_build + q]
+        if g["ragged"] and sc.shape[0] > 0:
+            n = int(rng.choice([0, 1, 7, 64, 65, sc.shape[0] // 2, sc.shape[0]]))
+            sc = sc[np.sort(rng.choice(sc.shape[0], size=min(n, sc.shape[0]), replace=False))]
+        query.append(np.ascontiguousarray(sc, np.float32))
+        init.append(poses[n_build + q] + np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(-0.02, 0.02)], np.float32))
+    init = np.stack(init).astype(np.float32)
+    pts, offs = synth.pack_scans(query)
+    pose, cov = m.match_batch(init, pts, offs)
+    cfg = m.last_launch_config()
+    assert cfg["parity_effective"] == "exact", cfg
+    if max(q.shape[0] for q in query) <= 1088 and cfg["texel_cache"]:
+        assert "chain wavefront" in cfg["kernel"] and cfg["block"] == 320, cfg
+    for q in range(B):
+        for o in impls:
+            po, co = o["match"](init[q], query[q], zero)
+            assume(not reference_undefined(o))
+        if not np.isfinite(po).all():  # singular H: the reference divides by a zero determinant (NaN payloads not pinned)
+            assert np.array_equal(np.isnan(pose[q]), np.isnan(po)), (g, q)
+            continue
+        assert np.array_equal(bits(pose[q]), bits(po)), (g, q, query[q].shape, pose[q], po)
+        if query[q].shape[0]:
+            assert np.array_equal(bits(cov[q]), bits(co)), (g, q)
+    m.close()
