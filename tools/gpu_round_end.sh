@@ -48,3 +48,12 @@ timeout 900 python tests/tools/soak.py 30000 --default --free-run > "$OUT/soak_d
 echo "== dense soak (16384 beams, 2048^2), 1500 steps"; S=$(date +%s)
 timeout 900 python tests/tools/soak_dense.py 1500 --beams 16384 --size 2048 --check 500 > "$OUT/soak_dense_16384beams_2048map_1500.json" 2> /dev/null; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-300 "$OUT/soak_dense_16384beams_2048map_1500.json"
 echo "== ThreadSanitizer over the facade"; bash tools/tsan_facade.sh 2>&1 | tail -4; cp gpurun_out/tsan/tsan_stdout.txt "$OUT/sanitizer_tsan_facade.txt" 2>/dev/null
+echo "== default-mode batches by size (chain-wavefront form up to 3072 scans)"; S=$(date +%s)
+for L in 1 3; do timeout 300 python tools/batch_size_sweep.py --levels $L --variants "default;HSM_EXACT_CHAIN_WAVE=0" > "$OUT/batch_size_sweep_l$L.jsonl" 2> /dev/null; done; echo "rc=$? ($(( $(date +%s) - S )) s)"
+python - "$OUT" <<'PY'
+import json, sys
+for L in (1, 3):
+    for ln in open(f"{sys.argv[1]}/batch_size_sweep_l{L}.jsonl"):
+        d = json.loads(ln)
+        print(L, d["batch"], " | ".join("%s %.1f us%s" % (k[:24], v["us"], "" if v["bit_identical_to_first"] else " DIFF") for k, v in d.items() if isinstance(v, dict)))
+PY
