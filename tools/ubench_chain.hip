@@ -7,6 +7,7 @@
 //   2 chains   : two independent chains interleaved
 //   4 chains   : four
 //   lds        : the chain job's pattern -- ds_read_b128 + s_waitcnt + 4 dependent adds
+//   pk chain   : v_pk_add_f32 v[0:1], v[2:3], v[0:1] back to back (round 5: two chains per lane?)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -35,6 +36,12 @@ __global__ __launch_bounds__(256) void probe(float* out, unsigned long long* cyc
             for (int i = 0; i < 8; ++i)
                 asm volatile("v_add_f32 %0, %4, %0\n\tv_add_f32 %1, %4, %1\n\tv_add_f32 %2, %4, %2\n\tv_add_f32 %3, %4, %3"
                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(b));
+        } else if (MODE == 6) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 r = {r0, r1}, bb = {b, b};
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(r) : "v"(bb));
+            r0 = r.x, r1 = r.y;
         } else {
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 a, c;
@@ -85,5 +92,6 @@ int main() {
     run<3>("2 chains interleaved", d_out, d_cyc);
     run<4>("4 chains interleaved", d_out, d_cyc);
     run<5>("ds_read_b128 + wait + 4 adds (32 adds per iteration)", d_out, d_cyc);
+    run<6>("v_pk_add_f32 chain (cycles per packed add)", d_out, d_cyc);
     return 0;
 }
