@@ -73,7 +73,11 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
 // CW (round 5): a CHAIN WAVEFRONT.  The workgroup gets one more wavefront (index NS) that produces nothing: it runs every
 // round's chain job, the running sums never leave its registers inside a GN step, and no producer carries a job on top of
 // its own row any more -- the round's critical path is max(job, production) instead of the owner's job + production.
-// Five wavefronts per SIMD (4 workgroups x 5 per CU) need <= 96 VGPRs, so fewer rows keep a cached texel (BPC).
+// Launched for batches that leave a CU at most THREE such workgroups (hector_mi355.hip, launch_match_exact): the dispatcher
+// places a workgroup only where every SIMD has room for ceil(5 / 4) = 2 of its wavefronts, so the third workgroup fits for
+// certain only if a SIMD holds six wavefronts -- 80 VGPRs, i.e. fewer rows with a cached texel (BPC = HSM_XBPC_CW) -- and
+// a fourth does not (tools/study/ubench_wg_placement.hip, profiles/r05/README.md 9); the launch bounds ask for five per SIMD
+// (the compiler's figure includes the LDS: four workgroups), tests/test_kernel_resources.py holds the 80.
 template <int NS, int BPL, int BPC = BPL, bool CW = false>
 __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
