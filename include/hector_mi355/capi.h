@@ -85,7 +85,10 @@ enum { HSM_PARITY_FAST = 0, HSM_PARITY_EXACT = 1, HSM_PARITY_RELAXED = 2, HSM_PA
  * defaults 0.4 / 0.6 (HSL/map/GridMapLogOdds.h:117-118). */
 int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x,
                float start_y, const hsm_opts* opts /* may be NULL */, hsm_ctx** out);
-/* replaces: MapRepMultiMap::~MapRepMultiMap                   MapRepMultiMap.h:74-81 */
+/* replaces: MapRepMultiMap::~MapRepMultiMap                   MapRepMultiMap.h:74-81
+ * Waits for the context's queued work, releases everything.  Never fails towards the caller; if a runtime call fails during
+ * teardown, everything else is still released, hsm_last_error() of this thread then reads "hsm_destroy: <call>: <error>", and
+ * the runtime's per-thread error state is cleared (it is not left for the next hipGetLastError() of an unrelated call). */
 void hsm_destroy(hsm_ctx* h);
 
 /* replaces: MapRepMultiMap::reset -> MapProcContainer::reset  MapRepMultiMap.h:83-90, MapProcContainer.h:67-71 */
