@@ -78,8 +78,11 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
 // certain only if a SIMD holds six wavefronts -- 80 VGPRs, i.e. fewer rows with a cached texel (BPC = HSM_XBPC_CW) -- and
 // a fourth does not (tools/study/ubench_wg_placement.hip, profiles/r05/README.md 9); the launch bounds ask for five per SIMD
 // (the compiler's figure includes the LDS: four workgroups), tests/test_kernel_resources.py holds the 80.
+// (With at most TWO such workgroups per CU the second one fits at four wavefronts per SIMD as well -- 2/1/1/1 leaves two slots
+// everywhere --, so launches of up to 2 x CUs workgroups take an instantiation with the full texel cache at 128 VGPRs: what a
+// map that outgrows the L2s needs.)
 template <int NS, int BPL, int BPC = BPL, bool CW = false>
-__global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
+__global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <= 96 ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
   constexpr int NC = 9 * NS;  // chains per workgroup
   static_assert(!CW || NC <= 64, "the chain wavefront runs one job per round: lane = chain");

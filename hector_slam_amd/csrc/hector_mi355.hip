@@ -452,12 +452,20 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
     // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
     // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
     // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
-    const bool cw = h->exact_chain_wave && (P.batch + 3) / 4 <= 3 * h->compute_units;
+    const int groups = (P.batch + 3) / 4;
+    // ... and a map that outgrows the L2s (4096^2: 136 us with six cached rows against 128.5 with fifteen, at 3072 scans) keeps
+    // round 3's form at three workgroups per CU; up to two per CU the chain-wavefront form has the full texel cache as well
+    const bool cw2 = h->exact_chain_wave && groups <= 2 * h->compute_units;
+    const bool cw = cw2 || (h->exact_chain_wave && groups <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23));
     if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
     if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
     // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
     // exit edges --; a 13-row instantiation costs compile time only: a batch of 720-beam scans runs 13 rounds instead of 17)
-    if (per_lane <= 13) return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
+    if (per_lane <= 13) {
+      if (cw2) return launch_match_exact_cached<4, 13, 13, true>(h, P, stream);
+      return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
+    }
+    if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
     if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
     return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
   }

@@ -162,11 +162,12 @@ def test_no_register_of_an_inflight_gather_is_touched(device_asm):
     """EVERY instantiation in the default library (round-3 verdict: two were guarded): the quad and plane layouts, four and
     eight scans per workgroup, 9 and 17 rows, the relaxed arithmetic, and the three exact-order forms"""
     names = texel_cache_kernels(device_asm)
-    assert len(names) >= 15, names
+    assert len(names) >= 17, names
     for need in ("gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1E", "gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0E",
                  "gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi2ELi1ELb0E",
                  "gn_match_exact_cached_kernelILi4ELi17ELi15ELb0E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb0E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb0E",
                  "gn_match_exact_cached_kernelILi4ELi13ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi13ELi7ELb1E",
+                 "gn_match_exact_cached_kernelILi4ELi13ELi13ELb1E", "gn_match_exact_cached_kernelILi4ELi17ELi15ELb1E",
                  "gn_match_exact_cached_kernelILi4ELi17ELi6ELb1E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb1E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb1E"):
         assert any(need in n for n in names), (need, names)
     for kernel in names:
@@ -194,9 +195,10 @@ def designed_waves_per_simd(name):
     m = re.search(r"22gn_match_cached_kernelILi\d+ELi\d+ELi\d+ELi(\d+)ELb[01]E", name)
     if m:
         return 5 if int(m.group(1)) > 1 else 4
-    m = re.search(r"28gn_match_exact_cached_kernelILi\d+ELi\d+ELi\d+ELb([01])E", name)
-    if m:
-        return 5 if m.group(1) == "1" else 4  # (the compiler's figure includes the LDS: four workgroups of five wavefronts)
+    m = re.search(r"28gn_match_exact_cached_kernelILi\d+ELi\d+ELi(\d+)ELb([01])E", name)
+    if m:  # chain-wavefront forms: five per SIMD (the compiler's figure includes the LDS: four workgroups of five wavefronts),
+        # four for the full-texel-cache instantiations that are launched up to two workgroups per CU
+        return (5 if 5 * int(m.group(1)) + 50 <= 96 else 4) if m.group(2) == "1" else 4
     if "20gn_match_coop_kernel" in name:
         return 1  # one workgroup per CU by design (K <= 64 workgroups on 256 CUs)
     return None
@@ -207,9 +209,11 @@ def test_chain_wavefront_forms_leave_room_for_six_wavefronts_per_simd(device_asm
     workgroups' odd wavefronts landed on -- only if a SIMD holds SIX of its wavefronts: the dispatcher wants room for
     ceil(5 / 4) = 2 more on EVERY SIMD (tools/study/ubench_wg_placement.hip, profiles/r05/README.md 9).  512 / 6 -> 80 VGPRs."""
     ks = {k: v for k, v in kernels(device_asm).items() if re.search(r"28gn_match_exact_cached_kernelILi\d+ELi\d+ELi\d+ELb1E", k)}
-    assert len(ks) == 4, sorted(ks)
+    assert len(ks) == 6, sorted(ks)
+    two_per_cu = [k for k in ks if "ILi4ELi17ELi15ELb1E" in k or "ILi4ELi13ELi13ELb1E" in k]  # launched up to two per CU: 2/1/1/1 leaves
+    assert len(two_per_cu) == 2                                                                # two slots on every SIMD at four per SIMD
     for k, v in ks.items():
-        assert v["vgpr"] <= 80 and v["scratch"] == 0, (k, v)
+        assert v["vgpr"] <= (128 if k in two_per_cu else 80) and v["scratch"] == 0, (k, v)
         assert 3 * v["lds"] <= 160 * 1024, (k, v)
 
 

@@ -20,14 +20,35 @@ def main():
     ap.add_argument("--sizes", default="16,64,128,256,512,768,1024,1536,2048,3072,3584,4096")
     ap.add_argument("--variants", default="default;HSM_WPS=1;HSM_WPS=1,HSM_EXACT_CHAIN_WAVE=1")
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--workload", default="config3", help="config3 (the headline scene) or config4 (the 4096^2 pyramid's scene)")
     args = ap.parse_args()
     import torch
     from hector_slam_amd import capi
     dev = torch.device("cuda", 0)
     sizes = [int(s) for s in args.sizes.split(",")]
     B = max(sizes)
-    bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)
-    init = init_l0 if args.levels == 1 else init_pyr
+    res, size, n_beams = bench.RESOLUTION, bench.MAP_SIZE, bench.N_BEAMS
+    if args.workload == "config3":
+        bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)
+        init = init_l0 if args.levels == 1 else init_pyr
+    else:  # as bench.extra_workload builds it
+        import math
+        from hector_slam_amd import synth
+        n_beams, size, res, room, rmax, _, _ = bench.WORKLOADS[args.workload]
+        sfac = float(np.float32(1.0) / np.float32(res))
+        world = synth.World.make(room[0], room[1], seed=1234)
+        rng_noise = np.random.default_rng(1235)
+        bp = synth.loop_trajectory(world, 100).astype(np.float32)
+        bs = [synth.make_scan(world, p, n_beams, sfac, rng_noise, range_max=rmax) for p in bp]
+        rng = np.random.default_rng(1236)
+        base = synth.loop_trajectory(world, B, phase=rng.uniform(0, 2 * math.pi)).astype(np.float64)
+        base[:, :2] += rng.uniform(-0.5, 0.5, size=(B, 2)) * (room[0] / 40.0)
+        base[:, 2] += rng.uniform(-0.3, 0.3, size=B)
+        truth = base.astype(np.float32)
+        rng_q = np.random.default_rng(1237)
+        scans = [synth.make_scan(world, p, n_beams, sfac, rng_q, pad_to_full=True, range_max=rmax) for p in truth]
+        init = synth.perturb_poses(truth, np.random.default_rng(1239), 0.15 if args.levels > 1 else 0.04, 0.05 if args.levels > 1 else 0.01)
+        pts, offs = synth.pack_scans(scans)
     d_init = torch.from_numpy(init).to(dev)
     d_pts = torch.from_numpy(pts).to(dev)
     d_offs = torch.from_numpy(offs).to(dev)
@@ -36,7 +57,7 @@ def main():
     for spec in args.variants.split(";"):
         env = dict(kv.split("=") for kv in spec.split(",") if "=" in kv)
         os.environ.update(env)
-        m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, args.levels, device=0)
+        m = capi.MapRepMultiMap(res, size, size, args.levels, device=0)
         for k in env:
             os.environ.pop(k)
         m.setUpdateFactorFree(0.4)
@@ -47,10 +68,10 @@ def main():
     cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
     for b in sizes:
         ref = None
-        row = {"levels": args.levels, "batch": b}
+        row = {"workload": args.workload, "levels": args.levels, "batch": b}
         for spec, m in variants:
             def launch():
-                m.match_batch_device(b, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), bench.N_BEAMS,
+                m.match_batch_device(b, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), n_beams,
                                      pose.data_ptr(), cov.data_ptr(), stream.cuda_stream)
             pose.zero_()
             for _ in range(3):
