@@ -100,6 +100,9 @@ int main() {
   run<6, 80>("6 waves, 80 VGPRs, 1 KB", 2048, 1024, hold);
   run<10, 96>("10 waves, 96 VGPRs, 80 KB", 1024, 80448, hold);
   run<8, 128>("8 waves, 128 VGPRs, 80 KB", 1024, 80448, hold);
+  run<5, 128>("5 waves, 128 VGPRs, 74144 B (two rounds per barrier)", 1024, 74144, hold);
+  run<5, 128>("5 waves, 128 VGPRs, 65536 B", 1024, 65536, hold);
+  run<5, 128>("5 waves, 128 VGPRs, 40224 B", 1024, 40224, hold);
   run<9, 80>("9 waves, 80 VGPRs, 79408 B (paired-chain form)", 1024, 79408, hold);
   run<9, 80>("9 waves, 80 VGPRs, 1 KB", 1024, 1024, hold);
   run<9, 80>("9 waves, 80 VGPRs, 64 KB", 1024, 65536, hold);
