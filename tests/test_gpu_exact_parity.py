@@ -190,6 +190,34 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         assert same(ph[k], po) and same(ch[k], co), k
 
 
+@pytest.mark.parametrize("chain_wave", ["1", "0"])
+def test_batch_with_a_workgroup_of_empty_scans(capi, oracle_mod, pyramid_scene, kind, chain_wave, monkeypatch):
+    """twelve scans, the middle four empty: that workgroup (four scans each, in both texel-cache exact forms) leaves before the
+    first barrier with every wavefront -- the chain wavefront included --, its scans pass their start estimates through, and the
+    workgroups around it are unaffected"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    monkeypatch.setenv("HSM_EXACT_CHAIN_WAVE", chain_wave)
+    g = exact_gpu(capi, sc, o, waves_per_scan=1)
+    scans = [sc.query_scans[q % len(sc.query_scans)] for q in range(12)]
+    for q in range(4, 8):
+        scans[q] = scans[q][:0]
+    init = np.stack([sc.query_init[q % len(sc.query_init)] for q in range(12)])
+    pts, offs = synth.pack_scans(scans)
+    pb, cb = g.match_batch(init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["texel_cache"] and cfg["grid"] == 3 and cfg["block"] == (320 if chain_wave == "1" else 256), cfg
+    for q, sq in enumerate(scans):
+        po, co = o.match(init[q], sq, cov=np.zeros(9, np.float32))
+        assert same(pb[q], po), q
+        if sq.shape[0]:
+            assert same(cb[q], co), q
+        else:
+            assert same(pb[q], init[q]) and not cb[q].any(), q
+    g.close()
+
+
 def test_dense_scan_bit_identical(capi, oracle_mod, pyramid_scene, kind):
     """16k-beam scans (configs[4] shape): the exact form keeps the scan on one 16-wave workgroup"""
     from hector_slam_amd import synth
