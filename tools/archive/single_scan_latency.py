@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """hsm_match host-call latency (default mode: reference order) by scan length, for launch-knob variants given as
-"K=V,K=V;..." (read when a context is created).  Poses of every variant compared bit for bit with the first variant's."""
+"K=V,K=V;..." (read when a context is created).  Poses of every variant compared bit for bit with the first variant's.
+(Round 5 ran it with HSM_EXACT_SINGLE_CW=0/1 -- single scans through the chain-wavefront batch kernel, a knob of that experiment's
+build only: profiles/r05/single_scan_latency_chain_wavefront_form.jsonl, README 9.  Pass --variants with knobs that exist.)"""
 import argparse
 import json
 import os
@@ -14,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="HSM_EXACT_SINGLE_CW=0;HSM_EXACT_SINGLE_CW=1")
+    ap.add_argument("--variants", default="default;HSM_PARITY=fast")
     ap.add_argument("--calls", type=int, default=300)
     args = ap.parse_args()
     from hector_slam_amd import capi, synth
