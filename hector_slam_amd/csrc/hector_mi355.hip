@@ -588,8 +588,13 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
   // 1024: 80.3 -> 37.1, 2048: 92.4 -> 39.3, 3072: 134.5 -> 48.6, 3584: 135.9 -> 60.7 (without the chain wavefront).
   // (hsm_match's single scans stay on the team form: it stops its chain at the scan's last beam and keeps the endpoints in
   // registers -- 1081 beams 94 vs 92 us per call, 720 beams 74 vs 90, 360 beams 51 vs 59 through the chain-wavefront form)
+  // Longer scans (rows beyond the seventeenth stream from memory in every step, one dependent round trip per row): still one
+  // wavefront per scan once the batch has more scans than the device has CUs -- 2162-beam scans, 1024 / 3072 per launch: 83 / 117 us
+  // against 154 / 258 for the teams; 3243 beams: 140 / 195 against 228 / 381; up to 256 scans the 16-wavefront teams are as fast
+  // or faster (110-121 against 122) -- and dense scans (>= exact_dense_min beams) keep their one-workgroup-per-scan form below.
   if (exact && wps > 1 && h->wps_override == 0 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 &&
-      h->exact_cached && h->exact_chain_wave && max_n <= 17 * 64)
+      h->exact_cached && h->exact_chain_wave &&
+      (max_n <= 17 * 64 || (P.batch > h->compute_units && !(h->exact_dense && max_n >= h->exact_dense_min))))
     wps = 1;
   if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, stream);
   switch (wps) {

@@ -190,6 +190,30 @@ def test_batch_ragged_bit_identical(capi, oracle_mod, pyramid_scene, kind, form,
         assert same(ph[k], po) and same(ch[k], co), k
 
 
+def test_mid_size_batch_of_long_scans_takes_one_wavefront_per_scan(capi, oracle_mod, pyramid_scene, kind):
+    """300 scans of 1622 beams (26 rows: nine stream from memory in every step) in the default launch rule: more scans than the
+    device has CUs -> one wavefront per scan + chain wavefront instead of teams; every pose equal to the reference's"""
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    g = exact_gpu(capi, sc, o)
+    rng = np.random.default_rng(11)
+    scans, init = [], []
+    for q in range(300):
+        a = sc.query_scans[q % len(sc.query_scans)]
+        scans.append(np.concatenate([a, a[::2] + np.float32(0.01)]))
+        init.append(sc.query_init[q % len(sc.query_init)] + rng.uniform(-0.02, 0.02, 3).astype(np.float32))
+    init = np.stack(init).astype(np.float32)
+    pts, offs = synth.pack_scans(scans)
+    pb, cb = g.match_batch(init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["texel_cache"] and cfg["block"] == 320 and "chain wavefront" in cfg["kernel"], cfg
+    for q in range(0, 300, 7):
+        po, co = o.match(init[q], scans[q], cov=np.zeros(9, np.float32))
+        assert same(pb[q], po) and same(cb[q], co), q
+    g.close()
+
+
 @pytest.mark.parametrize("chain_wave", ["1", "0"])
 def test_batch_with_a_workgroup_of_empty_scans(capi, oracle_mod, pyramid_scene, kind, chain_wave, monkeypatch):
     """twelve scans, the middle four empty: that workgroup (four scans each, in both texel-cache exact forms) leaves before the
