@@ -219,6 +219,7 @@ struct hsm_ctx {
   bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
   int exact_dense_min = 4096;
   int compute_units = 256;   // of this device (hsm_create)
+  int exact_split_tail = 1;  // env HSM_EXACT_SPLIT_TAIL=0: one launch however the batch divides into generations
   int exact_chain_wave = 1;  // env HSM_EXACT_CHAIN_WAVE=0: no chain-only wavefront, teams of wavefronts for batches below 4096 scans (rounds 3-4)    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
   const char* last_kernel = "";  // name of the matcher kernel the last launch used (hsm_last_launch_kernel)
   unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
@@ -438,6 +439,33 @@ int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   return HSM_OK;
 }
 
+// the texel-cache exact forms of launch_match_exact, by scan length and by how many workgroups the launch leaves a CU
+int launch_match_exact_cached_forms(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  const int per_lane = (max_n + 63) / 64;
+  // A launch that leaves every CU at most THREE workgroups takes the chain-wavefront form (gn_match_exact.h, CW): a fifth
+  // wavefront per workgroup runs the chain jobs, so a round lasts max(job, production) instead of job + production --
+  // 36 us against 52 for a level-0 batch of up to 2048 scans, 49 against 57 at 3072 (profiles/r05/README.md 9).  Not
+  // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
+  // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
+  // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
+  const int groups = (P.batch + 3) / 4;
+  // ... and a map that outgrows the L2s (4096^2: 136 us with six cached rows against 128.5 with fifteen, at 3072 scans) keeps
+  // round 3's form at three workgroups per CU; up to two per CU the chain-wavefront form has the full texel cache as well
+  const bool cw2 = h->exact_chain_wave && groups <= 2 * h->compute_units;
+  const bool cw = cw2 || (h->exact_chain_wave && groups <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23));
+  if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
+  if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
+  // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
+  // exit edges --; a 13-row instantiation costs compile time only: a batch of 720-beam scans runs 13 rounds instead of 17)
+  if (per_lane <= 13) {
+    if (cw2) return launch_match_exact_cached<4, 13, 13, true>(h, P, stream);
+    return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
+  }
+  if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
+  if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
+  return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
+}
+
 template <int WPS, int SPB>
 int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
@@ -445,29 +473,29 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
   // chain-wavefront form (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
   // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  Scans longer than 17 beams per lane stream their tail rows.
   if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
-    const int per_lane = (max_n + 63) / 64;
-    // A launch that leaves every CU at most THREE workgroups takes the chain-wavefront form (gn_match_exact.h, CW): a fifth
-    // wavefront per workgroup runs the chain jobs, so a round lasts max(job, production) instead of job + production --
-    // 36 us against 52 for a level-0 batch of up to 2048 scans, 49 against 57 at 3072 (profiles/r05/README.md 9).  Not
-    // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
-    // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
-    // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
-    const int groups = (P.batch + 3) / 4;
-    // ... and a map that outgrows the L2s (4096^2: 136 us with six cached rows against 128.5 with fifteen, at 3072 scans) keeps
-    // round 3's form at three workgroups per CU; up to two per CU the chain-wavefront form has the full texel cache as well
-    const bool cw2 = h->exact_chain_wave && groups <= 2 * h->compute_units;
-    const bool cw = cw2 || (h->exact_chain_wave && groups <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23));
-    if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
-    if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
-    // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
-    // exit edges --; a 13-row instantiation costs compile time only: a batch of 720-beam scans runs 13 rounds instead of 17)
-    if (per_lane <= 13) {
-      if (cw2) return launch_match_exact_cached<4, 13, 13, true>(h, P, stream);
-      return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
+    // More than one generation of workgroups (four per CU) with a remainder that the chain-wavefront form takes: the whole
+    // generations go out in round 3's form, the remainder behind them in its own launch -- 5000 scans: 57 + 36 us instead of the
+    // 104 a single launch takes (its last, part-filled generation runs ~47 us in the rotating-owner form).
+    const int groups = (P.batch + 3) / 4, full = 4 * h->compute_units, rest = groups % full;
+    if (h->exact_chain_wave && h->exact_split_tail && groups > full && rest > 0 &&
+        (rest <= 2 * h->compute_units || (rest <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23)))) {
+      MatchParams A = P, B = P;
+      A.batch = (groups - rest) * 4;
+      B.batch = P.batch - A.batch;
+      B.begin_world = P.begin_world + 3 * (size_t)A.batch;
+      if (P.offsets) B.offsets = P.offsets + A.batch;  // (absolute offsets into pts: the pointer moves, pts stays)
+      B.out_pose = P.out_pose + 3 * (size_t)A.batch;
+      if (P.out_cov) B.out_cov = P.out_cov + 9 * (size_t)A.batch;
+      B.clock_probe = nullptr;  // (scan 0's probe belongs to the first launch)
+      if (int rc = launch_match_exact_cached_forms(h, A, max_n, stream)) return rc;
+      const int grid_a = h->last_cfg[3];
+      if (int rc = launch_match_exact_cached_forms(h, B, max_n, stream)) return rc;
+      h->last_cfg[2] = 256;  // (hsm_last_launch_config describes the first launch; its grid counts both)
+      h->last_cfg[3] += grid_a;
+      h->last_kernel = "gn_match_exact_cached_kernel + its chain-wavefront form for the last, part-filled generation";
+      return HSM_OK;
     }
-    if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
-    if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
-    return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
+    return launch_match_exact_cached_forms(h, P, max_n, stream);
   }
 #if defined(HSM_EXPERIMENTS)
   // round 2's exact batch form: producer wavefronts + chain wavefronts per workgroup (gn_match.h), env HSM_EXACT_CACHED=0.
@@ -1046,6 +1074,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_EXACT_DENSE")) h->exact_dense = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE_MIN")) h->exact_dense_min = atoi(env);
   if (const char* env = getenv("HSM_EXACT_CHAIN_WAVE")) h->exact_chain_wave = atoi(env);
+  if (const char* env = getenv("HSM_EXACT_SPLIT_TAIL")) h->exact_split_tail = atoi(env);
   if (const char* env = getenv("HSM_WG_SYNC")) h->wg_sync = atoi(env) != 0;
 #if defined(HSM_EXPERIMENTS)  // switches of forms that only an experiment build holds
   if (const char* env = getenv("HSM_EXACT_BATCH")) h->exact_batch_form = atoi(env);

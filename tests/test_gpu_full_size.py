@@ -167,7 +167,7 @@ def test_batches_below_4096_scans_take_the_chain_wavefront_form(capi, oracle_mod
     pts, offs = synth.pack_scans(sc.query_scans)
     cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
     full = None
-    for B in (3073, 3072, 1024, 5, 1):
+    for B in (3073, 3072, 1024, 5, 1):  # (batches beyond one generation of workgroups: test_batch_of_more_than_one_generation...)
         p_b, o_b = synth.pack_scans(sc.query_scans[:B])
         pose, cov = g.match_batch(sc.query_init[:B], p_b, o_b)
         cfg = g.last_launch_config()
@@ -182,6 +182,41 @@ def test_batches_below_4096_scans_take_the_chain_wavefront_form(capi, oracle_mod
         same = (bits(pose) == bits(cpu[:B])).all(1)
         assert same.all(), f"B={B}: {(~same).sum()} poses differ from the reference ({KIND})"
         record(test="chain_wavefront_form", batch=B, checker=KIND, bit_identical_to_reference=int(same.sum()), kernel=cfg)
+
+
+def test_batch_of_more_than_one_generation_splits_off_its_tail(capi, oracle_mod):
+    """5000 scans = one whole generation of the rotating-owner form (4096) + 904 in the chain-wavefront form, two launches behind
+    one call: every pose and covariance equal to the reference's, and equal to the single-launch result (HSM_EXACT_SPLIT_TAIL=0)"""
+    import os
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1081, map_size=2048, levels=3, resolution=0.05, n_build=120, n_query=5000,
+                          room=(40.0, 30.0), seed=99)
+    g, o = build_pair(capi, oracle_mod, sc)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    pose, cov = g.match_batch(sc.query_init, pts, offs)
+    cfg = g.last_launch_config()
+    assert "part-filled generation" in cfg["kernel"] and cfg["grid"] == 1250, cfg
+    cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
+    same = (bits(pose) == bits(cpu)).all(1)
+    assert same.all(), f"{(~same).sum()} of 5000 poses differ from the reference ({KIND})"
+    os.environ["HSM_EXACT_SPLIT_TAIL"] = "0"
+    try:
+        g1 = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels)
+    finally:
+        del os.environ["HSM_EXACT_SPLIT_TAIL"]
+    g1.setUpdateFactorFree(0.4)
+    g1.setUpdateFactorOccupied(0.9)
+    g1.build_map(sc.build_poses, sc.build_scans)
+    pose1, cov1 = g1.match_batch(sc.query_init, pts, offs)
+    assert "part-filled" not in g1.last_launch_config()["kernel"] and g1.last_launch_config()["grid"] == 1250
+    assert np.array_equal(bits(pose), bits(pose1)) and np.array_equal(bits(cov), bits(cov1))
+    # the shared-scan form (no offsets: every hypothesis matches the same scan) through the same split
+    init = np.repeat(sc.query_init[:1], 4100, axis=0) + np.random.default_rng(3).uniform(-0.03, 0.03, (4100, 3)).astype(np.float32)
+    pa, ca = g.match_batch(init, sc.query_scans[0])
+    pb, cb = g1.match_batch(init, sc.query_scans[0])
+    assert "part-filled" in g.last_launch_config()["kernel"]
+    assert np.array_equal(bits(pa), bits(pb)) and np.array_equal(bits(ca), bits(cb))
+    record(test="split_tail", batch=5000, checker=KIND, bit_identical_to_reference=int(same.sum()))
 
 
 def test_config4_share_4096map_pyramid(capi, oracle_mod):
