@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--variants", default="default;HSM_WPS=1;HSM_WPS=1,HSM_EXACT_CHAIN_WAVE=1")
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--workload", default="config3", help="config3 (the headline scene) or config4 (the 4096^2 pyramid's scene)")
+    ap.add_argument("--thin", type=int, default=1, help="every k-th beam of every scan only: the 13- / 9- / 5-row instantiations")
     ap.add_argument("--stretch", type=int, default=1, help="every scan k times as long (its beams repeated with a 1 cm offset): scans beyond the 17 register rows")
     args = ap.parse_args()
     import torch
@@ -50,6 +51,12 @@ def main():
         scans = [synth.make_scan(world, p, n_beams, sfac, rng_q, pad_to_full=True, range_max=rmax) for p in truth]
         init = synth.perturb_poses(truth, np.random.default_rng(1239), 0.15 if args.levels > 1 else 0.04, 0.05 if args.levels > 1 else 0.01)
         pts, offs = synth.pack_scans(scans)
+    if args.thin > 1:
+        o = np.asarray(offs, np.int64)
+        parts = [pts[o[q]:o[q + 1]][::args.thin] for q in range(B)]
+        pts = np.ascontiguousarray(np.concatenate(parts), np.float32)
+        offs = np.concatenate([[0], np.cumsum([p.shape[0] for p in parts])]).astype(np.int32)
+        n_beams = int(max(p.shape[0] for p in parts))
     if args.stretch > 1:  # offsets[] form: scan q = its own beams, then copies shifted by 1 cm, 2 cm, ...
         o = np.asarray(offs, np.int64)
         parts = [np.concatenate([pts[o[q]:o[q + 1]] + np.float32(0.2 * k) for k in range(args.stretch)]) for q in range(B)]
