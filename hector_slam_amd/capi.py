@@ -28,7 +28,8 @@ from . import build as _build
 HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
 PARITY_FAST, PARITY_EXACT, PARITY_RELAXED, PARITY_AUTO = 0, 1, 2, 3
-GATHER_AUTO, GATHER_PEER, GATHER_RCCL = 0, 1, 2
+GATHER_AUTO, GATHER_PEER, GATHER_RCCL, GATHER_DIRECT = 0, 1, 2, 3
+EXCHANGE_HANDLE_BYTES = 64
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -90,6 +91,17 @@ SIGNATURES = {
     "hsm_group_gather_note": (C.c_char_p, [_vp]),
     "hsm_group_gathered": (_vp, [_vp, _i, _i]),
     "hsm_retain_scan": (_i, [_vp, _vp, _i, _f32p]),
+    "hsm_exchange_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "hsm_exchange_destroy": (None, [_vp]),
+    "hsm_exchange_handle": (_i, [_vp, _vp]),
+    "hsm_exchange_connect": (_i, [_vp, _vp]),
+    "hsm_exchange_connect_local": (_i, [_vp, C.POINTER(_vp)]),
+    "hsm_exchange_post": (_i, [_vp, _vp, _i, _i, _vp]),
+    "hsm_exchange_wait": (_i, [_vp, _vp, _vp]),
+    "hsm_exchange_post_wait": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "hsm_exchange_epochs": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "hsm_exchange_status": (_i, [_vp]),
+    "hsm_exchange_memory_kind": (C.c_char_p, [_vp]),
     "hsm_level_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "hsm_map_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
     "hsm_world_coords_pose": (_i, [_vp, _i, _f32p, _f32p]),
@@ -152,7 +164,9 @@ def load_library(build_if_missing: bool = True):
 
 
 def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
-    """[begin, end) of shard `rank` of `total` scans over `world` replicas: the library's ONE partitioning rule (hsm_shard_bounds)"""
+    """[begin, end) of shard `rank` of `total` scans over `world` replicas: the library's ONE partitioning rule, asked of the
+    library itself (hsm_shard_bounds).  sharding.shard_bounds is the same closed form in Python -- it must not need a HIP
+    toolchain or a built library for an index computation; tests/test_sharding_cpu.py holds the two equal."""
     b, e = C.c_int(0), C.c_int(0)
     _check(load_library().hsm_shard_bounds(int(total), int(rank), int(world), C.byref(b), C.byref(e)), "hsm_shard_bounds")
     return b.value, e.value
@@ -633,7 +647,8 @@ class MapRepGroup:
         _check(self._lib.hsm_group_synchronize(self._g), "hsm_group_synchronize")
 
     def set_gather(self, mode: int):
-        """GATHER_AUTO / GATHER_PEER / GATHER_RCCL for match_batch_device (RCCL asked for explicitly raises if unavailable)"""
+        """GATHER_AUTO / GATHER_DIRECT / GATHER_RCCL / GATHER_PEER for match_batch_device (DIRECT or RCCL asked for explicitly raise
+        if unavailable)"""
         _check(self._lib.hsm_group_set_gather(self._g, mode), "hsm_group_set_gather")
 
     def debug_force_p2p(self, on: bool):
@@ -641,12 +656,12 @@ class MapRepGroup:
         _check(self._lib.hsm_group_debug_force_p2p(self._g, 1 if on else 0), "hsm_group_debug_force_p2p")
 
     def gather_mode(self):
-        """("rccl" | "peer", note): what match_batch_device gathers with (initialises the RCCL communicators if still open)"""
+        """("direct" | "rccl" | "peer", note): what match_batch_device gathers with (takes the decision if it is still open)"""
         m = self._lib.hsm_group_gather_mode(self._g)
-        return {GATHER_PEER: "peer", GATHER_RCCL: "rccl"}.get(m, "undecided"), self._lib.hsm_group_gather_note(self._g).decode()
+        return {GATHER_PEER: "peer", GATHER_RCCL: "rccl", GATHER_DIRECT: "direct"}.get(m, "undecided"), self._lib.hsm_group_gather_note(self._g).decode()
 
     def gathered(self, replica, want_cov=False):
-        """device pointer (int, 0 = none) of the all-gathered poses / Hessians replica `replica` holds after an RCCL gather"""
+        """device pointer (int, 0 = none) of the all-gathered poses / Hessians replica `replica` holds after a direct / RCCL gather"""
         return int(self._lib.hsm_group_gathered(self._g, replica, 1 if want_cov else 0) or 0)
 
     def match_batch(self, begin_world, pts, offsets=None, want_cov=True):
@@ -660,6 +675,70 @@ class MapRepGroup:
                                                out.reshape(-1), None if cov is None else cov.ctypes.data),
                "hsm_group_match_batch")
         return out, cov
+
+
+class PoseExchange:
+    """hsm_exchange_*: this rank's end of the device-side gather of sharded result rows (capi.h; protocol in
+    csrc/pose_exchange.h).  `handle()` is what the other processes need (64 bytes, any channel); `connect(handles)` maps their
+    mailboxes; inside ONE process `connect_local(list of PoseExchange in rank order)` uses peer access instead."""
+
+    def __init__(self, rank: int, world: int, total_rows: int, cols: int = 3, depth: int = 4, device: int = -1):
+        self._lib = load_library()
+        h = _vp()
+        _check(self._lib.hsm_exchange_create(int(device), int(rank), int(world), int(total_rows), int(cols), int(depth), C.byref(h)),
+               "hsm_exchange_create")
+        self._h = h
+        self.rank, self.world, self.total_rows, self.cols, self.depth = rank, world, total_rows, cols, depth
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hsm_exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def handle(self) -> bytes:
+        buf = C.create_string_buffer(EXCHANGE_HANDLE_BYTES)
+        _check(self._lib.hsm_exchange_handle(self._h, C.cast(buf, _vp)), "hsm_exchange_handle")
+        return buf.raw
+
+    def connect(self, handles):
+        """handles: the world x 64-byte IPC handles in rank order (bytes, or a list of bytes)"""
+        blob = b"".join(handles) if not isinstance(handles, (bytes, bytearray)) else bytes(handles)
+        if len(blob) != self.world * EXCHANGE_HANDLE_BYTES:
+            raise ValueError(f"expected {self.world} handles of {EXCHANGE_HANDLE_BYTES} bytes")
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(self._lib.hsm_exchange_connect(self._h, C.cast(buf, _vp)), "hsm_exchange_connect")
+
+    def connect_local(self, ranks):
+        arr = (_vp * self.world)(*[r._h for r in ranks])
+        _check(self._lib.hsm_exchange_connect_local(self._h, arr), "hsm_exchange_connect_local")
+
+    def post(self, d_rows: int, first_row: int, n_rows: int, stream: int = 0):
+        _check(self._lib.hsm_exchange_post(self._h, d_rows, int(first_row), int(n_rows), stream), "hsm_exchange_post")
+
+    def wait(self, d_out_all: int, stream: int = 0):
+        _check(self._lib.hsm_exchange_wait(self._h, d_out_all, stream), "hsm_exchange_wait")
+
+    def post_wait(self, d_rows: int, first_row: int, n_rows: int, lag: int, d_out_all: int, stream: int = 0):
+        _check(self._lib.hsm_exchange_post_wait(self._h, d_rows, int(first_row), int(n_rows), int(lag), d_out_all, stream),
+               "hsm_exchange_post_wait")
+
+    def epochs(self):
+        p, w = C.c_ulonglong(0), C.c_ulonglong(0)
+        _check(self._lib.hsm_exchange_epochs(self._h, C.byref(p), C.byref(w)), "hsm_exchange_epochs")
+        return p.value, w.value
+
+    def check(self):
+        """raises HsmError if a wait timed out (call after synchronising the stream)"""
+        _check(self._lib.hsm_exchange_status(self._h), "hsm_exchange_status")
+
+    def memory_kind(self) -> str:
+        return self._lib.hsm_exchange_memory_kind(self._h).decode()
 
 
 def pose_difference_larger_than(p1, p2, dist_thresh, ang_thresh) -> bool:

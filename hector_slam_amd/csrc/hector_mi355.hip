@@ -49,6 +49,7 @@ ncclResult_t ncclGetVersion(int* version);
 #include "gn_match.h"
 #include "gn_match_exact.h"
 #include "hector_mi355/capi.h"
+#include "hsm_host.h"
 #include "map_update.h"
 
 namespace {
@@ -66,6 +67,13 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
   g_last_error = buf;
   return code;
 }
+
+}  // namespace
+
+// the other objects of the library report through the same per-thread text (hsm_host.h)
+int hsm_host::fail(int code, const char* what, hipError_t e) { return ::fail(code, what, e); }
+
+namespace {
 
 #define HIP_TRY(expr)                                         \
   do {                                                        \
@@ -2237,6 +2245,9 @@ struct hsm_group {
   std::vector<float*> d_all_pose, d_all_cov;  // all-gather receive blocks of the replicas other than the root
   std::vector<size_t> d_all_cap;              // floats of pose block (cov block: 3x)
   std::string gather_note;                    // why AUTO settled on peer copies, if it did
+  // HSM_GATHER_DIRECT: one mailbox exchange per replica (pose_exchange.hip), re-made when the gathered row count changes
+  std::vector<hsm_exchange*> xpose, xcov;
+  size_t x_rows = 0;
   std::mutex mu;  // one group call at a time
 };
 
@@ -2256,7 +2267,7 @@ static int group_ensure_gather(hsm_group* g) {
   const int R = (int)g->members.size();
   auto settle_peer = [&](const std::string& why) -> int {
     if (g->gather_pref == HSM_GATHER_RCCL) return fail(HSM_ERR_HIP, ("hsm_group: RCCL gather requested but unavailable: " + why).c_str());
-    g->gather_note = why;
+    g->gather_note += why;
     g->gather_mode = HSM_GATHER_PEER;
     return HSM_OK;
   };
@@ -2266,6 +2277,27 @@ static int group_ensure_gather(hsm_group* g) {
   }
   std::vector<int> devs;
   for (hsm_ctx* h : g->members) devs.push_back(h->device);
+  if (g->gather_pref == HSM_GATHER_AUTO || g->gather_pref == HSM_GATHER_DIRECT) {
+    // the device-side exchange needs every replica's kernels to store into every other replica's HBM: the same device, or
+    // peer access (xGMI on one node)
+    std::string why;
+    if (R > HSM_EXCHANGE_MAX_WORLD) why = "more replicas than HSM_EXCHANGE_MAX_WORLD";
+    for (int a = 0; a < R && why.empty(); ++a)
+      for (int b = 0; b < R && why.empty(); ++b) {
+        if (devs[a] == devs[b]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devs[a], devs[b]) != hipSuccess || !can) {
+          (void)hipGetLastError();
+          why = "no peer access between devices " + std::to_string(devs[a]) + " and " + std::to_string(devs[b]);
+        }
+      }
+    if (why.empty()) {
+      g->gather_mode = HSM_GATHER_DIRECT;
+      return HSM_OK;
+    }
+    if (g->gather_pref == HSM_GATHER_DIRECT) return fail(HSM_ERR_HIP, ("hsm_group: direct gather requested but unavailable: " + why).c_str());
+    g->gather_note = "direct exchange unavailable (" + why + "); ";
+  }
   for (int a = 0; a < R; ++a)
     for (int b = a + 1; b < R; ++b)
       if (devs[a] == devs[b]) return settle_peer("a device is listed more than once (one RCCL rank per device)");
@@ -2277,9 +2309,6 @@ static int group_ensure_gather(hsm_group* g) {
     g->comms.clear();
     return settle_peer(std::string("ncclCommInitAll: ") + api->GetErrorString(r));
   }
-  g->d_all_pose.assign((size_t)R, nullptr);
-  g->d_all_cov.assign((size_t)R, nullptr);
-  g->d_all_cap.assign((size_t)R, 0);
   g->gather_mode = HSM_GATHER_RCCL;
   return HSM_OK;
 }
@@ -2359,12 +2388,16 @@ int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned leve
   g->d_cov.assign((size_t)n_devices, nullptr);
   g->d_cap.assign((size_t)n_devices, 0);
   g->evt.assign((size_t)n_devices, nullptr);
+  g->d_all_pose.assign((size_t)n_devices, nullptr);
+  g->d_all_cov.assign((size_t)n_devices, nullptr);
+  g->d_all_cap.assign((size_t)n_devices, 0);
   if (const char* env = getenv("HSM_GROUP_GATHER")) {
     if (strcmp(env, "rccl") == 0) g->gather_pref = HSM_GATHER_RCCL;
     else if (strcmp(env, "peer") == 0) g->gather_pref = HSM_GATHER_PEER;
+    else if (strcmp(env, "direct") == 0) g->gather_pref = HSM_GATHER_DIRECT;
     else if (strcmp(env, "auto") != 0) {
       hsm_group_destroy(g);
-      return fail(HSM_ERR_INVALID, "hsm_group_create: HSM_GROUP_GATHER must be one of auto, rccl, peer");
+      return fail(HSM_ERR_INVALID, "hsm_group_create: HSM_GROUP_GATHER must be one of auto, direct, rccl, peer");
     }
   }
   *out = g;
@@ -2373,17 +2406,21 @@ int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned leve
 
 int hsm_group_set_gather(hsm_group* g, int mode) {
   if (!g) return fail(HSM_ERR_INVALID, "null group");
-  if (mode != HSM_GATHER_AUTO && mode != HSM_GATHER_PEER && mode != HSM_GATHER_RCCL)
+  if (mode != HSM_GATHER_AUTO && mode != HSM_GATHER_PEER && mode != HSM_GATHER_RCCL && mode != HSM_GATHER_DIRECT)
     return fail(HSM_ERR_INVALID, "hsm_group_set_gather: unknown mode");
   std::lock_guard<std::mutex> glk(g->mu);
   g->gather_pref = mode;
+  g->gather_note.clear();
   if (mode == HSM_GATHER_PEER) {
     g->gather_mode = HSM_GATHER_PEER;
     return HSM_OK;
   }
-  // AUTO / RCCL: decide again (communicators, once made, are kept and reused)
-  g->gather_mode = g->comms.empty() ? HSM_GATHER_AUTO : HSM_GATHER_RCCL;
-  return mode == HSM_GATHER_RCCL ? group_ensure_gather(g) : HSM_OK;
+  if (mode == HSM_GATHER_RCCL && !g->comms.empty()) {  // communicators, once made, are kept and reused
+    g->gather_mode = HSM_GATHER_RCCL;
+    return HSM_OK;
+  }
+  g->gather_mode = HSM_GATHER_AUTO;  // decide again
+  return mode == HSM_GATHER_AUTO ? HSM_OK : group_ensure_gather(g);
 }
 
 int hsm_group_debug_force_p2p(hsm_group* g, int on) {
@@ -2417,6 +2454,11 @@ void hsm_group_destroy(hsm_group* g) {
     RcclApi* api = rccl_api();
     for (ncclComm_t c : g->comms)
       if (c && api->CommDestroy) (void)api->CommDestroy(c);
+  }
+  if (!g->xpose.empty() || !g->xcov.empty()) {
+    for (hsm_ctx* h : g->members) (void)hsm_synchronize(h);
+    for (hsm_exchange* x : g->xpose) hsm_exchange_destroy(x);
+    for (hsm_exchange* x : g->xcov) hsm_exchange_destroy(x);
   }
   TeardownLog log_, *log = &log_;  // (as hsm_destroy: name the first failing call, leave no error behind for the next caller)
   for (size_t r = 0; r < g->members.size(); ++r) {
@@ -2485,7 +2527,35 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
   const int root_dev = g->members[(size_t)root]->device;
   if (int rc = group_ensure_gather(g)) return rc;
   const bool rccl = g->gather_mode == HSM_GATHER_RCCL;
+  const bool direct = g->gather_mode == HSM_GATHER_DIRECT;
   const size_t total = first[(size_t)R];
+  if (direct && total > 0) {
+    // Device-side exchange: one mailbox per replica for [total, 3] (+ one for [total, 9]), made when the gathered row count
+    // changes (a particle filter keeps its particle count; anything else pays a re-allocation here)
+    const bool want_cov = d_out_cov_all != nullptr;
+    if (g->x_rows != total || g->xpose.empty() || (want_cov && g->xcov.empty())) {
+      for (hsm_ctx* h : g->members)
+        if (int rc0 = hsm_synchronize(h)) return rc0;
+      const bool remake_pose = g->x_rows != total || g->xpose.empty();
+      auto make = [&](std::vector<hsm_exchange*>& xs, int cols) -> int {
+        for (hsm_exchange* x : xs) hsm_exchange_destroy(x);
+        xs.assign((size_t)R, nullptr);
+        for (int r = 0; r < R; ++r)
+          if (int rc0 = hsm_exchange_create(g->members[(size_t)r]->device, r, R, (int)total, cols, 2, &xs[(size_t)r])) return rc0;
+        for (int r = 0; r < R; ++r)
+          if (int rc0 = hsm_exchange_connect_local(xs[(size_t)r], xs.data())) return rc0;
+        return HSM_OK;
+      };
+      if (remake_pose) {
+        if (int rc0 = make(g->xpose, 3)) return rc0;
+        for (hsm_exchange* x : g->xcov) hsm_exchange_destroy(x);  // (shaped for the old row count)
+        g->xcov.clear();
+      }
+      if (want_cov && g->xcov.empty())
+        if (int rc0 = make(g->xcov, 9)) return rc0;
+      g->x_rows = total;
+    }
+  }
   bool equal = counts[0] > 0;  // ncclAllGather wants the same count from every rank
   for (int r = 1; r < R; ++r) equal = equal && counts[r] == counts[0];
   const bool self_send = rccl && g->force_p2p;  // test hook: the send / receive form for every shard, the root's own included
@@ -2499,7 +2569,7 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
     std::lock_guard<std::mutex> lk(h->mu);
     if (int rc2 = select_device(h)) return rc2;
     if (!g->evt[(size_t)r]) HIP_TRY(hipEventCreateWithFlags(&g->evt[(size_t)r], hipEventDisableTiming));
-    if (rccl && equal && r != root && total * 3 > g->d_all_cap[(size_t)r]) {  // all-gather receive blocks of a non-root replica
+    if (((rccl && equal) || direct) && r != root && total * 3 > g->d_all_cap[(size_t)r]) {  // all-gather receive blocks of a non-root replica
       (void)hipFree(g->d_all_pose[(size_t)r]);
       (void)hipFree(g->d_all_cov[(size_t)r]);
       g->d_all_pose[(size_t)r] = g->d_all_cov[(size_t)r] = nullptr;
@@ -2522,7 +2592,9 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
                                               d_scan_offsets ? d_scan_offsets[r] : nullptr, shared_n, g->d_pose[(size_t)r],
                                               d_out_cov_all ? g->d_cov[(size_t)r] : nullptr, h->stream))
         return rc2;
-      if (!rccl || (r == root && !equal && !self_send)) {  // (RCCL send/recv gather: the root's own shard is a local copy)
+      if (direct) {
+        // (below, also for a replica without scans: every replica posts every epoch)
+      } else if (!rccl || (r == root && !equal && !self_send)) {  // (RCCL send/recv gather: the root's own shard is a local copy)
         HIP_TRY(hipMemcpyPeerAsync(d_out_pose_all + 3 * first[(size_t)r], root_dev, g->d_pose[(size_t)r], h->device,
                                    n * 3 * sizeof(float), h->stream));
         if (d_out_cov_all)
@@ -2530,10 +2602,24 @@ int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* c
                                      n * 9 * sizeof(float), h->stream));
       }
     }
+    if (direct && total > 0) {
+      // ONE launch on this replica's stream, behind its match: store the shard's rows into every replica's mailbox and
+      // unpack all shards' rows as they arrive -- the root into the caller's arrays, the others into blocks the group
+      // keeps (every replica holds all poses afterwards: hsm_group_gathered).  No collective, no event, no host wait.
+      if (int rc2 = hsm_exchange_post_wait(g->xpose[(size_t)r], g->d_pose[(size_t)r], (int)first[(size_t)r], (int)n, 0,
+                                           r == root ? d_out_pose_all : g->d_all_pose[(size_t)r], h->stream))
+        return rc2;
+      if (d_out_cov_all)
+        if (int rc2 = hsm_exchange_post_wait(g->xcov[(size_t)r], g->d_cov[(size_t)r], (int)first[(size_t)r], (int)n, 0,
+                                             r == root ? d_out_cov_all : g->d_all_cov[(size_t)r], h->stream))
+          return rc2;
+      return HSM_OK;
+    }
     if (!rccl) HIP_TRY(hipEventRecord(g->evt[(size_t)r], h->stream));
     return HSM_OK;
   });
   if (rc != HSM_OK) return rc;
+  if (direct) return HSM_OK;
   if (rccl) {
     // ONE grouped collective over the group's communicators, each rank's part on its replica's stream (behind its match):
     // equal shards -> ncclAllGather of [B/G, 3] (+ [B/G, 9]); the root receives straight into the caller's arrays, the
@@ -2588,6 +2674,10 @@ int hsm_group_synchronize(hsm_group* g) {
   if (!g) return fail(HSM_ERR_INVALID, "null group");
   for (hsm_ctx* h : g->members)
     if (int rc = hsm_synchronize(h)) return rc;
+  for (hsm_exchange* x : g->xpose)  // a gather whose rows did not all arrive says so here
+    if (int rc = hsm_exchange_status(x)) return rc;
+  for (hsm_exchange* x : g->xcov)
+    if (int rc = hsm_exchange_status(x)) return rc;
   return HSM_OK;
 }
 

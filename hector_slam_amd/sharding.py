@@ -1,9 +1,16 @@
 """Multi-GPU data parallelism for batched matching: one process per GPU, the pyramid replicated,
-the batch of independent (pose hypothesis, scan) pairs split contiguously across ranks, and ONE kind of
-collective -- an all-gather of the [B/G, 3] fp32 poses (optionally the [B/G, 9] Hessians), per batched match
-(AsyncRowGather) or, for a stream of batches, per bucket of batches (BucketedRowGather: the host cost of
-enqueueing a collective is as large as a whole matcher launch).  With backend "nccl" this is RCCL over xGMI; the payload is tens of KiB per
-rank, i.e. latency-bound, so a single un-bucketed all-gather is the right shape.
+the batch of independent (pose hypothesis, scan) pairs split contiguously across ranks, and ONE exchange step --
+every rank ends up with every rank's [B/G, 3] fp32 poses (optionally the [B/G, 9] Hessians) -- per batched match.
+
+Transports of that step:
+  DirectRowGather    (round 6, what bench.py --gpus N times) the library's device-side exchange (hsm_exchange_*,
+                     csrc/pose_exchange.h): every rank stores its rows straight into every rank's IPC-mapped mailbox over
+                     xGMI, one small kernel per match on the matcher's stream; torch.distributed only carries the 64-byte
+                     IPC handles once, at set-up.
+  AsyncRowGather     one torch.distributed all-gather per match (backend "nccl" = RCCL); 45 us of host time per enqueue
+                     and an RCCL kernel beside the matcher launch (103 us per step against 58.5: profiles/r05/README.md 7)
+  BucketedRowGather  the same collective for a bucket of consecutive matches: amortises the above, but is not a gather
+                     per match; kept as the labelled comparison figure.
 The reference has no distributed path at all; nothing here translates reference code.
 """
 from __future__ import annotations
@@ -13,11 +20,16 @@ import torch.distributed as dist
 
 
 def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous [begin, end) of rank's share; the first total % world ranks get one extra.  The rule itself lives in the
-    native library (hsm_shard_bounds): the single-process group (hsm_group_match_batch) and this process-per-GPU path split a
-    batch identically, so results gathered by either transport line up row for row."""
-    from . import capi
-    return capi.shard_bounds(total, rank, world)
+    """Contiguous [begin, end) of rank's share; the first total % world ranks get one extra.  The same closed form as the
+    native library's hsm_shard_bounds (tests/test_sharding_cpu.py::test_shard_bounds_is_the_native_rule holds the two
+    equal), so the single-process group (hsm_group_match_batch) and this process-per-GPU path split a batch identically and
+    results gathered by either transport line up row for row -- stated here in Python so that an index computation (and
+    the CPU / gloo path built on it) needs neither a HIP toolchain nor a built library."""
+    if total < 0 or world <= 0 or not 0 <= rank < world:
+        raise ValueError(f"shard_bounds: bad argument (total={total}, rank={rank}, world={world})")
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
 
 
 def max_shard(total: int, world: int) -> int:
@@ -105,6 +117,82 @@ class AsyncRowGather:
             if self.work[s] is not None:
                 self.work[s].wait()
                 self.work[s] = None
+
+
+class DirectRowGather:
+    """ONE gather per batched match without a collective: the device-side exchange of the native library.
+
+    Set-up (once): every rank creates its mailbox (capi.PoseExchange), the 64-byte IPC handles travel over the process group
+    (all_gather_object -- any backend), every rank maps the others' mailboxes.  Per match, on the matcher's stream:
+    ``launch()`` = ONE kernel that posts this rank's rows of batch k to every rank and -- with ``lag`` = 1 -- unpacks batch
+    k-1's gathered rows, which have been travelling behind a whole matcher launch; ``drain()`` waits for what is still in
+    flight.  Rows of rank r sit at ``shard_bounds(total_rows, r, world)`` of the gathered [total_rows, cols] array.
+    The mailbox holds 2 + 2 lag buffers: no acknowledgements are needed (csrc/pose_exchange.h).
+    Without a process group it is a one-rank exchange (same kernels, same protocol)."""
+
+    def __init__(self, total_rows: int, cols: int, device, lag: int = 1, group=None, dtype=torch.float32):
+        from . import capi
+        assert dtype == torch.float32, "the exchange carries fp32 rows"
+        self.group = group
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank = dist.get_rank(group) if self.dist else 0
+        self.total_rows, self.cols, self.lag = total_rows, cols, lag
+        self.first_row, end = shard_bounds(total_rows, self.rank, self.world)
+        self.rows = end - self.first_row
+        dev = torch.device(device)
+        self.x = capi.PoseExchange(self.rank, self.world, total_rows, cols, depth=2 + 2 * lag, device=dev.index if dev.index is not None else -1)
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, self.x.handle(), group=group)
+            self.x.connect(handles)
+        self.local = torch.zeros((max(self.rows, 1), cols), dtype=dtype, device=dev)[: self.rows]
+        self.out = [torch.zeros((total_rows, cols), dtype=dtype, device=dev) for _ in range(2)]
+        self.launched = 0   # epochs posted
+        self.landed = 0     # epochs unpacked (stream order)
+        self.collectives = 0  # torch.distributed collectives on the data path: stays 0
+
+    def next_local(self) -> torch.Tensor:
+        """[rows, cols] view the next batch's results go into (one buffer: the post that reads it precedes the next matcher
+        launch in stream order)"""
+        return self.local
+
+    def launch(self, stream=None) -> None:
+        """the batch written into next_local() has been queued on ``stream``: post it, unpack the batch ``lag`` matches back"""
+        s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        e = self.launched + 1
+        w = e - self.lag
+        lands = w >= 1 and w > self.landed  # (not after a drain: that batch has been unpacked already)
+        self.x.post_wait(self.local.data_ptr(), self.first_row, self.rows, self.lag, self.out[w % 2].data_ptr() if lands else 0, s)
+        self.launched = e
+        if lands:
+            self.landed = w
+
+    def drain(self, stream=None) -> None:
+        """wait (on the stream) for every posted batch"""
+        s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        while self.landed < self.launched:
+            self.landed += 1
+            self.x.wait(self.out[self.landed % 2].data_ptr(), s)
+
+    flush = drain
+
+    def wait_all(self) -> None:
+        pass  # nothing outside the stream: synchronising the stream is the wait
+
+    def last_result(self) -> torch.Tensor:
+        """[total_rows, cols]: every rank's rows of the most recent batch (drains; valid once the stream has been synchronised)"""
+        if self.launched == 0:
+            raise RuntimeError("DirectRowGather.last_result: no batch yet")
+        self.drain()
+        return self.out[self.landed % 2]
+
+    def check(self) -> None:
+        """raises if a wait timed out (after synchronising the stream)"""
+        self.x.check()
+
+    def close(self) -> None:
+        self.x.close()
 
 
 class BucketedRowGather:

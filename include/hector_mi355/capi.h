@@ -178,10 +178,13 @@ int hsm_update_by_scan_level(hsm_ctx* h, int level, const float pose_world[3],
  * (bench.py's --gpus N uses the other deployment shape: one process per GPU and an RCCL all-gather of device-resident
  * poses through torch.distributed; bench.py --group N drives this one.) */
 typedef struct hsm_group hsm_group;
-/* how hsm_group_match_batch_device gathers.  AUTO (default; env HSM_GROUP_GATHER=auto|rccl|peer at hsm_group_create):
- * RCCL when librccl loads, every replica sits on its own device and ncclCommInitAll succeeds, else peer copies
- * (hsm_group_gather_note says why).  RCCL asked for explicitly fails instead of falling back. */
-enum { HSM_GATHER_AUTO = 0, HSM_GATHER_PEER = 1, HSM_GATHER_RCCL = 2 };
+/* how hsm_group_match_batch_device gathers.  AUTO (default; env HSM_GROUP_GATHER=auto|direct|rccl|peer at hsm_group_create):
+ * DIRECT -- the device-side exchange below (hsm_exchange_*: every replica's kernel stores its rows into every replica's
+ * mailbox, one launch per replica behind its match, no collective, no event) -- whenever the replicas' devices can access
+ * each other (or are the same device); else RCCL when librccl loads, every replica sits on its own device and
+ * ncclCommInitAll succeeds; else peer copies (hsm_group_gather_note says why).  DIRECT or RCCL asked for explicitly fail
+ * instead of falling back. */
+enum { HSM_GATHER_AUTO = 0, HSM_GATHER_PEER = 1, HSM_GATHER_RCCL = 2, HSM_GATHER_DIRECT = 3 };
 int hsm_group_set_gather(hsm_group* g, int mode);
 /* test hook: with the RCCL gather, send EVERY shard -- the root's own too (a send to self) -- through the grouped ncclSend /
  * ncclRecv form that unequal shards take, instead of ncclAllGather.  Lets a one-device box run that form on hardware. */
@@ -189,13 +192,13 @@ int hsm_group_debug_force_p2p(hsm_group* g, int on);
 /* The partitioning of `total` scans over `world` replicas (contiguous shards, the first total % world hold one more): [begin, end)
  * of shard `rank`.  Used by hsm_group_match_batch and by hector_slam_amd/sharding.py -- one rule for both transports. */
 int hsm_shard_bounds(int total, int rank, int world, int* begin, int* end);
-/* the mode in effect: HSM_GATHER_PEER or HSM_GATHER_RCCL.  The decision -- dlopen of librccl and ncclCommInitAll over the group's
- * devices, SECONDS on a multi-GPU node -- is taken on first use: by this call, by hsm_group_set_gather(RCCL), or else inside the
+/* the mode in effect: HSM_GATHER_DIRECT, HSM_GATHER_RCCL or HSM_GATHER_PEER.  The decision -- for RCCL: dlopen of librccl and
+ * ncclCommInitAll over the group's devices, SECONDS on a multi-GPU node -- is taken on first use: by this call, by hsm_group_set_gather(RCCL), or else inside the
  * first hsm_group_match_batch_device.  A latency-sensitive caller asks for the mode once right after hsm_group_create. */
 int hsm_group_gather_mode(hsm_group* g);
 const char* hsm_group_gather_note(const hsm_group* g);
-/* RCCL gather with equal shards is an all-gather: replica i (other than the root, which received into the caller's arrays)
- * holds all poses [sum(counts) * 3] (want_cov: all Hessians [sum * 9]) in a block the group owns; NULL otherwise */
+/* the DIRECT gather, and the RCCL gather with equal shards, are all-gathers: replica i (other than the root, which received into
+ * the caller's arrays) holds all poses [sum(counts) * 3] (want_cov: all Hessians [sum * 9]) in a block the group owns; NULL otherwise */
 const float* hsm_group_gathered(hsm_group* g, int replica, int want_cov);
 int hsm_group_create(float map_resolution, int size_x, int size_y, unsigned levels, float start_x, float start_y,
                      const int* devices, int n_devices, hsm_group** out);
@@ -211,8 +214,9 @@ int hsm_group_process_scan(hsm_group* g, const float hint_world[3], const float*
  * d_pts_xy[r], d_scan_offsets[r]: CSR offsets relative to the shard, or d_scan_offsets == NULL / entries NULL for
  * pose hypotheses of one shared scan of shared_n beams per replica).  The poses of all shards are gathered, in replica
  * order, into d_out_pose_all [sum(counts) * 3] on replica `root`'s device (and the Hessians into d_out_cov_all
- * [sum * 9] unless NULL): by a grouped ncclAllGather (equal counts) / ncclSend + ncclRecv (ragged counts) on the replicas'
- * own streams, or by hipMemcpyPeerAsync on each replica's own stream (hsm_group_set_gather).  Asynchronous: returns when
+ * [sum * 9] unless NULL): by the device-side exchange (one launch per replica on its own stream), by a grouped ncclAllGather
+ * (equal counts) / ncclSend + ncclRecv (ragged counts) on the replicas' own streams, or by hipMemcpyPeerAsync on each replica's
+ * own stream (hsm_group_set_gather).  Asynchronous: returns when
  * everything is queued; root's context stream is ordered behind the gather (hsm_synchronize(hsm_group_member(g, root)) or
  * hsm_group_synchronize wait for it). */
 int hsm_group_match_batch_device(hsm_group* g, const int* counts, const float* const* d_begin_world,
@@ -225,6 +229,47 @@ int hsm_group_match_batch(hsm_group* g, int batch, const float* begin_world, con
                           const int* scan_offsets, int shared_n, float* out_pose, float* out_cov);
 /* what hsm_match does to the coarse-level containers, without matching (MapRepMultiMap.h:127) */
 int hsm_retain_scan(hsm_ctx* h, const float* pts_xy, int n, const float origo[2]);
+
+/* ---- device-side gather of sharded results (extension; the reference has no multi-device path) -------------------
+ * The one exchange step of a batched matchData sharded over G GPUs (MapRepMultiMap.h:116-132 is the call being sharded;
+ * SURVEY.md 8(e)): every rank ends up with every rank's [B/G, cols] rows (cols = 3 poses, 9 Hessians).  No collective library
+ * on the data path: every rank owns a MAILBOX in its own HBM; a POST stores a rank's rows -- one 8-byte {value, epoch tag}
+ * store per float, system scope -- into every rank's mailbox over xGMI (its own included); a WAIT polls the own mailbox until
+ * every value of that epoch has arrived and unpacks it into a dense fp32 array.  One small kernel per step on the caller's
+ * stream (protocol and flow control: hector_slam_amd/csrc/pose_exchange.h).  Used by hsm_group_* (HSM_GATHER_DIRECT)
+ * and, one process per GPU, by hector_slam_amd/sharding.py (DirectRowGather: the handles travel once over torch.distributed,
+ * the rows never do).
+ *
+ *   create          rank `rank` of `world` (<= 16) on `device` (-1 = current): a mailbox of `depth` buffers of
+ *                   [total_rows][cols] values.  depth >= 2 + 2 * lag (lag: how many posts a rank runs ahead of its waits).
+ *   handle          64-byte hipIpcMemHandle of this rank's mailbox -- hand it to the other PROCESSES (any channel)
+ *   connect         handles of all ranks, world x 64 bytes in rank order (the own entry is ignored): maps the peers' mailboxes
+ *   connect_local   the ranks of ONE process: ranks[r] = rank r's exchange (peer access instead of IPC)
+ *   post            epoch = posted + 1: rows [first_row, first_row + n_rows) of the gathered array, from d_rows [n_rows][cols]
+ *                   (device memory, written by work queued earlier on `stream`), to every rank
+ *   wait            epoch = waited + 1 (must have been posted by this rank): d_out_all [total_rows][cols] holds all ranks'
+ *                   rows when the launch completes (NULL: arrival only).  Bounded: values that do not arrive within
+ *                   HSM_EXCHANGE_TIMEOUT_MS (default 2000) read NaN and hsm_exchange_status fails.
+ *   post_wait       ONE launch: post epoch e = posted + 1 and wait for epoch e - lag (skipped while e <= lag, or when that epoch
+ *                   has been waited for already)
+ *   status          HSM_OK, or HSM_ERR_HIP after a timed-out wait (text in hsm_last_error)
+ * Every rank calls post the same number of times; post and wait of one exchange go on ONE stream (or streams the caller orders). */
+typedef struct hsm_exchange hsm_exchange;
+#define HSM_EXCHANGE_HANDLE_BYTES 64
+#define HSM_EXCHANGE_MAX_WORLD 16
+int hsm_exchange_create(int device, int rank, int world, int total_rows, int cols, int depth, hsm_exchange** out);
+void hsm_exchange_destroy(hsm_exchange* x);
+int hsm_exchange_handle(hsm_exchange* x, void* handle64);
+int hsm_exchange_connect(hsm_exchange* x, const void* handles);
+int hsm_exchange_connect_local(hsm_exchange* x, hsm_exchange* const* ranks);
+int hsm_exchange_post(hsm_exchange* x, const float* d_rows, int first_row, int n_rows, void* stream);
+int hsm_exchange_wait(hsm_exchange* x, float* d_out_all, void* stream);
+int hsm_exchange_post_wait(hsm_exchange* x, const float* d_rows, int first_row, int n_rows, int lag, float* d_out_all,
+                           void* stream);
+int hsm_exchange_epochs(const hsm_exchange* x, unsigned long long* posted, unsigned long long* waited);
+int hsm_exchange_status(hsm_exchange* x);
+/* "uncached" or "fine-grained": the kind of device memory the mailbox got */
+const char* hsm_exchange_memory_kind(const hsm_exchange* x);
 
 /* ---- host mirror support: replaces getGridMap(level) cell access --------------
  * HSL/slam_main/MapRepMultiMap.h:95, HSL/map/GridMapBase.h:141-159 */

@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# a checked build: a kernel that misses its occupancy target is an error here (hector_slam_amd/build.py)
+os.environ.setdefault("HSM_BUILD_STRICT", "1")
 
 
 def pytest_configure(config):

@@ -943,13 +943,13 @@ def test_group_gathers_with_rccl(capi, pyramid_scene, monkeypatch):
             sp, so = synth.pack_scans(sc.query_scans[b:e])
             shards.append([torch.from_numpy(np.ascontiguousarray(sc.query_init[b:e])).to(dev), torch.from_numpy(sp).to(dev), torch.from_numpy(so).to(dev)])
         got = {}
-        for mode in (capi.GATHER_RCCL, capi.GATHER_PEER):
+        for mode in (capi.GATHER_RCCL, capi.GATHER_PEER, capi.GATHER_DIRECT):
             grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, devices)
             grp.set_update_factors(0.4, 0.9)
             for r in range(ndev):
                 grp.member(r).build_map(sc.build_poses, sc.build_scans)
             grp.set_gather(mode)
-            assert grp.gather_mode()[0] == ("rccl" if mode == capi.GATHER_RCCL else "peer")
+            assert grp.gather_mode()[0] == {capi.GATHER_RCCL: "rccl", capi.GATHER_PEER: "peer", capi.GATHER_DIRECT: "direct"}[mode]
             root = ndev - 1
             rdev = torch.device("cuda", devices[root])
             for rep in range(3):
@@ -961,7 +961,7 @@ def test_group_gathers_with_rccl(capi, pyramid_scene, monkeypatch):
                 grp.synchronize()
                 assert np.array_equal(bits(d_all.cpu().numpy()), bits(want_p[:nb])), (mode, ragged, rep)
                 assert np.array_equal(bits(d_cov.cpu().numpy()), bits(want_c[:nb])), (mode, ragged, rep)
-            if mode == capi.GATHER_RCCL and not ragged and ndev > 1:  # an all-gather: every other replica holds all poses too
+            if (mode == capi.GATHER_DIRECT or (mode == capi.GATHER_RCCL and not ragged)) and ndev > 1:  # an all-gather: every other replica holds all poses too
                 ptr = grp.gathered(0)
                 assert ptr != 0
             if mode == capi.GATHER_RCCL:
@@ -980,11 +980,13 @@ def test_group_gathers_with_rccl(capi, pyramid_scene, monkeypatch):
             got[mode] = d_all.cpu().numpy()
             grp.close()
         assert np.array_equal(bits(got[capi.GATHER_RCCL]), bits(got[capi.GATHER_PEER]))
-    # one device listed twice: no second RCCL rank on it
+        assert np.array_equal(bits(got[capi.GATHER_DIRECT]), bits(got[capi.GATHER_PEER]))
+    # one device listed twice: AUTO takes the device-side exchange (round 6; it needs no communicator); no second RCCL rank
+    # on one device -- RCCL asked for explicitly is refused, and says why
     grp = capi.MapRepGroup(sc.resolution, sc.map_size, sc.map_size, sc.levels, [0, 0])
     mode, note = grp.gather_mode()
-    assert mode == "peer" and "more than once" in note
-    with pytest.raises(capi.HsmError):
+    assert mode == "direct", (mode, note)
+    with pytest.raises(capi.HsmError, match="more than once"):
         grp.set_gather(capi.GATHER_RCCL)
     grp.close()
     monkeypatch.setenv("HSM_GROUP_GATHER", "Rccl")  # a typo must not silently select something
@@ -1039,8 +1041,8 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
     p2, _ = grp.match_batch(sc.query_init[:2], *synth.pack_scans(sc.query_scans[:2]))
     assert np.array_equal(bits(p2), bits(pb[:2]))
     assert grp.match_batch(np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), np.zeros(1, np.int32))[0].shape == (0, 3)
-    # device-resident shards (uneven: 5 / 0 / 11 scans), gathered on replica 2's device by peer copies; repeated so
-    # that the persistent workers and the per-replica result blocks are reused
+    # device-resident shards (uneven: 5 / 0 / 11 scans), gathered on replica 2's device (AUTO: the device-side exchange;
+    # then peer copies); repeated so that the persistent workers, the mailboxes and the per-replica result blocks are reused
     bounds = [(0, 5), (5, 5), (5, 16)]
     shards = []
     for r, (b, e) in enumerate(bounds):
@@ -1050,7 +1052,10 @@ def test_single_process_device_group(capi, oracle_mod, pyramid_scene, kind):
                        torch.from_numpy(sh_offs).to(dev)])
     root = 2
     rdev = torch.device("cuda", devices[root])
-    for rep in range(3):
+    assert grp.gather_mode()[0] == "direct"
+    for rep in range(6):
+        if rep == 3:
+            grp.set_gather(capi.GATHER_PEER)
         d_all = torch.zeros((16, 3), dtype=torch.float32, device=rdev)
         d_cov = torch.zeros((16, 9), dtype=torch.float32, device=rdev)
         torch.cuda.synchronize()

@@ -13,17 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def device_asm(tmp_path_factory):
+def device_asm():
     from hector_slam_amd import build
-    hipcc = build.hipcc_path()
-    if hipcc is None:
+    if build.hipcc_path() is None:
         pytest.skip("hipcc not found")
-    out = tmp_path_factory.mktemp("isa") / "device.s"
-    cmd = [hipcc] + [f for f in build.FLAGS if f not in ("-shared", "-fPIC")] + [
-        "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "hector_slam_amd", "csrc"),
-        build.SRC, "-o", str(out)]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    return out.read_text()
+    return build.device_asm()  # every translation unit of the library, with the library's own flags
 
 
 def kernels(asm):
@@ -219,7 +213,10 @@ def test_chain_wavefront_forms_leave_room_for_six_wavefronts_per_simd(device_asm
 
 def test_build_fails_on_a_missed_occupancy_target():
     from hector_slam_amd import build
-    assert "-Werror=pass-failed" in build.FLAGS
+    assert "-Werror=pass-failed" in build.STRICT_FLAGS
+    # checked builds (this suite, __graft_entry__.build(), the round-end script) keep it an error; only the lazily-run
+    # user-side build may fall back to a build without the check (with a warning)
+    assert os.environ.get("HSM_BUILD_STRICT") == "1"
 
 
 def test_every_matcher_instantiation_reaches_its_designed_occupancy(device_asm):

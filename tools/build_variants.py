@@ -8,7 +8,4 @@ out = os.path.join(os.path.dirname(b.LIB), "variants")
 os.makedirs(out, exist_ok=True)
 for spec in sys.argv[1:]:
     name, flags = spec.split(":", 1)
-    dst = os.path.join(out, f"libhector_mi355_{name}.so")
-    cmd = [b.hipcc_path()] + b.FLAGS + flags.split() + ["-I", os.path.join(b._ROOT, "include"), "-I", os.path.join(b._PKG, "csrc"), b.SRC, "-o", dst]
-    subprocess.run(cmd, check=True)
-    print(dst)
+    print(b.build_variant(os.path.join(out, f"libhector_mi355_{name}.so"), flags.split()))
