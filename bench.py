@@ -1076,9 +1076,9 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
 def group_leg(args):
     """`--group N`: the C++ single-process deployment shape (hsm_group_*): ONE process, one replica of the map per device,
     persistent worker threads, device-resident shards of 4096 scans per device, the poses of all shards gathered on replica
-    0's device -- once through RCCL (ncclCommInitAll + one grouped ncclAllGather per step, librccl dlopen'ed by the library)
-    and once through peer copies.  Prints one JSON line in the bench schema (value = the RCCL gather's throughput when RCCL is
-    available, else the peer gather's); `gathers` holds both."""
+    0's device -- through the device-side exchange (hsm_exchange_*, the group's default), through RCCL (ncclCommInitAll + one
+    grouped ncclAllGather per step, librccl dlopen'ed by the library) and through peer copies.  Prints one JSON line in the
+    bench schema (value = the first of those that is available); `gathers` holds all three."""
     import torch
     from hector_slam_amd import capi, synth
     N = args.group
@@ -1116,7 +1116,7 @@ def group_leg(args):
         grp.member(0).synchronize()
         want.append((r, d_tmp.cpu().numpy().copy()))
     gathers = {}
-    modes = [("rccl", capi.GATHER_RCCL), ("peer", capi.GATHER_PEER)]
+    modes = [("direct", capi.GATHER_DIRECT), ("rccl", capi.GATHER_RCCL), ("peer", capi.GATHER_PEER)]
     for name, mode in modes:
         try:
             grp.set_gather(mode)
@@ -1135,7 +1135,7 @@ def group_leg(args):
         ok = all(bool((got[r * B:(r + 1) * B].view(np.uint32) == w.view(np.uint32)).all()) for r, w in want)
         gathers[name] = {"value": N * B * its * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                          "gathered_rows_bit_identical_to_single_context": ok}
-    best = gathers.get("rccl") if "value" in gathers.get("rccl", {}) else gathers.get("peer", {})
+    best = next((gathers[k] for k in ("direct", "rccl", "peer") if "value" in gathers.get(k, {})), {})
     out = {"metric": "scan-match GN iterations/sec (1081-beam, 2048^2 map)", "value": best.get("value"), "unit": "GN it/s", "n_gpus": N,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": best.get("ms_per_step"), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -120,6 +120,7 @@ SIGNATURES = {
     "hsm_debug_set_coop_barrier": (_i, [_vp, C.c_uint]),
     "hsm_debug_set_coop_mute": (_i, [_vp, _i]),
     "hsm_debug_coop_fallbacks": (_i, [_vp]),
+    "hsm_debug_spec_stats": (_i, [_vp, _i, _vp]),
     "hsm_debug_marks_nonzero": (_i, [_vp, _i, _vp]),
     "hsm_debug_sincos": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
     "hsm_debug_expf": (_i, [_vp, _i, _f32p, _f32p, _f32p]),
@@ -563,6 +564,12 @@ class MapRepMultiMap:
 
     def debug_set_coop_mute(self, block_plus_one):
         _check(self._lib.hsm_debug_set_coop_mute(self._h, int(block_plus_one)), "hsm_debug_set_coop_mute")
+
+    def debug_spec_stats(self, enable=True):
+        """(boundaries, candidate == carry, shifted, re-run) of the speculative-carry matcher's stitching passes since the last call"""
+        out = (C.c_ulonglong * 4)()
+        _check(self._lib.hsm_debug_spec_stats(self._h, 1 if enable else 0, C.cast(out, _vp)), "hsm_debug_spec_stats")
+        return tuple(int(x) for x in out)
 
     def debug_coop_fallbacks(self):
         return int(self._lib.hsm_debug_coop_fallbacks(self._h))

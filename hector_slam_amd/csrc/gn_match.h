@@ -90,6 +90,10 @@ struct LevelView {
   int gn_steps;        // 1 + maxIterations (ScanMatcher.h:74,94-97)
 };
 
+struct SpecStats {  // optional counters of gn_match_spec_kernel: boundaries walked, candidate == carry, shifted, re-run
+  unsigned long long boundaries, exact, shifted, rerun;
+};
+
 struct MatchParams {
   LevelView lv[kMaxLevels];
   int first_level;         // coarsest level to run (levels first_level .. last_level, descending)
@@ -116,6 +120,10 @@ struct MatchParams {
                              // publishes its records, 0 = none -- how the suite provokes the exchange timeout
   unsigned long long* clock_probe;  // nullptr, or four words the wave of scan 0 fills: shader-clock counter (s_memtime)
                                     // and 100 MHz wall clock at its first GN step [0,1] and at its end [2,3]
+  float* spec_scratch;     // gn_match_spec_kernel: [batch][spec_stride] float4s for the nine products of every beam
+  unsigned spec_stride;    // float4s per scan
+  SpecStats* spec_stats;   // nullptr, or counters the stitching pass adds to (hsm_debug_spec_stats)
+  int n_bound;             // HOST ONLY: 0 = scan lengths live on the device only (max_n is a hint), else no scan is longer than this
 };
 
 __device__ __forceinline__ void publish_done(const MatchParams& P) {

@@ -48,6 +48,7 @@ ncclResult_t ncclGetVersion(int* version);
 
 #include "gn_match.h"
 #include "gn_match_exact.h"
+#include "gn_match_spec.h"
 #include "hector_mi355/capi.h"
 #include "hsm_host.h"
 #include "map_update.h"
@@ -224,6 +225,11 @@ struct hsm_ctx {
   bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
   int last_cfg[6] = {0, 0, 0, 0, 0, 0};
   int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
+  bool exact_spec = false;       // env HSM_EXACT_SPEC=1: one-workgroup-per-scan launches in exact order take the speculative-carry form (gn_match_spec.h:
+                                 // the same bits; measured SLOWER than the literal chains on one CU -- DESIGN.md 8 -- hence opt-in)
+  float* d_spec_scratch = nullptr;   // gn_match_spec_kernel: products of every beam, [batch][stride] float4s
+  size_t spec_scratch_cap = 0;       // float4s
+  SpecStats* d_spec_stats = nullptr; // hsm_debug_spec_stats
   bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
   int exact_dense_min = 4096;
   int compute_units = 256;   // of this device (hsm_create)
@@ -599,7 +605,41 @@ int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream
 // reference order, launches that cannot fill the chip with one wavefront per scan (single scans, small batches): one wavefront
 // adds, fifteen produce one round ahead of it (gn_match_exact_dense_kernel, gn_match.h) -- a 16 k-beam match of configs[4] in
 // 0.9 instead of 1.2 ms, the nine chains' own 16 384 x 14 x 8.5 cycles being 0.8
-int launch_match_exact_dense(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+int launch_match_exact_dense(hsm_ctx* h, const MatchParams& P0, int max_n, hipStream_t stream) {
+  MatchParams P = P0;
+  // Round 6, opt-in (HSM_EXACT_SPEC=1): the speculative-carry form (gn_match_spec.h) -- the same sums bit for bit, the chains cut
+  // into segments that run in parallel -- whenever the host knows a true bound of the scan lengths (its product scratch is sized
+  // from it).  The shift rule accepts ~97 % of the segments of real chains, but on ONE CU the form is bound by what it moves
+  // (16 k texel lines + 1.2 MB of products per GN step through one L1) and by a lone workgroup's ~2 us per dependent load: 2.8 ms
+  // per 16 k-beam match against 0.9 for the literal chain below (profiles/r06/README.md).
+  if (h->exact_spec && P.n_bound > 0 && max_n <= P.n_bound) {
+    const size_t stride = spec_scratch_float4s_bound(P.n_bound);  // enough for every n <= n_bound
+    const size_t need = stride * (size_t)P.batch;
+    if (need > h->spec_scratch_cap) {
+      HIP_TRY(hipStreamSynchronize(stream));  // (a launch in flight may still read the old block)
+      if (h->d_spec_scratch) HIP_TRY(hipFree(h->d_spec_scratch));
+      h->d_spec_scratch = nullptr;
+      h->spec_scratch_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->d_spec_scratch, need * sizeof(float4)));
+      h->spec_scratch_cap = need;
+    }
+    P.spec_scratch = h->d_spec_scratch;
+    P.spec_stride = (unsigned)stride;
+    P.spec_stats = h->d_spec_stats;
+    if (h->layout == kLayoutPlane)
+      hipLaunchKernelGGL((gn_match_spec_kernel<kLayoutPlane>), dim3(P.batch), dim3(1024), 0, stream, P);
+    else
+      hipLaunchKernelGGL((gn_match_spec_kernel<kLayoutQuad>), dim3(P.batch), dim3(1024), 0, stream, P);
+    HIP_TRY(hipGetLastError());
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = 16;
+    h->last_cfg[2] = 1024;
+    h->last_cfg[3] = P.batch;
+    h->last_cfg[4] = 0;
+    h->last_cfg[5] = 0;
+    h->last_kernel = "gn_match_spec_kernel";
+    return HSM_OK;
+  }
   if (h->layout == kLayoutPlane)
     hipLaunchKernelGGL((gn_match_exact_dense_kernel<kLayoutPlane>), dim3(P.batch), dim3(1024), 0, stream, P);
   else
@@ -632,7 +672,7 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
       h->exact_cached && h->exact_chain_wave &&
       (max_n <= 17 * 64 || (P.batch > h->compute_units && !(h->exact_dense && max_n >= h->exact_dense_min))))
     wps = 1;
-  if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, stream);
+  if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, max_n, stream);
   switch (wps) {
     case 1: {
       // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
@@ -1080,6 +1120,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_DENSE_BITS")) h->dense_bits = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE")) h->exact_dense = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_SPEC")) h->exact_spec = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE_MIN")) h->exact_dense_min = atoi(env);
   if (const char* env = getenv("HSM_EXACT_CHAIN_WAVE")) h->exact_chain_wave = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SPLIT_TAIL")) h->exact_split_tail = atoi(env);
@@ -1172,6 +1213,8 @@ void hsm_destroy(hsm_ctx* h) {
   if (h->copy_stream) TEARDOWN(log, hipStreamSynchronize(h->copy_stream));
   for (Level& L : h->levels) free_level(L, log);
   TEARDOWN(log, hipFree(h->d_scan));
+  TEARDOWN(log, hipFree(h->d_spec_scratch));
+  TEARDOWN(log, hipFree(h->d_spec_stats));
   TEARDOWN(log, hipFree(h->d_beam_recs));
   TEARDOWN(log, hipFree(h->d_retained));
   TEARDOWN(log, hipFree(h->d_retained_alt));
@@ -1282,7 +1325,7 @@ int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]) {
 
 static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
                                      const int* d_scan_offsets, int shared_n, float* d_out_pose,
-                                     float* d_out_cov, void* stream) {
+                                     float* d_out_cov, void* stream, int n_bound = 0) {
   if (batch < 0 || !d_begin_world || !d_out_pose || (!d_scan_offsets && shared_n < 0))
     return fail(HSM_ERR_INVALID, "hsm_match_batch_device: bad argument");
   if (batch == 0) return HSM_OK;
@@ -1297,6 +1340,8 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   P.shared_n = shared_n;
   P.out_pose = d_out_pose;
   P.out_cov = d_out_cov;
+  // a true bound of the scan lengths, where the host has one: a shared scan's length, or what the caller computed from host offsets
+  P.n_bound = d_scan_offsets ? n_bound : shared_n;
   // workgroup -> XCD mapping (gn_match.h, xcd_block): chunks dealt to the XCDs in turn balance the data-dependent
   // per-scan time; maps whose touched region outgrows the L2s keep one contiguous eighth of the batch per XCD
   P.xcd_chunk = h->levels[0].cells() <= ((size_t)1 << 23) ? h->xcd_chunk : 0;
@@ -1383,7 +1428,7 @@ int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float
     }
   }
   if (int rc = match_batch_device_nolock(h, batch, d_begin, d_pts, d_offs, hint, d_pose,
-                                         out_cov ? d_cov : nullptr, h->stream))
+                                         out_cov ? d_cov : nullptr, h->stream, scan_offsets ? hint : 0))
     return rc;
   HIP_TRY(hipMemcpyAsync(out_pose, d_pose, b_pose, hipMemcpyDeviceToHost, h->stream));
   if (out_cov) HIP_TRY(hipMemcpyAsync(out_cov, d_cov, b_cov, hipMemcpyDeviceToHost, h->stream));
@@ -1436,6 +1481,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.pts = pts;
   P.offsets = nullptr;
   P.shared_n = n;
+  P.n_bound = n;
   P.out_pose = hs_dev + 3;
   P.out_cov = hs_dev + 6;
   P.trace = trace_steps > 0 ? hs_dev + kTraceOff : nullptr;
@@ -1444,6 +1490,7 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.done_seq = seq;
   P.err_flag = reinterpret_cast<unsigned*>(hs_dev + kErrFlagOff);
   P.coop_mute_block = h->coop_mute_block;
+  P.clock_probe = h->clock_probe;
   if (n >= h->coop_min_beams && h->wps_override == 0 && !wants_exact(h)) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
@@ -1533,7 +1580,8 @@ static bool scan_is_read_once(const hsm_ctx* h, int n) {
   if (!wants_exact(h))
     return n <= kMaxRegisterResidentBeams && h->bpl_override != 0 && (n < h->coop_min_beams || h->wps_override != 0);
   const int wps = choose_wps(h, 1, n);
-  if (wps > 1 && h->wps_override == 0 && h->exact_dense && n >= h->exact_dense_min) return n <= 2 * kDenseRound;
+  if (wps > 1 && h->wps_override == 0 && h->exact_dense && n >= h->exact_dense_min)
+    return !h->exact_spec && n <= 2 * kDenseRound;  // (the speculative-carry form re-reads the endpoints in every GN step)
   return n <= kExactGroupRounds * 64 * wps;
 }
 
@@ -2896,6 +2944,24 @@ int hsm_debug_set_coop_mute(hsm_ctx* h, int block_plus_one) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
   std::lock_guard<std::mutex> lk(h->mu);
   h->coop_mute_block = block_plus_one;
+  return HSM_OK;
+}
+
+int hsm_debug_spec_stats(hsm_ctx* h, int enable, unsigned long long out[4]) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (int rc = select_device(h)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (h->d_spec_stats) HIP_TRY(hipMemcpy(out, h->d_spec_stats, sizeof(SpecStats), hipMemcpyDeviceToHost));
+  }
+  if (enable && !h->d_spec_stats) HIP_TRY(hipMalloc((void**)&h->d_spec_stats, sizeof(SpecStats)));
+  if (h->d_spec_stats) HIP_TRY(hipMemset(h->d_spec_stats, 0, sizeof(SpecStats)));
+  if (!enable && h->d_spec_stats) {
+    HIP_TRY(hipFree(h->d_spec_stats));
+    h->d_spec_stats = nullptr;
+  }
   return HSM_OK;
 }
 

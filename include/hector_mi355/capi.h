@@ -386,6 +386,11 @@ int hsm_debug_marks_nonzero(hsm_ctx* h, int level, unsigned long long out[2]);
 /* test hook: set the monotonic arrival counter of the cooperative matcher's grid barrier (it advances by
  * workgroups x GN steps per dense match and wraps at 2^32) */
 int hsm_debug_set_coop_barrier(hsm_ctx* h, unsigned value);
+/* gn_match_spec_kernel (one scan per workgroup, reference order, speculative carries: csrc/spec_chain.h): counters of its
+ * stitching passes since the last call -- out[0] segments settled, [1] unused (0), [2] accepted by the shift rule, [3] re-run
+ * literally.  enable != 0 keeps counting (zeroed by every call), 0 stops.  Results never
+ * depend on these numbers: they only say how fast the exact form ran. */
+int hsm_debug_spec_stats(hsm_ctx* h, int enable, unsigned long long out[4]);
 /* test hook: workgroup `block_plus_one - 1` of the multi-workgroup dense matcher (HSM_PARITY_FAST / _RELAXED, >= 4096 beams)
  * never publishes its partial sums (0 = off) -- the exchange of every workgroup then times out, which is what a device that
  * cannot keep the K workgroups co-resident looks like.  hsm_match handles that by matching the scan again on the

@@ -260,19 +260,25 @@ def test_dense_scan_bit_identical(capi, oracle_mod, pyramid_scene, kind):
 
 
 @pytest.mark.parametrize("layout", ["quad", "plane"])
-def test_dense_scan_producers_ahead_of_the_chain_form(capi, oracle_mod, pyramid_scene, kind, layout, monkeypatch):
-    """round 5: dense scans in the reference's order run gn_match_exact_dense_kernel -- one wavefront adds, fifteen produce
-    one 960-beam round ahead of it.  Same products, same order of the additions as the 16-wavefront team form
-    (HSM_EXACT_DENSE=0): pose, covariance and every hook-trace record bit-identical to it and to the reference, for scan
-    lengths on both sides of the round boundaries (3 .. 19 rounds, ragged last rounds), in the explicit EXACT mode and in the
-    library default; a batch of dense scans takes the same form"""
+def test_dense_scan_forms_are_bit_identical(capi, oracle_mod, pyramid_scene, kind, layout, monkeypatch):
+    """Dense scans in the reference's order, three forms of the same sums:
+      * round 5, the default: gn_match_exact_dense_kernel -- one wavefront adds, fifteen produce one round ahead of it;
+      * round 6, opt-in (HSM_EXACT_SPEC=1): gn_match_spec_kernel -- the nine chains cut into segments that run in parallel from
+        speculated carries, stitched by the exact shift rule, re-run literally where the rule does not apply (csrc/spec_chain.h);
+      * the 16-wavefront team form (HSM_EXACT_DENSE=0).
+    Pose, covariance and every hook-trace record are bit-identical between the three and to the reference, for scan lengths
+    on both sides of the round / segment boundaries, in the explicit EXACT mode and in the library default; a batch of dense
+    scans takes the same form; the stitching counters show that both the shift and the re-run path ran"""
     import ctypes as C
     from hector_slam_amd import synth
     sc = pyramid_scene
     o = make_oracle(oracle_mod, kind, sc)
     lay = capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE
     monkeypatch.setenv("HSM_EXACT_DENSE_MIN", "1920")
+    monkeypatch.setenv("HSM_EXACT_SPEC", "1")
     g = exact_gpu(capi, sc, o, layout=lay)
+    monkeypatch.delenv("HSM_EXACT_SPEC")
+    lit = exact_gpu(capi, sc, o, layout=lay)
     monkeypatch.setenv("HSM_EXACT_DENSE", "0")
     team = exact_gpu(capi, sc, o, layout=lay)
     monkeypatch.delenv("HSM_EXACT_DENSE")
@@ -283,18 +289,22 @@ def test_dense_scan_producers_ahead_of_the_chain_form(capi, oracle_mod, pyramid_
     rng = np.random.default_rng(79)
     lib = capi.load_library()
     scans = []
-    for n_beams in (2561, 2880, 2881, 4096, 5000, 8192, 16384, 17290):  # (up to 2560 beams a single scan runs on 8 wavefronts)
+    g.debug_spec_stats(True)
+    for n_beams in (2561, 2880, 2881, 3584, 3585, 4096, 5000, 8192, 16384, 16385, 17290):  # (up to 2560 beams a single scan runs on 8 wavefronts)
         q = n_beams % 3
         pts = synth.make_scan(sc.world, sc.query_truth[q], n_beams, s, rng, pad_to_full=True)  # exactly n_beams endpoints
         assert pts.shape[0] == n_beams
         scans.append((q, pts))
         pg, cg = g.matchData(sc.query_init[q], pts)
         cfg = g.last_launch_config()
-        assert cfg["kernel"] == "gn_match_exact_dense_kernel" and cfg["block"] == 1024 and cfg["waves_per_scan"] == 16, (n_beams, pts.shape, cfg)
+        assert cfg["kernel"] == "gn_match_spec_kernel" and cfg["block"] == 1024 and cfg["waves_per_scan"] == 16, (n_beams, pts.shape, cfg)
+        pl, cl = lit.matchData(sc.query_init[q], pts)
+        assert lit.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel", lit.last_launch_config()
         pt, ct = team.matchData(sc.query_init[q], pts)
         assert team.last_launch_config()["kernel"].startswith("gn_match_kernel"), team.last_launch_config()
         po, co = o.match(sc.query_init[q], pts)
         assert same(pg, po) and same(cg, co), (n_beams, "vs the reference")
+        assert same(pl, po) and same(cl, co), (n_beams, "literal dense form vs the reference")
         assert same(pg, pt) and same(cg, ct), (n_beams, "vs the team form")
         pa, ca = auto.matchData(sc.query_init[q], pts)
         assert same(pa, po) and same(ca, co), (n_beams, "library default")
@@ -303,31 +313,74 @@ def test_dense_scan_producers_ahead_of_the_chain_form(capi, oracle_mod, pyramid_
         # the hook trace (draw / debug interfaces of the facade): 14 records, each the reference's step
         a = np.ascontiguousarray(pts, np.float32)
         tr = {}
-        for name, ctx in (("dense", g), ("team", team)):
+        for name, ctx in (("spec", g), ("literal", lit), ("team", team)):
             pose, cov, trace, nst = np.zeros(3, np.float32), np.zeros(9, np.float32), np.zeros(14 * 12, np.float32), C.c_int(0)
             capi._check(lib.hsm_match_trace(ctx._h, sc.query_init[q], a.ctypes.data, a.shape[0], np.zeros(2, np.float32), pose, cov, trace, 14,
                                             C.byref(nst)), "hsm_match_trace")
             assert nst.value == 14 and same(pose, po) and same(cov, co), (name, n_beams)
             tr[name] = trace
-        assert same(tr["dense"], tr["team"]), n_beams
+        assert same(tr["spec"], tr["team"]) and same(tr["literal"], tr["team"]), n_beams
+    walked, exact, shifted, rerun = g.debug_spec_stats(False)
+    assert walked > 0 and shifted + rerun == walked and shifted > 0 and rerun > 0, (walked, exact, shifted, rerun)
+    assert shifted / walked > 0.8, (walked, shifted, rerun)  # real chains: 10-16 re-runs per chain of 55-512 segments (tools/study/spec_chain_stats.py)
     # single-level matchData (ScanMatcher::matchData with an explicit iteration count) on a dense scan, library default
     q, pts = scans[-2]
     lvl_pts = pts * np.float32(0.5)
-    pl, cl = auto.match_level(1, sc.query_init[q], lvl_pts, 7)
-    assert auto.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel"
     pol, col = o.match_level(1, sc.query_init[q], lvl_pts, 7)
-    assert same(pl, pol) and same(cl, col), "single-level dense match"
-    # a batch of dense scans: one workgroup per scan
-    sel = [sc_ for sc_ in scans if sc_[1].shape[0] >= 4000][:4]
+    for ctx, name in ((auto, "gn_match_exact_dense_kernel"), (g, "gn_match_spec_kernel")):
+        pl, cl = ctx.match_level(1, sc.query_init[q], lvl_pts, 7)
+        assert ctx.last_launch_config()["kernel"] == name
+        assert same(pl, pol) and same(cl, col), ("single-level dense match", name)
+    # a batch of dense scans (ragged lengths, host offsets: the bound of the lengths is known): one workgroup per scan
+    sel = [sc_ for sc_ in scans if sc_[1].shape[0] >= 4000][:5]
     pts, offs = synth.pack_scans([p for _, p in sel])
     init = np.stack([sc.query_init[q] for q, _ in sel])
-    pb, cb = g.match_batch(init, pts, offs)
-    assert g.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel" and g.last_launch_config()["grid"] == len(sel)
-    for k, (q, p) in enumerate(sel):
-        po, co = o.match(sc.query_init[q], p)
-        assert same(pb[k], po) and same(cb[k], co), k
-    for ctx in (g, team, auto):
+    for ctx, name in ((g, "gn_match_spec_kernel"), (lit, "gn_match_exact_dense_kernel")):
+        pb, cb = ctx.match_batch(init, pts, offs)
+        assert ctx.last_launch_config()["kernel"] == name and ctx.last_launch_config()["grid"] == len(sel)
+        for k, (q, p) in enumerate(sel):
+            po, co = o.match(sc.query_init[q], p)
+            assert same(pb[k], po) and same(cb[k], co), (name, k)
+    # device-resident CSR offsets: the lengths are not known to the host, the shared_n argument is only a hint -- the form whose
+    # scratch is sized from a bound is not taken
+    import torch
+    d_init, d_pts, d_offs = (torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (init, pts, offs))
+    d_pose = torch.zeros((len(sel), 3), dtype=torch.float32, device="cuda")
+    g.match_batch_device(len(sel), d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 4096, d_pose.data_ptr(), 0, 0)
+    g.synchronize()
+    assert g.last_launch_config()["kernel"] == "gn_match_exact_dense_kernel"
+    assert same(d_pose.cpu().numpy(), pb)
+    for ctx in (g, lit, team, auto):
         ctx.close()
+
+
+def test_speculative_carry_form_on_short_scans_and_many_poses(capi, oracle_mod, pyramid_scene, kind, monkeypatch):
+    """the same form forced onto the node's scan lengths (HSM_EXACT_DENSE_MIN=128: segments of 32 beams) over every query
+    scan from near and far starts: bit-identical to the reference -- the shift rule is exact, whatever the data"""
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    monkeypatch.setenv("HSM_EXACT_DENSE_MIN", "128")
+    monkeypatch.setenv("HSM_EXACT_SPEC", "1")
+    g = exact_gpu(capi, sc, o)
+    rng = np.random.default_rng(5)
+    n = 0
+    for q in range(len(sc.query_scans)):
+        for k in range(4):
+            init = sc.query_init[q].copy()  # (starts the reference itself survives: it indexes the grid with (int)NaN once it diverges)
+            init[:2] += rng.uniform(-0.1, 0.1, 2).astype(np.float32) * np.float32(k)
+            init[2] += np.float32(rng.uniform(-0.04, 0.04) * k)
+            pts = sc.query_scans[q][: [len(sc.query_scans[q]), 720, 361, 130][k]]
+            pg, cg = g.matchData(init, pts)
+            if len(pts) >= 320:  # (shorter scans run on fewer wavefronts: the team form)
+                assert g.last_launch_config()["kernel"] == "gn_match_spec_kernel", (len(pts), g.last_launch_config())
+                n += 1
+            po, co = o.match(init, pts)
+            if np.isnan(po).any():  # the reference's own iteration diverged (a far start on few beams): NaN payloads are not pinned
+                assert np.array_equal(np.isnan(pg), np.isnan(po)), (q, k)
+                continue
+            assert same(pg, po) and same(cg, co), (q, k)
+    assert n >= 2 * len(sc.query_scans)
+    g.close()
 
 
 def test_slam_loop_from_empty_map_bit_identical(capi, oracle_mod, pyramid_scene, kind):
