@@ -206,26 +206,43 @@ public:
       return;
     }
     std::vector<float> begin(3 * static_cast<size_t>(B)), pose(3 * static_cast<size_t>(B)), cov;
-    std::vector<int> offsets(static_cast<size_t>(B) + 1, 0);
+    bool shared = true;  // every hypothesis looks at the same container: the particle-filter case
     for (int i = 0; i < B; ++i) {
-      offsets[i + 1] = offsets[i] + scans[i]->getSize();
+      shared = shared && scans[i] == scans[0];
       for (int k = 0; k < 3; ++k) {
         begin[3 * i + k] = beginEstimatesWorld[i][k];
-      }
-    }
-    std::vector<float> pts(2 * static_cast<size_t>(offsets[B]));
-    for (int i = 0; i < B; ++i) {
-      const int n = scans[i]->getSize();
-      for (int j = 0; j < n; ++j) {
-        const Eigen::Vector2f& p = scans[i]->getVecEntry(j);
-        pts[2 * (static_cast<size_t>(offsets[i]) + j)] = p[0];
-        pts[2 * (static_cast<size_t>(offsets[i]) + j) + 1] = p[1];
       }
     }
     if (covOut) {
       cov.assign(9 * static_cast<size_t>(B), 0.0f);
     }
-    hsm_match_batch(ctx, B, &begin[0], pts.empty() ? 0 : &pts[0], &offsets[0], 0, &pose[0], covOut ? &cov[0] : 0);
+    if (shared) {
+      // ONE scan travels (hsm_match_batch with scan_offsets == NULL: the start poses and the results cross PCIe once each, the
+      // scan is copied once) -- not B copies of it packed into a CSR array
+      const int n = scans[0]->getSize();
+      std::vector<float> pts(2 * static_cast<size_t>(n));
+      for (int j = 0; j < n; ++j) {
+        const Eigen::Vector2f& p = scans[0]->getVecEntry(j);
+        pts[2 * static_cast<size_t>(j)] = p[0];
+        pts[2 * static_cast<size_t>(j) + 1] = p[1];
+      }
+      hsm_match_batch(ctx, B, &begin[0], pts.empty() ? 0 : &pts[0], 0, n, &pose[0], covOut ? &cov[0] : 0);
+    } else {
+      std::vector<int> offsets(static_cast<size_t>(B) + 1, 0);
+      for (int i = 0; i < B; ++i) {
+        offsets[i + 1] = offsets[i] + scans[i]->getSize();
+      }
+      std::vector<float> pts(2 * static_cast<size_t>(offsets[B]));
+      for (int i = 0; i < B; ++i) {
+        const int n = scans[i]->getSize();
+        for (int j = 0; j < n; ++j) {
+          const Eigen::Vector2f& p = scans[i]->getVecEntry(j);
+          pts[2 * (static_cast<size_t>(offsets[i]) + j)] = p[0];
+          pts[2 * (static_cast<size_t>(offsets[i]) + j) + 1] = p[1];
+        }
+      }
+      hsm_match_batch(ctx, B, &begin[0], pts.empty() ? 0 : &pts[0], &offsets[0], 0, &pose[0], covOut ? &cov[0] : 0);
+    }
     for (int i = 0; i < B; ++i) {
       posesOut[i] = Eigen::Vector3f(pose[3 * i], pose[3 * i + 1], pose[3 * i + 2]);
     }

@@ -185,6 +185,52 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < poses.size(); ++k)
       for (int j = 0; j < 3; ++j) wr(out, poses[k][j]);
   }
+  // hypotheses phase (SLAM_DRIVER_HYPOTHESES=N, e.g. 4096: BASELINE configs[2]'s particle-filter-style use): N start estimates
+  // around the last pose, all looking at the LAST scan.  Reference build: N matchData calls; MI355X build: ONE matchDataBatch whose
+  // N container pointers are the same container.  The poses go to a file of their own (SLAM_DRIVER_HYP_OUT), the time of the call
+  // (median of 7 repetitions after 2 warm-up calls on the MI355X build; one pass on the reference) to SLAM_DRIVER_HYP_TIMING.
+  if (const char* hn = getenv("SLAM_DRIVER_HYPOTHESES")) {
+    const int N = atoi(hn);
+    if (N > 0 && !kept.empty()) {
+      const size_t logMark = g_log.size();
+      const hectorslam::DataContainer& last = kept.back();
+      std::vector<Eigen::Vector3f> hints((size_t)N), poses((size_t)N);
+      unsigned lcg = 12345u;
+      auto uni = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xffffu) / 65535.0f * 2.0f - 1.0f; };
+      for (int k = 0; k < N; ++k) {
+        const float dx = uni(), dy = uni(), dth = uni();
+        hints[(size_t)k] = keptPose.back() + Eigen::Vector3f(0.30f * dx, 0.30f * dy, 0.10f * dth);
+      }
+      std::vector<double> call_us;
+#ifdef HECTOR_MI355_CAPI_H
+      std::vector<const hectorslam::DataContainer*> ptrs((size_t)N, &last);
+      for (int rep = 0; rep < 9; ++rep) {
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        static_cast<hectorslam::MapRepMultiMap*>(slam->rep())->matchDataBatch(hints, ptrs, poses);
+        if (rep >= 2) call_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+      }
+#else
+      Eigen::Matrix3f cov;
+      const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < N; ++k) poses[(size_t)k] = slam->rep()->matchData(hints[(size_t)k], last, cov);
+      call_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+#endif
+      g_log.resize(logMark);
+      if (const char* ho = getenv("SLAM_DRIVER_HYP_OUT"))
+        if (FILE* hf = fopen(ho, "wb")) {
+          for (int k = 0; k < N; ++k)
+            for (int j = 0; j < 3; ++j) wr(hf, poses[(size_t)k][j]);
+          fclose(hf);
+        }
+      if (const char* ht = getenv("SLAM_DRIVER_HYP_TIMING"))
+        if (FILE* tf = fopen(ht, "w")) {
+          std::sort(call_us.begin(), call_us.end());
+          fprintf(tf, "{\"hypotheses\": %d, \"beams\": %d, \"median_us_all_hypotheses\": %.2f, \"min_us\": %.2f, \"repetitions\": %zu}\n", N,
+                  last.getSize(), call_us[call_us.size() / 2], call_us[0], call_us.size());
+          fclose(tf);
+        }
+    }
+  }
   wr(out, (int)g_log.size());
   if (!g_log.empty()) fwrite(&g_log[0], sizeof(float), g_log.size(), out);
   wr(out, (int)locker->locks.load());
