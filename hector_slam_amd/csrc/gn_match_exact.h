@@ -36,8 +36,15 @@ namespace hsm {
 
 constexpr int kXRow = 64 + kExactPad;  // floats per staged row: 16-byte aligned rows, chain lanes on distinct banks
 
+#ifndef HSM_XEARLY  // round 6: wavefronts run ahead of the round barriers so that the owner's interval holds only the job --
+                    // 2 = the balanced schedule (3 / 3 / 2 half-rows + job), 1 = the next owner produces two rows, 0 = round 3's schedule
+#define HSM_XEARLY 2
+#endif
 #ifndef HSM_XBPC  // cached rows of the 17-row instantiation (see the kernel)
 #define HSM_XBPC 15
+#endif
+#ifndef HSM_XBPC_MAIN  // ... of the four-producer form without a chain wavefront (the 4096-scan launch): the balanced schedule holds
+#define HSM_XBPC_MAIN (HSM_XEARLY == 2 ? 13 : HSM_XBPC)  // a row's nine products across a barrier, which 15 cached rows do not leave room for
 #endif
 #ifndef HSM_XBPC_CW  // ... of the chain-wavefront form (five wavefronts per SIMD: 96 VGPRs)
 #define HSM_XBPC_CW 6
@@ -81,6 +88,30 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
 // (With at most TWO such workgroups per CU the second one fits at four wavefronts per SIMD as well -- 2/1/1/1 leaves two slots
 // everywhere --, so launches of up to 2 x CUs workgroups take an instantiation with the full texel cache at 128 VGPRs: what a
 // map that outgrows the L2s needs.)
+// -DHSM_XTIMELINE (variant builds only: tools/study/exact_timeline.py): workgroup 0 stamps s_memtime at every round's barrier
+// (arrival, release) and job end, per wavefront, into MatchParams::clock_probe [wave][row][4]; the last GN step's stamps stay
+#ifdef HSM_XTIMELINE
+#define HSM_XT(row, slot)                                                                                            \
+  do {                                                                                                               \
+    if (P.clock_probe != nullptr && blockIdx.x == 0 && lane == 0)                                                    \
+      P.clock_probe[((size_t)wave * BPL + (size_t)(row)) * 4 + (slot)] = (unsigned long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define HSM_XT(row, slot) \
+  do {                    \
+  } while (0)
+#endif
+
+#ifndef HSM_XWGPRIO  // issue priority of a workgroup's producers by its dispatch order on the CU (blockIdx >> 8): the hardware arbitrates
+#define HSM_XWGPRIO 3  // by priority, then AGE, so the workgroup dispatched last to a CU loses every tie and ends last (profiles/r06).
+#endif                 // 0 = off; 1 = priority = order; 2 = (order + GN step) & 3: every workgroup is favoured in some steps; 3 = min(order, 2)
+__device__ __forceinline__ void set_prio_uniform(int p) {  // s_setprio takes an immediate
+  if (p <= 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+
 template <int NS, int BPL, int BPC = BPL, bool CW = false>
 __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <= 96 ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
@@ -186,6 +217,16 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     }
     return;
   }
+#ifdef HSM_XTIMELINE_WG  // (variant builds: start / end wall clock (100 MHz) and XCC id of every workgroup, [block][4] behind the other stamps)
+  if (P.clock_probe != nullptr && wave == 0 && lane == 0) {
+    P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 0] = wall_clock64();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
   const float2* __restrict__ pts = P.pts + (n > 0 ? beg : 0);  // an empty scan's loads (clamped to element 0) stay inside the array
   f2(*mine)[64] = lds_pts[wave];
   f2 pv[RV > 0 ? RV : 1];
@@ -246,6 +287,10 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     // one GN step; FIRST = the peeled step (compile-time)
     auto gn_step = [&](auto FIRST) {
       constexpr bool kFirst = decltype(FIRST)::value;
+#ifdef HSM_XTIMELINE_STEPS  // (variant builds: one stamp per GN step of workgroup 0's first wavefront, behind the per-round stamps' block)
+      if (P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0 && step_no < 32)
+        P.clock_probe[(size_t)4 * 31 * 4 + step_no] = (unsigned long long)__builtin_readcyclecounter();
+#endif
       f2 pq[kFirst ? BPL : 1];  // the peeled step's endpoint load registers
       auto endpoint_issue = [&](int k) {
         int i = max(min((int)lane_id_now() + 64 * k, n - 1), 0);
@@ -350,22 +395,34 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
       // the four staged values of one beam (OccGridMapUtil.h:332-346 and :80-87), with the source's signs:
       //   gx = -((P00-P10)*xFacInv + (P01-P11)*fx) == (P10-P00)*xFacInv + (P11-P01)*fx   (negation commutes with rounding)
       //   rotDeriv = (-ry)*gx + rx*gy == rx*gy - ry*gx,  (rx, ry) = R(theta) p shared with the transform (gn_match.h)
-      auto produce = [&](int k, float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy) {
-        const int buf = k % NB;
+      // the nine products of :83-97, one rounding each like the reference's; the chain lane only adds
+      // (in two halves: the four terms of a beam -- gx, gy, funVal, rotDeriv -- are what a wavefront that runs ahead of a barrier keeps
+      // in registers; the nine products are formed from them when the row is staged)
+      auto beam_terms4 = [&](float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy, float (&tm)[4]) {
         const float xFacInv = 1.0f - fx, yFacInv = 1.0f - fy;
         const float M = ((i0 * xFacInv + i1 * fx) * (yFacInv)) + ((i2 * xFacInv + i3 * fx) * (fy));
-        const float gx = ((i1 - i0) * xFacInv) + ((i3 - i2) * fx);
-        const float gy = ((i2 - i0) * yFacInv) + ((i3 - i1) * fy);
-        const float funVal = 1.0f - M;
-        const float rotDeriv = r.r.x * gy - r.r.y * gx;
-        // lane l at row + 4 l: ds_write_addtid_b32 (address = M0 + offset + 4 * lane) needs no address VGPR and half the LDS
-        // cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).  M0 is reserved, not allocatable: nothing else in this kernel
-        // uses it (gfx9+ DS operations do not)
+        tm[0] = ((i1 - i0) * xFacInv) + ((i3 - i2) * fx);  // gx
+        tm[1] = ((i2 - i0) * yFacInv) + ((i3 - i1) * fy);  // gy
+        tm[2] = 1.0f - M;                                  // funVal
+        tm[3] = r.r.x * tm[1] - r.r.y * tm[0];             // rotDeriv
+      };
+      auto products_of = [&](const float (&tm)[4], float (&pp)[9]) {
+        const float gx = tm[0], gy = tm[1], funVal = tm[2], rotDeriv = tm[3];
+        pp[0] = gx * funVal, pp[1] = gy * funVal, pp[2] = rotDeriv * funVal;
+        pp[3] = gx * gx, pp[4] = gy * gy, pp[5] = rotDeriv * rotDeriv;
+        pp[6] = gx * gy, pp[7] = gx * rotDeriv, pp[8] = gy * rotDeriv;
+      };
+      auto products = [&](float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy, float (&pp)[9]) {
+        float tm[4];
+        beam_terms4(i0, i1, i2, i3, r, fx, fy, tm);
+        products_of(tm, pp);
+      };
+      // lane l at row + 4 l: ds_write_addtid_b32 (address = M0 + offset + 4 * lane) needs no address VGPR and half the LDS
+      // cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).  M0 is reserved, not allocatable: nothing else in this kernel
+      // uses it (gfx9+ DS operations do not)
+      auto stage_write = [&](int k, const float (&pp)[9]) {
+        const int buf = k % NB;
         const unsigned m0v = st_wave + (unsigned)buf * (NS * kXRows * kXRow * 4);
-        // the nine products of :83-97, one rounding each like the reference's; the chain lane only adds
-        const float p0 = gx * funVal, p1 = gy * funVal, p2 = rotDeriv * funVal;
-        const float p3 = gx * gx, p4 = gy * gy, p5 = rotDeriv * rotDeriv;
-        const float p6 = gx * gy, p7 = gx * rotDeriv, p8 = gy * rotDeriv;
         asm volatile(
             "s_mov_b32 m0, %[m]\n\t"
             "s_nop 0\n\t"
@@ -379,11 +436,19 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
             "ds_write_addtid_b32 %[p7] offset:%[o7]\n\t"
             "ds_write_addtid_b32 %[p8] offset:%[o8]"
             :
-            : [m] "s"(m0v), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6),
-              [p7] "v"(p7), [p8] "v"(p8), [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4),
+            : [m] "s"(m0v), [p0] "v"(pp[0]), [p1] "v"(pp[1]), [p2] "v"(pp[2]), [p3] "v"(pp[3]), [p4] "v"(pp[4]), [p5] "v"(pp[5]), [p6] "v"(pp[6]),
+              [p7] "v"(pp[7]), [p8] "v"(pp[8]), [o0] "n"(0 * kXRow * 4), [o1] "n"(1 * kXRow * 4), [o2] "n"(2 * kXRow * 4),
               [o3] "n"(3 * kXRow * 4), [o4] "n"(4 * kXRow * 4), [o5] "n"(5 * kXRow * 4), [o6] "n"(6 * kXRow * 4),
               [o7] "n"(7 * kXRow * 4), [o8] "n"(8 * kXRow * 4)
             : "memory");
+      };
+      // the four staged values of one beam (OccGridMapUtil.h:332-346 and :80-87), with the source's signs:
+      //   gx = -((P00-P10)*xFacInv + (P01-P11)*fx) == (P10-P00)*xFacInv + (P11-P01)*fx   (negation commutes with rounding)
+      //   rotDeriv = (-ry)*gx + rx*gy == rx*gy - ry*gx,  (rx, ry) = R(theta) p shared with the transform (gn_match.h)
+      auto produce = [&](int k, float i0, float i1, float i2, float i3, const BeamRot& r, float fx, float fy) {
+        float pp[9];
+        products(i0, i1, i2, i3, r, fx, fy, pp);
+        stage_write(k, pp);
       };
       // one chain job: lane l runs unit u = 64 j + l = (round ku, chain c): 64 dependent additions on top of the chain's
       // running sum.  The chain's row streams through two 32-byte halves (16 VGPRs): a half is refilled right after its
@@ -424,12 +489,17 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
           runs[c] = run;
         }
       };
+      const int wg_order = (int)((blockIdx.x >> 8) & 3u);
+      const int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
+      if (HSM_XWGPRIO != 0 && !CW) set_prio_uniform(wg_prio);
       // round k is staged: meet, then (one wavefront) run the chain jobs that are complete with it
       const int my_rounds =
           __builtin_amdgcn_readfirstlane((int)((unsigned)(wave + 64 * NS - (step_no + owner_phase) % NS) % (unsigned)NS));
       auto round_done = [&](int k, bool last_round) {
         if (HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
+        if (k < BPL) HSM_XT(k, 0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (k < BPL) HSM_XT(k, 1);
         if (CW) return;  // the chain wavefront runs the job
         const int j_lo = (k * NCP) >> 6;
         const int j_hi = last_round ? (units + 63) >> 6 : ((k + 1) * NCP) >> 6;
@@ -451,12 +521,20 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
 #endif
         for (int j = j_lo; j < j_hi; ++j) chain_job(j, k);
         __builtin_amdgcn_s_setprio(HSM_XOWNER_PRIO_P);
+        if (k < BPL) HSM_XT(k, 2);
       };
       {
         BeamRot rc, rn;
         float fxc, fyc, fxn = 0.0f, fyn = 0.0f;
         unsigned long long next_moved = 0ull;
         constexpr bool kAhead = HSM_XLDS_AHEAD != 0 && !kFirst;
+        // (the first, peeled step keeps the rotating-owner schedule: measured slower with either early form -- all lanes gather, the
+        // endpoints stream from HBM, its waits are counted from a static issue order)
+#ifndef HSM_XEARLY_FIRST
+#define HSM_XEARLY_FIRST 0
+#endif
+        constexpr bool kBalanced = HSM_XEARLY == 2 && !CW && NCP == 64 && (!kFirst || HSM_XEARLY_FIRST != 0);
+        constexpr bool kEarly = HSM_XEARLY == 1 && !CW && NCP == 64 && !kFirst;
         f2 p_next = f2{0.0f, 0.0f};
         if (kAhead) p_next = endpoint(BPL > 1 ? 1 : 0);
         locate(0, endpoint(0), rc, fxc, fyc);
@@ -473,12 +551,102 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
 #if defined(HSM_EXPERIMENTS) && defined(HSM_XWHATIF) && HSM_XWHATIF == 2  // timing experiment: a second workgroup barrier per round
           asm volatile("s_barrier" ::: "memory");
 #endif
-          texel_ready(k, next_moved, k + 1 < BPL);
-          {
+          if (kBalanced) {
+            // Round 6.  Where a round's time went (profiles/r06/README.md: s_memtime per round): the owner of round k's job ran it behind
+            // barrier k and THEN produced its row k+1 -- job (~700 cycles) + production (~500) on every round's critical path, three
+            // wavefronts parked at barrier k+1 meanwhile (SQ_WAIT_ANY 0.53 of the wavefront cycles).  Now a wavefront runs AHEAD of
+            // the barriers by up to one row -- the products of a row that is early wait in nine registers until the barrier that
+            // frees its stage buffer -- on a schedule that gives the owner's interval nothing but the job and spreads its four
+            // productions over the other three: with o = (k - own round) mod 4, a = locate row k+1, b = products of row k,
+            //   o = 3: a | barrier k-1 | b, stage          o = 0: a, b (held) | barrier k-1 | stage
+            //   o = 1: a, b (held) | barrier k-1 | stage, JOB k-1 | barrier k          o = 2: a, b, stage (no barrier)
+            // i.e. intervals of 3, 3, 2 half-rows and the job.  Every wavefront still meets each round's barrier exactly once, in
+            // order; same products, same order of the additions: identical bits.
+            int mine_now = my_rounds;
+            asm volatile("" : "+s"(mine_now));  // (compared afresh in an SGPR at every round: see round_done)
+            const int o = (int)((unsigned)(k + NS - mine_now) % (unsigned)NS);
+            if (o == 3 && k >= 1) {
+              if (HSM_XWGPRIO == 0 && HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            texel_ready(k, next_moved, k + 1 < BPL);
             const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
-            produce(k, tx.x, tx.y, tx.z, tx.w, rc, fxc, fyc);
+            float pp[9];
+            products(tx.x, tx.y, tx.z, tx.w, rc, fxc, fyc, pp);
+            if (o >= 2 || k == 0) {
+              stage_write(k, pp);
+              if (k == 0 && o == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (no job -1 to run)
+            } else {  // o = 0, 1 with k >= 1: the products wait for barrier k-1
+              if (HSM_XWGPRIO == 0 && HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              stage_write(k, pp);
+              if (o == 1) {
+                __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+                chain_job(k - 1, k - 1);
+                if (HSM_XWGPRIO != 0) set_prio_uniform(wg_prio); else __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              }
+            }
+            if (k == BPL - 1 && o != 1) {  // the barrier of the last cached row (o = 1 has met it), and its job
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              if (o == 0) {
+                __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+                chain_job(k, k);
+                if (HSM_XWGPRIO != 0) set_prio_uniform(wg_prio); else __builtin_amdgcn_s_setprio(0);
+              }
+            }
+          } else if (kEarly) {
+            texel_ready(k, next_moved, k + 1 < BPL);
+            // Round 6.  The owner of round k's job used to run it behind barrier k and THEN produce its row k+1 -- job + production
+            // on every round's critical path, three wavefronts parked at barrier k+1 meanwhile (SQ_WAIT_ANY 0.53 of the wavefront
+            // cycles, profiles/r06/stall_table.txt).  Now the owner-to-be produces row k+1 BEFORE barrier k (its products wait in nine
+            // registers: stage buffer (k+1) % 2 is still being read by job k-1), so behind barrier k it only stages them and runs
+            // the job: an interval lasts max(job, two productions) instead of job + production.  Every wavefront still meets
+            // exactly one barrier per round; same products, same order of the additions.
+            const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
+            float pp[9];
+            products(tx.x, tx.y, tx.z, tx.w, rc, fxc, fyc, pp);
+            int mine_now = my_rounds;
+            asm volatile("" : "+s"(mine_now));  // (compared afresh in an SGPR at every round: see round_done)
+            const bool own_k = (int)((unsigned)k % (unsigned)NS) == mine_now;
+            const bool own_km1 = k >= 1 && (int)((unsigned)(k + NS - 1) % (unsigned)NS) == mine_now;
+            if (own_km1) {  // row k was produced early: barrier k-1, stage it, job k-1, barrier k
+              if (HSM_XOWNER_PRIO_P != 0) __builtin_amdgcn_s_setprio(0);
+              HSM_XT(k - 1, 0);
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              HSM_XT(k - 1, 1);
+              stage_write(k, pp);
+              __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+              chain_job(k - 1, k - 1);
+              __builtin_amdgcn_s_setprio(0);
+              HSM_XT(k - 1, 2);
+              HSM_XT(k, 0);
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              HSM_XT(k, 1);
+            } else {
+              stage_write(k, pp);
+              if (own_k && k + 1 < BPL) {
+                __builtin_amdgcn_s_setprio(HSM_XOWNER_PRIO_P);  // no barrier here: this wavefront produces row k+1 first
+              } else {
+                HSM_XT(k, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                HSM_XT(k, 1);
+                if (own_k) {  // the last cached row is this wavefront's: nothing to produce ahead
+                  __builtin_amdgcn_s_setprio(HSM_XJOB_PRIO);
+                  chain_job(k, k);
+                  __builtin_amdgcn_s_setprio(0);
+                  HSM_XT(k, 2);
+                }
+              }
+            }
+          } else {
+            texel_ready(k, next_moved, k + 1 < BPL);
+            {
+              const f4v& tx = k < BPC ? tq[k < BPC ? k : 0] : tu[k & 1];
+              produce(k, tx.x, tx.y, tx.z, tx.w, rc, fxc, fyc);
+            }
+            round_done(k, k == BPL - 1 && rounds == BPL);
           }
-          round_done(k, k == BPL - 1 && rounds == BPL);
           rc = rn;
           fxc = fxn;
           fyc = fyn;
@@ -517,6 +685,13 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
   }
+#ifdef HSM_XTIMELINE_STEPS
+  if (P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0 && step_no < 32)
+    P.clock_probe[(size_t)4 * 31 * 4 + step_no] = (unsigned long long)__builtin_readcyclecounter();
+#endif
+#ifdef HSM_XTIMELINE_WG
+  if (P.clock_probe != nullptr && wave == 0 && lane == 0) P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 1] = wall_clock64();
+#endif
   if (active && lane == 0) {
     const bool empty = n == 0;
     P.out_pose[3 * scan + 0] = empty ? b0 : pw0;

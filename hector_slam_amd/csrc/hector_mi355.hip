@@ -481,7 +481,7 @@ int launch_match_exact_cached_forms(hsm_ctx* h, const MatchParams& P, int max_n,
   }
   if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
   if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
-  return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
+  return launch_match_exact_cached<4, 17, HSM_XBPC_MAIN>(h, P, stream);
 }
 
 template <int WPS, int SPB>

@@ -159,7 +159,7 @@ def test_no_register_of_an_inflight_gather_is_touched(device_asm):
     assert len(names) >= 17, names
     for need in ("gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1E", "gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0E",
                  "gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi2ELi1ELb0E",
-                 "gn_match_exact_cached_kernelILi4ELi17ELi15ELb0E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb0E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb0E",
+                 "gn_match_exact_cached_kernelILi4ELi17ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb0E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb0E",
                  "gn_match_exact_cached_kernelILi4ELi13ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi13ELi7ELb1E",
                  "gn_match_exact_cached_kernelILi4ELi13ELi13ELb1E", "gn_match_exact_cached_kernelILi4ELi17ELi15ELb1E",
                  "gn_match_exact_cached_kernelILi4ELi17ELi6ELb1E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb1E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb1E"):
@@ -232,5 +232,5 @@ def test_every_matcher_instantiation_reaches_its_designed_occupancy(device_asm):
     assert seen >= 80, seen  # the team forms (6 widths x 2 layouts x BPL), the texel-cache forms, the exact forms, the dense matcher
     # the forms the default mode launches: exact single scan on four wavefronts, the exact batch form, the exact dense team
     for need in ("15gn_match_kernelILi4ELi1ELi1ELi0ELb1E", "15gn_match_kernelILi4ELi1ELi2ELi0ELb1E", "15gn_match_kernelILi16ELi1ELi2ELi0ELb1E",
-                 "28gn_match_exact_cached_kernelILi4ELi17ELi15E"):
+                 "28gn_match_exact_cached_kernelILi4ELi17ELi13ELb0E"):
         assert any(need in n for n in occ), need
