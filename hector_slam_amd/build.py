@@ -29,8 +29,11 @@ def _c(*names):
 
 
 # translation unit -> the files it includes (its own staleness test)
+_COMMON = _c("gn_match.h", "libm_exact.h", "hsm_host.h", "hsm_ctx.h") + [_CAPI]
 UNITS = {
-    "hector_mi355.hip": _c("hector_mi355.hip", "gn_match.h", "gn_match_exact.h", "map_update.h", "libm_exact.h", "hsm_host.h") + [_CAPI],
+    "hector_mi355.hip": _c("hector_mi355.hip", "gn_match_spec.h", "spec_chain.h", "map_update.h") + _COMMON,
+    "match_exact_cached.hip": _c("match_exact_cached.hip", "gn_match_exact.h") + _COMMON,
+    "match_teams.hip": _c("match_teams.hip") + _COMMON,
     "pose_exchange.hip": _c("pose_exchange.hip", "pose_exchange.h", "hsm_host.h") + [_CAPI],
 }
 SRC = os.path.join(_CSRC, "hector_mi355.hip")

@@ -2174,12 +2174,4 @@ __global__ void __launch_bounds__(448) pose_covariance_kernel(const LevelView L,
   }
 }
 
-// device sin/cos sweep for the parity tests
-__global__ void sincos_debug_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
-                                    float* __restrict__ c) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  sincos_f32(x[i], s[i], c[i]);
-}
-
 }  // namespace hsm

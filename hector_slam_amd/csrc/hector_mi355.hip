@@ -1,5 +1,6 @@
 // hector_mi355.hip -- host runtime + C ABI (include/hector_mi355/capi.h) of the
-// MI355X-native hector_mapping scan matcher.  Kernels: gn_match.h, map_update.h.
+// MI355X-native hector_mapping scan matcher.  Kernels: gn_match.h, map_update.h; the batch / team matcher forms are
+// launched from match_exact_cached.hip and match_teams.hip (hsm_ctx.h says which unit holds what).
 //
 // The context mirrors hectorslam::MapRepMultiMap (HSL/slam_main/MapRepMultiMap.h): a
 // pyramid of levels, each with its grid (log-odds + update stamps), its world<->map
@@ -47,19 +48,34 @@ ncclResult_t ncclGetVersion(int* version);
 #include <vector>
 
 #include "gn_match.h"
-#include "gn_match_exact.h"
 #include "gn_match_spec.h"
 #include "hector_mi355/capi.h"
+#include "hsm_ctx.h"
 #include "hsm_host.h"
 #include "map_update.h"
+
+namespace hsm {
+// device sin/cos sweep for the parity tests
+__global__ void sincos_debug_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
+                                    float* __restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sincos_f32(x[i], s[i], c[i]);
+}
+
+}  // namespace hsm
 
 namespace {
 
 using namespace hsm;
+using namespace hsm_host;
 
 thread_local std::string g_last_error;
 
-int fail(int code, const char* what, hipError_t e = hipSuccess) {
+}  // namespace
+
+// every object of the library reports through this per-thread text (hsm_host.h)
+int hsm_host::fail(int code, const char* what, hipError_t e) {
   char buf[512];
   if (e != hipSuccess)
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
@@ -69,11 +85,6 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
   return code;
 }
 
-}  // namespace
-
-// the other objects of the library report through the same per-thread text (hsm_host.h)
-int hsm_host::fail(int code, const char* what, hipError_t e) { return ::fail(code, what, e); }
-
 namespace {
 
 #define HIP_TRY(expr)                                         \
@@ -82,167 +93,8 @@ namespace {
     if (e__ != hipSuccess) return fail(HSM_ERR_HIP, #expr, e__); \
   } while (0)
 
-// d_small / h_small layout (floats): [0,3) begin pose | [3,6) out pose | [6,15) out cov |
-// [16,28) eval H,dTr | [kTraceOff, kTraceOff + 12 * max steps) per-step trace
-constexpr int kTraceOff = 64;
-constexpr int kDoneFlagOff = 32;  // one word of the pinned block: single-scan completion sequence number
-constexpr int kErrFlagOff = 33;   // the next word: receives that number when the cooperative matcher's exchange timed out
-constexpr int kMaxTraceSteps = 6 + 4 * (HSM_MAX_LEVELS - 1);
-constexpr int kSmallFloats = kTraceOff + 12 * kMaxTraceSteps;
-
-struct Level {
-  int sx = 0, sy = 0;
-  float cell_length = 0.f, scale_to_map = 0.f;
-  float limx = 0.f, limy = 0.f;
-  Affine2 mapTworld{}, worldTmap{};
-  // device planes
-  float* d_logodds = nullptr;
-  int* d_update_index = nullptr;
-  float* d_prob = nullptr;
-  float4* d_quad = nullptr;
-  unsigned int* d_key_free = nullptr;
-  unsigned int* d_key_occ = nullptr;
-  unsigned int* d_occ_bits = nullptr;
-  unsigned char* d_free_bytes = nullptr;  // dense scans: crossed-cell byte map in the key_free tiling (map_update.h)
-  // GridMapLogOddsFunctions (GridMapLogOdds.h:200-203)
-  float log_odds_free = 0.f, log_odds_occ = 0.f;
-  // OccGridMapBase counters / GridMapBase::lastUpdateIndex
-  int curr_update_index = 0, curr_mark_occ = -1, curr_mark_free = -1, last_update_index = -1;
-  unsigned int serial = 0;  // key-plane generation (map_update.h)
-  int bbox[4] = {0, 0, -1, -1};   // cell box touched by the last update
-  int dirty[4] = {0, 0, -1, -1};  // union of those boxes since hsm_take_dirty_bbox was last called
-  int key_rows[2] = {0, -1};      // rows that carry keys of the current key generation (union of the boxes since the planes were last cleared)
-  bool marks_pending = false;     // a mark pass was queued on this level and its apply pass has not been (scrub_marks)
-  size_t cells() const { return (size_t)sx * sy; }
-  int tiles_x() const { return (sx + 3) / 4; }
-  int quad_texels() const {
-#if HSM_QUAD_TILE
-    return tiles_x() * ((sy + 1) / 2) * 8;
-#else
-    return sx * sy;
-#endif
-  }
-};
-
 }  // namespace
 
-struct hsm_ctx {
-  int device = 0;
-  int layout = kLayoutQuad;
-  int wps_override = 0;
-  // updateByScan returns when its kernels are QUEUED (env HSM_ASYNC_UPDATE=0: wait for them): everything
-  // that reads the map afterwards is ordered behind them on `stream`.  Host endpoints are staged in one of
-  // two pinned blocks, each guarded by the event of the update that last read it.
-  bool texel_cache = true;          // env HSM_TEXEL_CACHE=0: plain gn_match_kernel for throughput launches too
-  // ordering between the context's stream (updates) and caller-owned streams (hsm_match_batch_device):
-  // per caller stream the update epoch it has been ordered behind, and whether it may still run a match
-  struct ForeignStream {
-    hipStream_t s;
-    unsigned long long ordered_epoch;
-    bool pending;
-  };
-  std::vector<ForeignStream> foreign;
-  unsigned long long upd_epoch = 1;
-  hipEvent_t evt_updates = nullptr, evt_foreign = nullptr;
-  bool async_update = true;
-  int update_zero_copy_max = 4096;  // env HSM_UPDATE_ZEROCOPY_MAX
-  int merged_mark_max = 4096;       // scans below this take the one-launch mark pass (env HSM_MERGED_MARK_MAX, 0 = never)
-  int scatter_texels_max = 1 << 30; // quad layout: scans below this write the texels from the apply pass (env HSM_SCATTER_TEXELS_MAX, 0 = never)
-  BeamRec* d_beam_recs = nullptr;   // dense scans: per-beam records of all levels (map_update.h BeamRec), [levels][cap]
-  size_t beam_recs_cap = 0;         // beams per level
-  float2* h_upd_pinned[2] = {nullptr, nullptr};
-  size_t h_upd_cap[2] = {0, 0};
-  hipEvent_t upd_evt[2] = {nullptr, nullptr};
-  bool upd_busy[2] = {false, false};
-  int upd_slot = 0;
-  bool spin_wait = true;       // single-scan matches: poll the kernel's completion word (env HSM_SPIN_WAIT=0: off)
-  unsigned done_seq = 0;
-  std::vector<Level> levels;
-  mutable std::mutex mu;
-  hipStream_t stream = nullptr;
-  // single-scan staging (device) + pinned result
-  float2* d_scan = nullptr;
-  size_t d_scan_cap = 0;
-  float* d_small = nullptr;   // begin pose[3] | out pose[3] | out cov[9] | eval[12]
-  float* h_small = nullptr;   // pinned mirror of d_small
-  // retained scan = MapRepMultiMap::dataContainers (level-0 units; scaled by 2^-l on use)
-  std::vector<float> retained_pts;
-  float retained_origo[2] = {0.f, 0.f};
-  bool retained_valid = false;  // false until the first match (reference: empty containers)
-  float2* d_retained = nullptr;
-  size_t d_retained_cap = 0;
-  bool d_retained_current = false;
-  // the upload of a dense scan for matchData runs on its own stream, into the OTHER of two device buffers, from a pinned
-  // staging block: it overlaps the update kernels still queued on `stream` (which read the buffer of the scan before)
-  // instead of waiting behind them; the match kernel waits for the copy's event (stage_scan_overlapped)
-  float2* d_retained_alt = nullptr;
-  size_t d_retained_alt_cap = 0;
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_evt = nullptr;
-  float2* h_copy_pinned = nullptr;
-  size_t h_copy_pinned_cap = 0;
-  bool overlap_upload = true;  // env HSM_OVERLAP_UPLOAD=0: the copy is queued on `stream` as before
-  bool queued_update = false;  // an asynchronous updateByScan was queued on `stream` since the host last saw it drained
-  // batch staging for the host-pointer convenience entry
-  void* d_batch = nullptr;
-  size_t d_batch_cap = 0;
-  // ... and for its shared-scan form (pose hypotheses of ONE scan): start poses, results and the scan in pinned, device-mapped host
-  // memory -- the kernel reads each start pose once and writes each result once, straight over PCIe, no copy command either way
-  void* h_hyp_pinned = nullptr;
-  size_t h_hyp_cap = 0;
-  // single-scan fast path: endpoints staged in pinned, device-mapped host memory and read by the
-  // matcher ONCE (they stay in VGPRs); results written by the kernel straight into h_small
-  float2* h_scan_pinned = nullptr;
-  size_t h_scan_pinned_cap = 0;
-  // ingested scan (hsm_ingest_laser_scan): device container + host copy, sensor trig table cache
-  float* d_ranges = nullptr;
-  void* d_trig = nullptr;           // float2 (running-angle table) or double2 (laser_geometry unit vectors)
-  int trig_kind = -1;
-  float ingest_origo[2] = {0.f, 0.f};
-  float2* d_ingest = nullptr;
-  size_t ingest_cap = 0;
-  std::vector<float> h_ingest;      // endpoints as the matcher/updater see them (host copy)
-  int ingest_n = -1;                // -1 = nothing ingested yet
-  float trig_a0 = 0.f, trig_inc = 0.f;
-  int trig_n = -1;
-  signed char* d_occ = nullptr;     // occupancy export staging
-  size_t d_occ_cap = 0;
-  unsigned coop_bar_base = 0;   // value the grid-barrier counter has when the next cooperative launch starts
-  float* d_partials = nullptr;  // [2][64][9] per-workgroup partial sums of gn_match_coop_kernel
-  int coop_min_beams = 4096;    // single scans at least this long take the multi-workgroup matcher (env HSM_COOP_MIN)
-  bool coop_tagged = true;      // env HSM_COOP_TAGGED=0: the counter grid barrier instead of the tagged-record exchange
-  void* d_cells = nullptr;  // interleaved {logodds, updateIndex} staging for hsm_download_cells
-  size_t d_cells_cap = 0;
-  int bpl_override = -1;  // 0 = force the memory loop (env HSM_BPL=0), -1 = auto
-  int exact_batch_form = 2;      // env HSM_EXACT_BATCH: 0 = the one-wavefront-per-scan exact form for batches, too; 1 = producer / chain workgroups on maps <= 2^23 cells only (the rule until the <8,2> shape); 2 = on every map
-  int xcd_chunk_exact = 0;       // env HSM_XCD_CHUNK_EXACT: the same for the exact-order texel-cache form (0 = contiguous eighths, its default)
-  int xcd_chunk = 16;            // env HSM_XCD_CHUNK: workgroups per chunk of the chunked-cyclic batch mapping (0 = contiguous eighths)
-  unsigned long long* clock_probe = nullptr;  // hsm_set_clock_probe
-  bool cached_wps2 = false;      // env HSM_CACHED_WPS2=1: with waves_per_scan = 2, batches use the two-wave texel-cache form (experimental)
-  int spb_large = 8;             // env HSM_SPB_LARGE=4|8: scans per workgroup of the texel-cache matcher on maps > 2^23 cells
-  int wg_sync = -1;              // env HSM_WG_SYNC=0|1: per-beam workgroup barrier of the texel-cache matcher (-1 = for maps > 2^23 cells)
-  int exact_shape = 0;           // env HSM_EXACT_SHAPE=7|8: producers per workgroup of the exact batch form (0 = by batch size)
-  bool dense_bits = true;        // env HSM_DENSE_BITS=0: dense scans keep the keyed update (map_update.h)
-  bool exact_cached = true;      // env HSM_EXACT_CACHED=0: exact-mode batches keep round 2's producer / chain-wavefront form (gn_match.h)
-  bool exact = false;     // HSM_PARITY_EXACT: H / dTr summed in the reference's beam order (gn_match.h exact_round)
-  bool auto_parity = true;  // HSM_PARITY_AUTO (default): every entry point in the reference's summation order (auto_wants_exact)
-  bool relaxed = false;   // HSM_PARITY_RELAXED: contracted multiply-adds in the throughput kernel (gn_match_cached_kernel<.., RELAXED>)
-  int last_cfg[6] = {0, 0, 0, 0, 0, 0};
-  int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
-  bool exact_spec = false;       // env HSM_EXACT_SPEC=1: one-workgroup-per-scan launches in exact order take the speculative-carry form (gn_match_spec.h:
-                                 // the same bits; measured SLOWER than the literal chains on one CU -- DESIGN.md 8 -- hence opt-in)
-  float* d_spec_scratch = nullptr;   // gn_match_spec_kernel: products of every beam, [batch][stride] float4s
-  size_t spec_scratch_cap = 0;       // float4s
-  SpecStats* d_spec_stats = nullptr; // hsm_debug_spec_stats
-  bool exact_dense = true;       // env HSM_EXACT_DENSE=0: dense scans in exact order keep the 16-wavefront team form (gn_match_kernel<16,...,EXACT>)
-  int exact_dense_min = 4096;
-  int compute_units = 256;   // of this device (hsm_create)
-  int exact_split_tail = 1;  // env HSM_EXACT_SPLIT_TAIL=0: one launch however the batch divides into generations
-  int exact_chain_wave = 1;  // env HSM_EXACT_CHAIN_WAVE=0: no chain-only wavefront, teams of wavefronts for batches below 4096 scans (rounds 3-4)    // env HSM_EXACT_DENSE_MIN: beams from which the producers-ahead-of-the-chain form takes over
-  const char* last_kernel = "";  // name of the matcher kernel the last launch used (hsm_last_launch_kernel)
-  unsigned coop_fallbacks = 0;  // dense single-scan matches re-run on one workgroup after an exchange timeout (match_single)
-  int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
-};
 
 namespace {
 
@@ -379,51 +231,12 @@ int ensure_scan_capacity(float2*& buf, size_t& cap, size_t n) {
   return HSM_OK;
 }
 
-template <int WPS, int SPB, int BPL>
-int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
-  const int block = 64 * WPS * SPB;
-  const int grid = (P.batch + SPB - 1) / SPB;
-  if constexpr (WPS == 1 && (BPL == 9 || BPL == 17)) {
-    // throughput launches of long scans: the texel-cache form (gn_match.h)
-    if (h->texel_cache && P.begin_world && !P.trace) {
-      if (h->layout == kLayoutQuad && h->relaxed)
-        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad, 1, true>), dim3(grid), dim3(block), 0, stream, P);
-      else if (h->layout == kLayoutQuad)
-        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
-      else
-        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
-      HIP_TRY(hipGetLastError());
-      h->last_cfg[0] = h->layout;
-      h->last_cfg[1] = WPS;
-      h->last_cfg[2] = block;
-      h->last_cfg[3] = grid;
-      h->last_cfg[4] = BPL;
-      h->last_cfg[5] = 1;
-      h->last_kernel = "gn_match_cached_kernel";
-      return HSM_OK;
-    }
-  }
-  h->last_cfg[5] = 0;
-  h->last_kernel = "gn_match_kernel";
-  if (h->layout == kLayoutPlane)
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, BPL>), dim3(grid), dim3(block), 0, stream, P);
-  else
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, BPL>), dim3(grid), dim3(block), 0, stream, P);
-  HIP_TRY(hipGetLastError());
-  h->last_cfg[0] = h->layout;
-  h->last_cfg[1] = WPS;
-  h->last_cfg[2] = block;
-  h->last_cfg[3] = grid;
-  h->last_cfg[4] = BPL;
-  return HSM_OK;
-}
-
 // waves per scan: enough wavefronts to fill 256 CUs x 4 SIMDs x several waves, but never
 // more lanes than beams
 int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   if (h->wps_override > 0) return h->wps_override;
   int wps = 1;
-  const long target_waves = 256L * 4 * 4;  // 4 waves per SIMD
+  const long target_waves = (long)h->compute_units * 4 * 4;  // 4 waves per SIMD on every CU of THIS device (a partitioned device has fewer)
   while (wps < 16 && (long)batch * wps < target_waves && 64 * wps < max_n) wps *= 2;
   // ... but keep about five beams per lane: every extra wavefront adds LDS staging + a barrier to each
   // of the 14 dependent GN steps, which costs more than the beam loop saves (single 1081-beam scan on
@@ -433,135 +246,7 @@ int choose_wps(const hsm_ctx* h, int batch, int max_n) {
   return wps < lat ? wps : lat;
 }
 
-// beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
-// team's VGPRs (0 = stream the endpoints from memory every GN step)
-// HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
-template <int NS, int BPL, int BPC = BPL, bool CW = false>
-int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
-  const int grid = (P.batch + NS - 1) / NS, block = 64 * (NS + (CW ? 1 : 0));
-  // workgroup -> XCD mapping: this form runs best with one contiguous eighth of the batch per XCD on every map size (2048^2
-  // headline: 57.5 us against 58.3 with the fast form's chunks of 16 workgroups dealt in turn; chunks of 8 / 32: 58.4;
-  // profiles/r04/exact_kernel_param_sweep.txt) -- its rounds are paced by barriers and chain jobs, not by how long a scan's
-  // gathers take, so the load balancing the chunks buy the fast form is not needed and the compacter L2 footprint wins.
-  // env HSM_XCD_CHUNK_EXACT=n restores chunks of n workgroups.
-  P.xcd_chunk = h->xcd_chunk_exact > 0 ? (h->xcd_chunk_exact * 4 / NS > 0 ? h->xcd_chunk_exact * 4 / NS : 1) : 0;
-  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, CW>), dim3(grid), dim3(block), 0, stream, P);
-  HIP_TRY(hipGetLastError());
-  h->last_kernel = CW ? "gn_match_exact_cached_kernel (chain wavefront)" : "gn_match_exact_cached_kernel";
-  h->last_cfg[0] = h->layout;
-  h->last_cfg[1] = 1;
-  h->last_cfg[2] = block;
-  h->last_cfg[3] = grid;
-  h->last_cfg[4] = BPL;
-  h->last_cfg[5] = 1;
-  return HSM_OK;
-}
 
-// the texel-cache exact forms of launch_match_exact, by scan length and by how many workgroups the launch leaves a CU
-int launch_match_exact_cached_forms(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  const int per_lane = (max_n + 63) / 64;
-  // A launch that leaves every CU at most THREE workgroups takes the chain-wavefront form (gn_match_exact.h, CW): a fifth
-  // wavefront per workgroup runs the chain jobs, so a round lasts max(job, production) instead of job + production --
-  // 36 us against 52 for a level-0 batch of up to 2048 scans, 49 against 57 at 3072 (profiles/r05/README.md 9).  Not
-  // beyond: the dispatcher places a workgroup only where EVERY SIMD has room for ceil(waves / 4) of its wavefronts
-  // (tools/study/ubench_wg_placement.hip), the fourth five-wavefront workgroup of a CU waits for a whole workgroup to
-  // retire, and at four per CU both forms deliver the same ~70 scans per us anyway.
-  const int groups = (P.batch + 3) / 4;
-  // ... and a map that outgrows the L2s (4096^2: 136 us with six cached rows against 128.5 with fifteen, at 3072 scans) keeps
-  // round 3's form at three workgroups per CU; up to two per CU the chain-wavefront form has the full texel cache as well
-  const bool cw2 = h->exact_chain_wave && groups <= 2 * h->compute_units;
-  const bool cw = cw2 || (h->exact_chain_wave && groups <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23));
-  if (per_lane <= 5) return cw ? launch_match_exact_cached<4, 5, 5, true>(h, P, stream) : launch_match_exact_cached<4, 5>(h, P, stream);
-  if (per_lane <= 9) return cw ? launch_match_exact_cached<4, 9, 9, true>(h, P, stream) : launch_match_exact_cached<4, 9>(h, P, stream);
-  // (a round loop that leaves behind the longest scan's last row costs the 17-row form 8 % on full-length scans -- sixteen
-  // exit edges --; a 13-row instantiation costs compile time only: a batch of 720-beam scans runs 13 rounds instead of 17)
-  if (per_lane <= 13) {
-    if (cw2) return launch_match_exact_cached<4, 13, 13, true>(h, P, stream);
-    return cw ? launch_match_exact_cached<4, 13, HSM_XBPC_CW + 1, true>(h, P, stream) : launch_match_exact_cached<4, 13>(h, P, stream);
-  }
-  if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
-  if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
-  return launch_match_exact_cached<4, 17, HSM_XBPC_MAIN>(h, P, stream);
-}
-
-template <int WPS, int SPB>
-int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
-  // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
-  // 36-lane chain job per round behind the round's barrier (gn_match_exact.h).  Measured against round 2's producer /
-  // chain-wavefront form (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
-  // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  Scans longer than 17 beams per lane stream their tail rows.
-  if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
-    // More than one generation of workgroups (four per CU) with a remainder that the chain-wavefront form takes: the whole
-    // generations go out in round 3's form, the remainder behind them in its own launch -- 5000 scans: 57 + 36 us instead of the
-    // 104 a single launch takes (its last, part-filled generation runs ~47 us in the rotating-owner form).
-    const int groups = (P.batch + 3) / 4, full = 4 * h->compute_units, rest = groups % full;
-    if (h->exact_chain_wave && h->exact_split_tail && groups > full && rest > 0 &&
-        (rest <= 2 * h->compute_units || (rest <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23)))) {
-      MatchParams A = P, B = P;
-      A.batch = (groups - rest) * 4;
-      B.batch = P.batch - A.batch;
-      B.begin_world = P.begin_world + 3 * (size_t)A.batch;
-      if (P.offsets) B.offsets = P.offsets + A.batch;  // (absolute offsets into pts: the pointer moves, pts stays)
-      B.out_pose = P.out_pose + 3 * (size_t)A.batch;
-      if (P.out_cov) B.out_cov = P.out_cov + 9 * (size_t)A.batch;
-      B.clock_probe = nullptr;  // (scan 0's probe belongs to the first launch)
-      if (int rc = launch_match_exact_cached_forms(h, A, max_n, stream)) return rc;
-      const int grid_a = h->last_cfg[3];
-      if (int rc = launch_match_exact_cached_forms(h, B, max_n, stream)) return rc;
-      h->last_cfg[2] = 256;  // (hsm_last_launch_config describes the first launch; its grid counts both)
-      h->last_cfg[3] += grid_a;
-      h->last_kernel = "gn_match_exact_cached_kernel + its chain-wavefront form for the last, part-filled generation";
-      return HSM_OK;
-    }
-    return launch_match_exact_cached_forms(h, P, max_n, stream);
-  }
-#if defined(HSM_EXPERIMENTS)
-  // round 2's exact batch form: producer wavefronts + chain wavefronts per workgroup (gn_match.h), env HSM_EXACT_CACHED=0.
-  // Measured (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2>
-  // and two gathers in flight.  Not in the default library since round 4 (the texel-cache form above serves every quad
-  // batch; the plane layout takes the one-wavefront exact form below).
-  if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form &&
-      (h->exact_batch_form == 2 || h->levels[0].cells() <= ((size_t)1 << 23))) {
-    const auto worst_cu = [&](int per_wg) { return ((P.batch + per_wg - 1) / per_wg + 255) / 256 * per_wg; };
-    int per_wg = worst_cu(8) < worst_cu(kExactScans) ? 8 : kExactScans;
-    if (h->exact_shape == 7 || h->exact_shape == 8) per_wg = h->exact_shape;
-    const int grid = (P.batch + per_wg - 1) / per_wg, block = per_wg == 8 ? 64 * 10 : 64 * (kExactScans + 1);
-    if (per_wg == 8) {
-      if (h->layout == kLayoutPlane)
-        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
-      else
-        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
-    } else if (h->layout == kLayoutPlane) {
-      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
-    } else {
-      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
-    }
-    HIP_TRY(hipGetLastError());
-    h->last_cfg[0] = h->layout;
-    h->last_cfg[1] = 1;
-    h->last_cfg[2] = block;
-    h->last_cfg[3] = grid;
-    h->last_cfg[4] = 0;
-    h->last_cfg[5] = 0;
-    return HSM_OK;
-  }
-#endif
-  const int block = 64 * WPS * SPB;
-  const int grid = (P.batch + SPB - 1) / SPB;
-  if (h->layout == kLayoutPlane)
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, 0, true>), dim3(grid), dim3(block), 0, stream, P);
-  else
-    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, 0, true>), dim3(grid), dim3(block), 0, stream, P);
-  HIP_TRY(hipGetLastError());
-  h->last_cfg[0] = h->layout;
-  h->last_cfg[1] = WPS;
-  h->last_cfg[2] = block;
-  h->last_cfg[3] = grid;
-  h->last_cfg[4] = 0;
-  h->last_cfg[5] = 0;
-  h->last_kernel = "gn_match_kernel (exact order)";
-  return HSM_OK;
-}
 
 // HSM_PARITY_AUTO (the default): EVERY match -- batched, single scan, dense scan, and the likelihood / covariance / Hessian
 // entry points -- takes the reference's summation order: bit-identical to the reference CPU matcher on every entry point.
@@ -572,27 +257,13 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
 // of 256 scans per family, of which the corridor family already failed (0.83 within 1e-4 m).  Round 5: the same argument holds for
 // one scan as for 4096, so the default does not try there either.  HSM_PARITY_FAST / _RELAXED stay opt-in for callers who trade
 // the guarantee for speed (profiles/r05/README.md has the prices: batch +34 % / +45 %, single 1081-beam scan ~35 vs ~95 us).
-// AUTO differs from HSM_PARITY_EXACT in one respect only: AUTO may pick ANY form that is bit-identical to the reference's chain
-// (the serial chain today; a faster exact form when one exists), HSM_PARITY_EXACT always runs the literal serial chains.
+// AUTO and HSM_PARITY_EXACT launch the same kernels today (launch_match treats them alike); the distinction kept in the API is one of
+// contract: AUTO promises the reference's BITS by whatever form delivers them, EXACT names the reference's order of additions.
 bool auto_wants_exact(const hsm_ctx* h, const MatchParams&) { return h->auto_parity; }
 // the effective summation order of the entry points that do not go through launch_match (staging decisions, likelihood,
 // covariance, Hessian probes)
 bool wants_exact(const hsm_ctx* h) { return h->exact || h->auto_parity; }
 
-template <int WPS, int SPB>
-int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
-  if (exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
-  const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
-  if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
-  // (two beams per lane: only one-wavefront teams get there by themselves -- choose_wps keeps ~5 beams per lane -- so wider
-  // teams, reachable through an explicit waves_per_scan only, share the three-beam instantiation)
-  if constexpr (WPS == 1)
-    if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
-  if (per_lane <= 3) return launch_match_t<WPS, SPB, 3>(h, P, stream);
-  if (per_lane <= 5) return launch_match_t<WPS, SPB, 5>(h, P, stream);
-  if (per_lane <= 9) return launch_match_t<WPS, SPB, 9>(h, P, stream);
-  return launch_match_t<WPS, SPB, 17>(h, P, stream);
-}
 
 int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact);
 
@@ -677,41 +348,7 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
       (max_n <= 17 * 64 || (P.batch > h->compute_units && !(h->exact_dense && max_n >= h->exact_dense_min))))
     wps = 1;
   if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, max_n, stream);
-  switch (wps) {
-    case 1: {
-      // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
-      // per-beam workgroup barrier (MatchParams::wg_sync) eight waves share the texel lines in the CU's L1 (4096^2
-      // pyramid: 132.8 -> 129.1 us; 16 per workgroup: 133 us; no effect on the 2048^2 workloads, which keep four)
-      const int per_lane = (max_n + 63) / 64;
-      if (h->spb_large == 8 && h->levels[0].cells() > ((size_t)1 << 23) && !exact && h->texel_cache && P.begin_world &&
-          !P.trace && h->bpl_override != 0 && per_lane > 5 && per_lane <= 17)
-        return per_lane <= 9 ? launch_match_t<1, 8, 9>(h, P, stream) : launch_match_t<1, 8, 17>(h, P, stream);
-      return launch_match_w<1, 4>(h, P, max_n, stream, exact);
-    }
-    case 2: {
-#if defined(HSM_EXPERIMENTS)
-      // experimental (HSM_CACHED_WPS2=1, explicit waves_per_scan = 2): the texel-cache form on a PAIR of waves per scan
-      // -- nine beams per lane, five waves per SIMD, 1.6 generations of waves for a 4096-scan launch (gn_match.h)
-      const int per_lane = (max_n + 127) / 128;
-      if (h->cached_wps2 && !exact && h->texel_cache && P.begin_world && !P.trace && h->bpl_override != 0 &&
-          h->layout == kLayoutQuad && per_lane > 0 && per_lane <= 9) {
-        hipLaunchKernelGGL((gn_match_cached_kernel<1, 9, kLayoutQuad, 2>), dim3(P.batch), dim3(128), 0, stream, P);
-        HIP_TRY(hipGetLastError());
-        h->last_cfg[0] = h->layout;
-        h->last_cfg[1] = 2;
-        h->last_cfg[2] = 128;
-        h->last_cfg[3] = P.batch;
-        h->last_cfg[4] = 9;
-        h->last_cfg[5] = 1;
-        return HSM_OK;
-      }
-#endif
-      return launch_match_w<2, 1>(h, P, max_n, stream, exact);
-    }
-    case 4: return launch_match_w<4, 1>(h, P, max_n, stream, exact);
-    case 8: return launch_match_w<8, 1>(h, P, max_n, stream, exact);
-    default: return launch_match_w<16, 1>(h, P, max_n, stream, exact);
-  }
+  return launch_match_by_width(h, P, max_n, stream, exact, wps);
 }
 
 // the schedule of MapRepMultiMap::matchData (MapRepMultiMap.h:116-132): coarse levels
@@ -1532,7 +1169,13 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
   P.err_flag = reinterpret_cast<unsigned*>(hs_dev + kErrFlagOff);
   P.coop_mute_block = h->coop_mute_block;
   P.clock_probe = h->clock_probe;
-  if (n >= h->coop_min_beams && h->wps_override == 0 && !wants_exact(h)) {
+  bool coop_now = n >= h->coop_min_beams && h->wps_override == 0 && !wants_exact(h);
+  if (coop_now && h->coop_skip > 0) {  // backing off after an exchange timeout: this match goes straight to the one-workgroup form
+    --h->coop_skip;
+    coop_now = false;
+  }
+  const bool coop_tried = coop_now;
+  if (coop_now) {
     // one dense scan: spread it over K workgroups of one cooperative launch (gn_match.h); the exact-order
     // form keeps the scan on one workgroup -- its nine summation chains are sequential anyway
     // one beam per lane.  16 k beams, matchData us for K = 16 / 24 / 32 / 64 workgroups: 79.8 / 71 / 66-70 / 64 with round 2's grid
@@ -1599,9 +1242,19 @@ static int match_single(hsm_ctx* h, MatchParams& P, const float begin_world[3], 
     if (int rc = launch_match(h, P, n, h->stream)) return rc;
     if (int rc = wait_single_scan(h, seq2)) return rc;
     ++h->coop_fallbacks;
+    h->coop_backoff = h->coop_backoff ? (h->coop_backoff < 1024 ? 2 * h->coop_backoff : 1024) : 1;
+    h->coop_skip = h->coop_backoff;
+    {
+      char b[200];
+      snprintf(b, sizeof b, "hsm_match: the multi-workgroup matcher's exchange timed out (device shared or busy); re-ran on one workgroup, "
+               "skipping that form for the next %u dense matches", h->coop_skip);
+      g_last_error = b;  // (not an error return: the pose is valid; the text tells who asks why a match took long)
+    }
     if (*reinterpret_cast<volatile unsigned*>(hs + kErrFlagOff) == seq2)
       return fail(HSM_ERR_HIP, "hsm_match: exchange timeout flagged by the one-workgroup matcher (cannot happen: it has no exchange)");
   }
+  else if (coop_tried)
+    h->coop_backoff = 0;  // an exchange completed: the device is ours again
   for (int i = 0; i < trace_steps * 12; ++i) trace[i] = hs[kTraceOff + i];
   out_pose_world[0] = hs[3];
   out_pose_world[1] = hs[4];

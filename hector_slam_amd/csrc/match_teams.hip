@@ -1,0 +1,185 @@
+// match_teams.hip -- launches of the team forms of the matcher (gn_match.h: gn_match_kernel on 1 .. 16 wavefronts per scan,
+// either summation order) and of the fast texel-cache forms (gn_match_cached_kernel).  About eighty instantiations: a
+// translation unit of its own so that an edit elsewhere does not rebuild them.
+#include "gn_match.h"
+#include "hsm_ctx.h"
+
+namespace hsm_host {
+namespace {
+
+#define HIP_TRY HSM_HIP_TRY
+
+template <int WPS, int SPB, int BPL>
+int launch_match_t(hsm_ctx* h, const MatchParams& P, hipStream_t stream) {
+  const int block = 64 * WPS * SPB;
+  const int grid = (P.batch + SPB - 1) / SPB;
+  if constexpr (WPS == 1 && (BPL == 9 || BPL == 17)) {
+    // throughput launches of long scans: the texel-cache form (gn_match.h)
+    if (h->texel_cache && P.begin_world && !P.trace) {
+      if (h->layout == kLayoutQuad && h->relaxed)
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad, 1, true>), dim3(grid), dim3(block), 0, stream, P);
+      else if (h->layout == kLayoutQuad)
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+      else
+        hipLaunchKernelGGL((gn_match_cached_kernel<SPB, BPL, kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
+      HIP_TRY(hipGetLastError());
+      h->last_cfg[0] = h->layout;
+      h->last_cfg[1] = WPS;
+      h->last_cfg[2] = block;
+      h->last_cfg[3] = grid;
+      h->last_cfg[4] = BPL;
+      h->last_cfg[5] = 1;
+      h->last_kernel = "gn_match_cached_kernel";
+      return HSM_OK;
+    }
+  }
+  h->last_cfg[5] = 0;
+  h->last_kernel = "gn_match_kernel";
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, BPL>), dim3(grid), dim3(block), 0, stream, P);
+  else
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, BPL>), dim3(grid), dim3(block), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = WPS;
+  h->last_cfg[2] = block;
+  h->last_cfg[3] = grid;
+  h->last_cfg[4] = BPL;
+  return HSM_OK;
+}
+
+template <int WPS, int SPB>
+int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
+  // throughput launches of the quad layout: every wavefront a producer with the texel cache, four scans per workgroup, one
+  // 36-lane chain job per round behind the round's barrier (gn_match_exact.h).  Measured against round 2's producer /
+  // chain-wavefront form (profiles/r03/README.md): 66-69 vs 92 us on the 2048^2 headline batch, 141-143 vs 199 us on the
+  // 3-level batch, 156-162 vs 291 us on the 4096^2 pyramid.  Scans longer than 17 beams per lane stream their tail rows.
+  if (WPS == 1 && P.begin_world && !P.trace && h->layout == kLayoutQuad && h->bpl_override != 0 && h->exact_cached) {
+    // More than one generation of workgroups (four per CU) with a remainder that the chain-wavefront form takes: the whole
+    // generations go out in round 3's form, the remainder behind them in its own launch -- 5000 scans: 57 + 36 us instead of the
+    // 104 a single launch takes (its last, part-filled generation runs ~47 us in the rotating-owner form).
+    const int groups = (P.batch + 3) / 4, full = 4 * h->compute_units, rest = groups % full;
+    if (h->exact_chain_wave && h->exact_split_tail && groups > full && rest > 0 &&
+        (rest <= 2 * h->compute_units || (rest <= 3 * h->compute_units && h->levels[0].cells() <= ((size_t)1 << 23)))) {
+      MatchParams A = P, B = P;
+      A.batch = (groups - rest) * 4;
+      B.batch = P.batch - A.batch;
+      B.begin_world = P.begin_world + 3 * (size_t)A.batch;
+      if (P.offsets) B.offsets = P.offsets + A.batch;  // (absolute offsets into pts: the pointer moves, pts stays)
+      B.out_pose = P.out_pose + 3 * (size_t)A.batch;
+      if (P.out_cov) B.out_cov = P.out_cov + 9 * (size_t)A.batch;
+      B.clock_probe = nullptr;  // (scan 0's probe belongs to the first launch)
+      if (int rc = launch_match_exact_cached_forms(h, A, max_n, stream)) return rc;
+      const int grid_a = h->last_cfg[3];
+      if (int rc = launch_match_exact_cached_forms(h, B, max_n, stream)) return rc;
+      h->last_cfg[2] = 256;  // (hsm_last_launch_config describes the first launch; its grid counts both)
+      h->last_cfg[3] += grid_a;
+      h->last_kernel = "gn_match_exact_cached_kernel + its chain-wavefront form for the last, part-filled generation";
+      return HSM_OK;
+    }
+    return launch_match_exact_cached_forms(h, P, max_n, stream);
+  }
+#if defined(HSM_EXPERIMENTS)
+  // round 2's exact batch form: producer wavefronts + chain wavefronts per workgroup (gn_match.h), env HSM_EXACT_CACHED=0.
+  // Measured (profiles/r02/README.md): 108 vs 122 us on the 2048^2 headline batch with the <7,1> shape, 92-97 us with <8,2>
+  // and two gathers in flight.  Not in the default library since round 4 (the texel-cache form above serves every quad
+  // batch; the plane layout takes the one-wavefront exact form below).
+  if (WPS == 1 && P.begin_world && !P.trace && h->exact_batch_form &&
+      (h->exact_batch_form == 2 || h->levels[0].cells() <= ((size_t)1 << 23))) {
+    const auto worst_cu = [&](int per_wg) { return ((P.batch + per_wg - 1) / per_wg + 255) / 256 * per_wg; };
+    int per_wg = worst_cu(8) < worst_cu(kExactScans) ? 8 : kExactScans;
+    if (h->exact_shape == 7 || h->exact_shape == 8) per_wg = h->exact_shape;
+    const int grid = (P.batch + per_wg - 1) / per_wg, block = per_wg == 8 ? 64 * 10 : 64 * (kExactScans + 1);
+    if (per_wg == 8) {
+      if (h->layout == kLayoutPlane)
+        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
+      else
+        hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad, 8, 2>), dim3(grid), dim3(block), 0, stream, P);
+    } else if (h->layout == kLayoutPlane) {
+      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutPlane>), dim3(grid), dim3(block), 0, stream, P);
+    } else {
+      hipLaunchKernelGGL((gn_match_exact_batch_kernel<kLayoutQuad>), dim3(grid), dim3(block), 0, stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = 1;
+    h->last_cfg[2] = block;
+    h->last_cfg[3] = grid;
+    h->last_cfg[4] = 0;
+    h->last_cfg[5] = 0;
+    return HSM_OK;
+  }
+#endif
+  const int block = 64 * WPS * SPB;
+  const int grid = (P.batch + SPB - 1) / SPB;
+  if (h->layout == kLayoutPlane)
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutPlane, 0, true>), dim3(grid), dim3(block), 0, stream, P);
+  else
+    hipLaunchKernelGGL((gn_match_kernel<WPS, SPB, kLayoutQuad, 0, true>), dim3(grid), dim3(block), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  h->last_cfg[0] = h->layout;
+  h->last_cfg[1] = WPS;
+  h->last_cfg[2] = block;
+  h->last_cfg[3] = grid;
+  h->last_cfg[4] = 0;
+  h->last_cfg[5] = 0;
+  h->last_kernel = "gn_match_kernel (exact order)";
+  return HSM_OK;
+}
+
+template <int WPS, int SPB>
+int launch_match_w(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact) {
+  if (exact) return launch_match_exact<WPS, SPB>(h, P, max_n, stream);
+  const int per_lane = (max_n + 64 * WPS - 1) / (64 * WPS);
+  if (h->bpl_override == 0 || per_lane > 17) return launch_match_t<WPS, SPB, 0>(h, P, stream);
+  // (two beams per lane: only one-wavefront teams get there by themselves -- choose_wps keeps ~5 beams per lane -- so wider
+  // teams, reachable through an explicit waves_per_scan only, share the three-beam instantiation)
+  if constexpr (WPS == 1)
+    if (per_lane <= 2) return launch_match_t<WPS, SPB, 2>(h, P, stream);
+  if (per_lane <= 3) return launch_match_t<WPS, SPB, 3>(h, P, stream);
+  if (per_lane <= 5) return launch_match_t<WPS, SPB, 5>(h, P, stream);
+  if (per_lane <= 9) return launch_match_t<WPS, SPB, 9>(h, P, stream);
+  return launch_match_t<WPS, SPB, 17>(h, P, stream);
+}
+
+}  // namespace
+
+int launch_match_by_width(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream, bool exact, int wps) {
+  switch (wps) {
+    case 1: {
+      // maps whose touched region outgrows the L2s: EIGHT consecutive scans per workgroup instead of four -- with the
+      // per-beam workgroup barrier (MatchParams::wg_sync) eight waves share the texel lines in the CU's L1 (4096^2
+      // pyramid: 132.8 -> 129.1 us; 16 per workgroup: 133 us; no effect on the 2048^2 workloads, which keep four)
+      const int per_lane = (max_n + 63) / 64;
+      if (h->spb_large == 8 && h->levels[0].cells() > ((size_t)1 << 23) && !exact && h->texel_cache && P.begin_world &&
+          !P.trace && h->bpl_override != 0 && per_lane > 5 && per_lane <= 17)
+        return per_lane <= 9 ? launch_match_t<1, 8, 9>(h, P, stream) : launch_match_t<1, 8, 17>(h, P, stream);
+      return launch_match_w<1, 4>(h, P, max_n, stream, exact);
+    }
+    case 2: {
+#if defined(HSM_EXPERIMENTS)
+      // experimental (HSM_CACHED_WPS2=1, explicit waves_per_scan = 2): the texel-cache form on a PAIR of waves per scan
+      // -- nine beams per lane, five waves per SIMD, 1.6 generations of waves for a 4096-scan launch (gn_match.h)
+      const int per_lane = (max_n + 127) / 128;
+      if (h->cached_wps2 && !exact && h->texel_cache && P.begin_world && !P.trace && h->bpl_override != 0 &&
+          h->layout == kLayoutQuad && per_lane > 0 && per_lane <= 9) {
+        hipLaunchKernelGGL((gn_match_cached_kernel<1, 9, kLayoutQuad, 2>), dim3(P.batch), dim3(128), 0, stream, P);
+        HIP_TRY(hipGetLastError());
+        h->last_cfg[0] = h->layout;
+        h->last_cfg[1] = 2;
+        h->last_cfg[2] = 128;
+        h->last_cfg[3] = P.batch;
+        h->last_cfg[4] = 9;
+        h->last_cfg[5] = 1;
+        return HSM_OK;
+      }
+#endif
+      return launch_match_w<2, 1>(h, P, max_n, stream, exact);
+    }
+    case 4: return launch_match_w<4, 1>(h, P, max_n, stream, exact);
+    case 8: return launch_match_w<8, 1>(h, P, max_n, stream, exact);
+    default: return launch_match_w<16, 1>(h, P, max_n, stream, exact);
+  }
+}
+
+}  // namespace hsm_host

@@ -79,12 +79,22 @@ def test_deferred_emit_holds_the_line_back(monkeypatch, tmp_path):
     rec = canned()
     monkeypatch.setenv("HSM_BENCH_DETAILS", str(tmp_path / "d.json"))
     monkeypatch.delenv("HSM_BENCH_CHILD", raising=False)
-    monkeypatch.setattr(bench, "_DEFER_EMIT", True)
+    from hsm_bench import common
+    common.defer_emit(True)
     buf = io.StringIO()
+    try:
+        with redirect_stdout(buf):
+            bench.emit(rec)
+        assert buf.getvalue() == "" and common._PENDING and common._PENDING[-1] is rec
+    finally:
+        common.defer_emit(False)
     with redirect_stdout(buf):
-        bench.emit(rec)
-    assert buf.getvalue() == "" and bench._PENDING and bench._PENDING[-1] is rec
-    monkeypatch.setattr(bench, "_DEFER_EMIT", False)
-    with redirect_stdout(buf):
-        bench.emit(bench._PENDING.pop())
+        common.emit_pending()
+    assert not common._PENDING
     assert json.loads(buf.getvalue().strip().splitlines()[-1])["value"] == rec["value"]
+
+
+def test_driver_entry_is_small():
+    """bench.py is the driver's entry point and nothing else: arguments, self-launch of --gpus N, dispatch into hsm_bench/"""
+    n = len(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read().splitlines())
+    assert n < 300, n

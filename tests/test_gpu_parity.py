@@ -813,6 +813,12 @@ def test_dense_matcher_exchange_timeout_falls_back_to_the_one_workgroup_matcher(
     assert dt < 60.0, dt  # one timeout, not one per remaining GN step
     print(f"exchange timeout + fallback: {dt:.2f} s")
     g.debug_set_coop_mute(0)
+    # back-off (round 6): after a timeout the NEXT dense match does not try the multi-workgroup form at all -- on a device another
+    # process keeps busy every match would otherwise pay the bounded wait and a second launch; the one after tries again, and the
+    # exchange that completes resets the back-off
+    pb, cb = g.matchData(sc.query_init[1], pts)
+    assert g.last_launch_config()["waves_per_scan"] == 16 and g.debug_coop_fallbacks() == 1
+    assert np.array_equal(bits(pb), bits(p1)) and np.array_equal(bits(cb), bits(c1))
     p2, c2 = g.matchData(sc.query_init[1], pts)
     assert g.last_launch_config()["waves_per_scan"] < 0 and g.debug_coop_fallbacks() == 1
     assert np.array_equal(bits(p2), bits(p0)) and np.array_equal(bits(c2), bits(c0))

@@ -31,7 +31,7 @@ def main():
     B = max(sizes)
     res, size, n_beams = bench.RESOLUTION, bench.MAP_SIZE, bench.N_BEAMS
     if args.workload == "config3":
-        bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)
+        bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)[:7]
         init = init_l0 if args.levels == 1 else init_pyr
     else:  # as bench.extra_workload builds it
         import math

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from hector_slam_amd import capi
-bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, 4096)
+bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, 4096)[:7]
 m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, 1)
 m.setUpdateFactorFree(0.4); m.setUpdateFactorOccupied(0.9)
 m.build_map(bp, bs)

@@ -17,7 +17,7 @@ def main():
     from hector_slam_amd import capi
     dev = torch.device("cuda", 0)
     B = 4096
-    bp, bs, truth, init, init_pyr, pts, offs = bench.make_inputs(0, B)
+    bp, bs, truth, init, init_pyr, pts, offs = bench.make_inputs(0, B)[:7]
     levels = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     m = capi.MapRepMultiMap(bench.RESOLUTION, bench.MAP_SIZE, bench.MAP_SIZE, levels, device=0)
     m.setUpdateFactorFree(0.4)

@@ -24,7 +24,7 @@ def main():
     from hector_slam_amd import capi
     dev = torch.device("cuda", 0)
     B = args.batch
-    bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)
+    bp, bs, truth, init_l0, init_pyr, pts, offs = bench.make_inputs(0, B)[:7]
     init = init_l0 if args.levels == 1 else init_pyr
     d_init = torch.from_numpy(init).to(dev)
     d_pts = torch.from_numpy(pts).to(dev)

@@ -41,7 +41,7 @@ def main():
         dropped = [c for c in g if c not in keep]
         if dropped:
             print("not offered by this rocprofv3:", dropped, file=sys.stderr)
-    bench.PMC_GROUPS = tuple(groups)
+    bench.pmc.PMC_GROUPS = tuple(groups)
     kernels = ["gn_match_exact_cached_kernel", "gn_match_cached_kernel"]
     vals, err = bench.pmc_collect(["--leg", "pmc", "--steps", steps, "--warmup", "3", "--no-cpu", "--no-pmc"], kernels, warmup=3)
     rec = {"kernels": vals, "errors": err, "groups": groups,
