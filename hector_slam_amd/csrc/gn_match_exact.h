@@ -533,7 +533,10 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
 #ifndef HSM_XEARLY_FIRST
 #define HSM_XEARLY_FIRST 0
 #endif
-        constexpr bool kBalanced = HSM_XEARLY == 2 && !CW && NCP == 64 && (!kFirst || HSM_XEARLY_FIRST != 0);
+        // (... and so does the 17-row form with fifteen cached rows, which has no registers left to hold a row across a barrier: the
+        // instantiation for maps that outgrow the L2s -- 4096^2 pyramid: 145 us with 15 cached rows and the rotating owner, 153 us
+        // with 13 and the balanced schedule, profiles/r06)
+        constexpr bool kBalanced = HSM_XEARLY == 2 && !CW && NCP == 64 && (!kFirst || HSM_XEARLY_FIRST != 0) && (BPL < 17 || BPC <= HSM_XBPC_MAIN);
         constexpr bool kEarly = HSM_XEARLY == 1 && !CW && NCP == 64 && !kFirst;
         f2 p_next = f2{0.0f, 0.0f};
         if (kAhead) p_next = endpoint(BPL > 1 ? 1 : 0);

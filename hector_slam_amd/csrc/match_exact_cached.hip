@@ -59,6 +59,9 @@ int launch_match_exact_cached_forms(hsm_ctx* h, const MatchParams& P, int max_n,
   }
   if (cw2) return launch_match_exact_cached<4, 17, HSM_XBPC, true>(h, P, stream);
   if (cw) return launch_match_exact_cached<4, 17, HSM_XBPC_CW, true>(h, P, stream);
+  // four workgroups per CU: the balanced schedule (13 cached rows) where level 0 fits the L2s, else round 3's (15 cached rows: the
+  // gathers of a map that misses the L2 cost more than the schedule gains)
+  if (HSM_XBPC_MAIN != HSM_XBPC && h->levels[0].cells() > ((size_t)1 << 23)) return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
   return launch_match_exact_cached<4, 17, HSM_XBPC_MAIN>(h, P, stream);
 }
 

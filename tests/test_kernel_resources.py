@@ -159,7 +159,7 @@ def test_no_register_of_an_inflight_gather_is_touched(device_asm):
     assert len(names) >= 17, names
     for need in ("gn_match_cached_kernelILi4ELi17ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi1ELi1ELb1E", "gn_match_cached_kernelILi8ELi17ELi1ELi1ELb0E",
                  "gn_match_cached_kernelILi4ELi9ELi1ELi1ELb0E", "gn_match_cached_kernelILi4ELi17ELi2ELi1ELb0E",
-                 "gn_match_exact_cached_kernelILi4ELi17ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb0E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb0E",
+                 "gn_match_exact_cached_kernelILi4ELi17ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi17ELi15ELb0E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb0E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb0E",
                  "gn_match_exact_cached_kernelILi4ELi13ELi13ELb0E", "gn_match_exact_cached_kernelILi4ELi13ELi7ELb1E",
                  "gn_match_exact_cached_kernelILi4ELi13ELi13ELb1E", "gn_match_exact_cached_kernelILi4ELi17ELi15ELb1E",
                  "gn_match_exact_cached_kernelILi4ELi17ELi6ELb1E", "gn_match_exact_cached_kernelILi4ELi9ELi9ELb1E", "gn_match_exact_cached_kernelILi4ELi5ELi5ELb1E"):

@@ -275,7 +275,7 @@ def _worker_group_child(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import time
     import types
-    import bench
+    from hsm_bench import group as bench
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:

@@ -35,12 +35,16 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 print("value", round(d["value"] / 1e6, 1), "M it/s", d["ms_per_step"], "kernel", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"])
 print("fast", round(d["fast_mode"]["value"] / 1e6, 1), d["fast_mode"]["kernel_ms"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("bit_identical_pose_fraction"))
-for k in ("headline_8d_starts", "relaxed", "pyramid", "pipelined", "cpu_baseline_all_cores"):
+for k in ("gentle_starts", "relaxed", "pyramid", "pipelined", "cpu_baseline_all_cores", "sustained"):
     print(k, json.dumps(d.get(k))[:300])
 for k, v in (d.get("configs") or {}).items():
     v = v or {}
     print(k, "value", v.get("value"), "ms", v.get("ms_per_step"), "match/update", v.get("match_ms"), v.get("update_ms"), "fast", (v.get("fast_mode") or {}).get("ms_per_step"), "err", v.get("error"))
 PY
+echo "== multi-rank path on this box: one rank with a process group (nccl), two ranks sharing the device (self-launched), the C++ group"; S=$(date +%s)
+HSM_BENCH_FORCE_DIST=1 HSM_BENCH_DETAILS=$OUT/bench_one_rank_nccl_group_details.json timeout 600 python bench.py --gpus 1 --steps 200 --warmup 10 --no-pmc --no-cpu > "$OUT/bench_one_rank_nccl_group.out" 2> "$OUT/bench_one_rank_nccl_group.err"; echo "rc=$?"; tail -1 "$OUT/bench_one_rank_nccl_group.out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('direct gather per match', d['ms_per_step'], d.get('gather_legs'))"
+HSM_BENCH_SHARE_GPU=1 HSM_BENCH_DETAILS=$OUT/bench_two_ranks_one_device_details.json timeout 600 python bench.py --gpus 2 --steps 100 --warmup 10 --no-pmc --no-cpu > "$OUT/bench_two_ranks_one_device.out" 2> "$OUT/bench_two_ranks_one_device.err"; echo "rc=$?"; tail -1 "$OUT/bench_two_ranks_one_device.out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('2 ranks', d['ms_per_step'], d.get('gather_legs'))"
+timeout 600 python bench.py --group 2 --steps 50 > "$OUT/bench_group2.out" 2> "$OUT/bench_group2.err"; echo "rc=$? ($(( $(date +%s) - S )) s)"
 echo "== node loop, default mode, 30000 scans"; S=$(date +%s)
 timeout 900 python tools/node_loop_parity.py 30000 --parity auto > "$OUT/node_loop_parity_default_30000.json" 2> "$OUT/node_loop.err"; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-400 "$OUT/node_loop_parity_default_30000.json"
 echo "== free-running soak, default mode, 30000 steps"; S=$(date +%s)
