@@ -99,6 +99,7 @@ SIGNATURES = {
     "hsm_exchange_post": (_i, [_vp, _vp, _i, _i, _vp]),
     "hsm_exchange_wait": (_i, [_vp, _vp, _vp]),
     "hsm_exchange_post_wait": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "hsm_match_batch_device_gather": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hsm_exchange_epochs": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "hsm_exchange_status": (_i, [_vp]),
     "hsm_exchange_memory_kind": (C.c_char_p, [_vp]),
@@ -501,6 +502,13 @@ class MapRepMultiMap:
         _check(self._lib.hsm_match_batch_device(self._h, batch, d_begin, d_pts, d_offsets or None, shared_n,
                                                 d_out_pose, d_out_cov or None, stream or None),
                "hsm_match_batch_device")
+
+    def match_batch_device_gather(self, batch, d_begin, d_pts, d_offsets, shared_n, d_out_pose, d_out_cov, exchange, first_row, lag,
+                                  d_out_all, stream=0):
+        """match_batch_device + one step of `exchange` (a PoseExchange) in one call; the launch carries the exchange where it can"""
+        _check(self._lib.hsm_match_batch_device_gather(self._h, batch, d_begin, d_pts, d_offsets, shared_n, d_out_pose, d_out_cov or None,
+                                                       exchange._h, int(first_row), int(lag), d_out_all or None, stream),
+               "hsm_match_batch_device_gather")
 
     def device_info(self):
         a = np.empty(4, np.int32)

@@ -53,6 +53,7 @@
 #include <hip/hip_cooperative_groups.h>
 
 #include "libm_exact.h"
+#include "pose_exchange.h"
 
 namespace hsm {
 
@@ -124,10 +125,50 @@ struct MatchParams {
   unsigned spec_stride;    // float4s per scan
   SpecStats* spec_stats;   // nullptr, or counters the stitching pass adds to (hsm_debug_spec_stats)
   int n_bound;             // HOST ONLY: 0 = scan lengths live on the device only (max_n is a hint), else no scan is longer than this
+  ExchangeFused xp;        // world > 0: this launch posts its poses into an exchange and unpacks an earlier epoch (forms that support
+                           // it say so by setting hsm_ctx::fused_exchange_done; the others leave both to a launch of pose_exchange.hip)
 };
 
 __device__ __forceinline__ void publish_done(const MatchParams& P) {
   if (P.done_flag) __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- a matcher launch that takes part in the pose exchange itself (MatchParams::xp, pose_exchange.h) -------------------------------
+// POST: the wavefront that has just finished scan `row` stores its pose -- three 8-byte {value, epoch tag} granules per rank, one
+// system-scope store each (global_store_dwordx2 sc0 sc1), lanes 0 .. 3 world - 1 in ONE instruction -- into every rank's mailbox.
+__device__ __forceinline__ void exchange_post_pose(const ExchangeFused& X, int row, float x, float y, float th) {
+  const int l = (int)(threadIdx.x & 63u);
+  if (l < 3 * X.world) {
+    const int p = l / 3, c = l - 3 * p;
+    const float v = c == 0 ? x : (c == 1 ? y : th);
+    uint64_t* dst = X.peer[p] + X.post_off + (size_t)row * 3 + c;
+    __hip_atomic_store(dst, ((uint64_t)X.post_tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// WAIT + unpack: workgroup `wb` of the `X.wait_blocks` extra workgroups behind the matcher's own (they are dispatched as those
+// retire, i.e. into the launch's tail, when the epoch they wait for -- one match back -- has long arrived); bounded like the
+// stand-alone kernel's wait (pose_exchange.hip)
+__device__ __forceinline__ void exchange_wait_unpack(const ExchangeFused& X, int wb) {
+  const uint64_t* box = X.peer[X.rank] + X.wait_off;
+  unsigned long long t0 = 0;
+  for (int i = wb * (int)blockDim.x + (int)threadIdx.x; i < X.total_granules; i += X.wait_blocks * (int)blockDim.x) {
+    uint64_t g = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool late = false;
+    while ((uint32_t)(g >> 32) != X.wait_tag) {
+      if (t0 == 0) t0 = wall_clock64() | 1ull;
+      __builtin_amdgcn_s_sleep(4);
+      g = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((uint32_t)(g >> 32) != X.wait_tag && wall_clock64() - t0 > X.timeout_ticks) {
+        late = true;
+        break;
+      }
+    }
+    if (late) {
+      __hip_atomic_fetch_add(X.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(X.status + 1, X.wait_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (X.out) X.out[i] = __uint_as_float(late ? 0x7fc00000u : (uint32_t)g);
+  }
 }
 
 // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md; used for speed only -- any placement is

@@ -967,7 +967,7 @@ int hsm_last_launch_config(const hsm_ctx* h, int cfg[5]) {
 
 static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
                                      const int* d_scan_offsets, int shared_n, float* d_out_pose,
-                                     float* d_out_cov, void* stream, int n_bound = 0) {
+                                     float* d_out_cov, void* stream, int n_bound = 0, const ExchangeFused* xp = nullptr) {
   if (batch < 0 || !d_begin_world || !d_out_pose || (!d_scan_offsets && shared_n < 0))
     return fail(HSM_ERR_INVALID, "hsm_match_batch_device: bad argument");
   if (batch == 0) return HSM_OK;
@@ -984,6 +984,8 @@ static int match_batch_device_nolock(hsm_ctx* h, int batch, const float* d_begin
   P.out_cov = d_out_cov;
   // a true bound of the scan lengths, where the host has one: a shared scan's length, or what the caller computed from host offsets
   P.n_bound = d_scan_offsets ? n_bound : shared_n;
+  if (xp) P.xp = *xp;
+  h->fused_exchange_done = false;
   // workgroup -> XCD mapping (gn_match.h, xcd_block): chunks dealt to the XCDs in turn balance the data-dependent
   // per-scan time; maps whose touched region outgrows the L2s keep one contiguous eighth of the batch per XCD
   P.xcd_chunk = h->levels[0].cells() <= ((size_t)1 << 23) ? h->xcd_chunk : 0;
@@ -1027,6 +1029,26 @@ int hsm_match_batch_device(hsm_ctx* h, int batch, const float* d_begin_world, co
   std::lock_guard<std::mutex> lk(h->mu);
   return match_batch_device_nolock(h, batch, d_begin_world, d_pts_xy, d_scan_offsets, shared_n, d_out_pose,
                                    d_out_cov, stream);
+}
+
+int hsm_match_batch_device_gather(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
+                                  const int* d_scan_offsets, int shared_n, float* d_out_pose, float* d_out_cov,
+                                  hsm_exchange* x, int first_row, int lag, float* d_out_all, void* stream) {
+  if (!h || !x) return fail(HSM_ERR_INVALID, "null context / exchange");
+  if (batch <= 0) return fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: every rank posts a non-empty shard");
+  std::lock_guard<std::mutex> lk(h->mu);
+  // The exchange step of this match: carried by the matcher launch itself where the form can (the exact-order batch forms: every
+  // wavefront posts its pose from the kernel's epilogue, extra workgroups at the end of the grid unpack the epoch `lag` matches
+  // back -- no launch of its own, nothing between two matcher launches), else one launch of the stand-alone exchange kernel behind it.
+  ExchangeFused f;
+  if (int rc = hsm_host::exchange_fused_begin(x, first_row, batch, lag, d_out_all, &f)) return rc;
+  if (int rc = match_batch_device_nolock(h, batch, d_begin_world, d_pts_xy, d_scan_offsets, shared_n, d_out_pose, d_out_cov, stream, 0, &f))
+    return rc;
+  if (h->fused_exchange_done) {
+    hsm_host::exchange_fused_commit(x, f);
+    return HSM_OK;
+  }
+  return hsm_exchange_post_wait(x, d_out_pose, first_row, batch, lag, d_out_all, stream);
 }
 
 int hsm_match_batch(hsm_ctx* h, int batch, const float* begin_world, const float* pts_xy,

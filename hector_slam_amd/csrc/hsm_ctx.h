@@ -192,6 +192,7 @@ struct hsm_ctx {
   // up to 1024, reset by the first exchange that completes) -- on a device another process keeps busy every dense match would
   // otherwise pay the full bounded wait, a host spin and a second launch (round-5 advisor)
   unsigned coop_skip = 0, coop_backoff = 0;
+  bool fused_exchange_done = false;  // the last launch_match carried MatchParams::xp itself (else the caller launches the exchange step)
   int last_parity = HSM_PARITY_FAST;  // the mode the last match launch actually ran in (hsm_last_launch_parity)
 };
 

@@ -14,7 +14,13 @@ namespace {
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
 template <int NS, int BPL, int BPC = BPL, bool CW = false>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
-  const int grid = (P.batch + NS - 1) / NS, block = 64 * (NS + (CW ? 1 : 0));
+  int grid = (P.batch + NS - 1) / NS;
+  const int block = 64 * (NS + (CW ? 1 : 0));
+  if (P.xp.world > 0) {  // this launch carries the pose exchange: every scan posts its pose, the workgroups behind the matcher's own unpack
+    P.xp.match_blocks = grid;
+    grid += P.xp.wait_blocks;
+    h->fused_exchange_done = true;
+  }
   // workgroup -> XCD mapping: this form runs best with one contiguous eighth of the batch per XCD on every map size (2048^2
   // headline: 57.5 us against 58.3 with the fast form's chunks of 16 workgroups dealt in turn; chunks of 8 / 32: 58.4;
   // profiles/r04/exact_kernel_param_sweep.txt) -- its rounds are paced by barriers and chain jobs, not by how long a scan's

@@ -63,4 +63,18 @@ HSM_XHD inline bool exchange_post_is_safe(uint64_t epoch, uint64_t waited, int d
   return epoch <= waited + 1 + lag_max;
 }
 
+// What a matcher launch needs to take part in an exchange itself (MatchParams::xp; world == 0: it does not): its epilogue posts every
+// scan's pose to every rank's mailbox, and `wait_blocks` extra workgroups at the end of its grid -- dispatched as the matcher's own
+// workgroups retire -- wait for an earlier epoch and unpack it.  No launch of its own for the exchange at all.
+struct ExchangeFused {
+  uint64_t* peer[kExchangeMaxWorld];  // every rank's mailbox as mapped in this process
+  float* out;                         // [total_rows][cols] of the waited epoch, or nullptr
+  unsigned* status;                   // pinned host words (timeouts)
+  unsigned long long post_off;        // first granule of the posted epoch's buffer + first_row * cols
+  unsigned long long wait_off;        // first granule of the waited epoch's buffer
+  unsigned long long timeout_ticks;
+  unsigned post_tag, wait_tag;        // low words of the epochs (wait_blocks == 0: nothing to wait for)
+  int world, rank, cols, total_granules, match_blocks, wait_blocks;
+};
+
 }  // namespace hsm

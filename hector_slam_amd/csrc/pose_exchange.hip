@@ -287,6 +287,53 @@ int hsm_exchange_post_wait(hsm_exchange* x, const float* d_rows, int first_row, 
   return HSM_OK;
 }
 
+}  // extern "C"
+
+// ---- a matcher launch that carries the exchange itself (gn_match.h: exchange_post_pose / exchange_wait_unpack) ---------------------
+// begin: what post_wait would launch, as the arguments a matcher kernel needs (epochs NOT advanced yet); commit: the matcher
+// launch that took them has been queued on `stream`.  A matcher form that cannot carry them leaves the step to hsm_exchange_post_wait.
+int hsm_host::exchange_fused_begin(hsm_exchange* x, int first_row, int n_rows, int lag, float* d_out_all, hsm::ExchangeFused* out) {
+  if (!x || !out) return hsm_host::fail(HSM_ERR_INVALID, "null exchange");
+  std::lock_guard<std::mutex> lk(x->mu);
+  if (!x->connected) return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: exchange not connected");
+  if (x->lay.cols != 3) return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: the exchange must carry 3-float rows (poses)");
+  if (lag < 0 || exchange_min_depth(lag) > x->lay.depth)
+    return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: lag needs a mailbox of depth >= 2 + 2 lag");
+  if (n_rows < 0 || first_row < 0 || (long long)first_row + n_rows > x->lay.total_rows)
+    return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: rows outside the gathered array");
+  const unsigned long long e = x->posted + 1;
+  unsigned long long w = e > (unsigned long long)lag ? e - (unsigned long long)lag : 0;
+  if (w <= x->waited) w = 0;
+  if (w != 0 && w != x->waited + 1)
+    return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: waits must follow each other");
+  if (!exchange_post_is_safe(e, w ? w - 1 : x->waited, x->lay.depth))
+    return hsm_host::fail(HSM_ERR_INVALID, "hsm_match_batch_device_gather: too far ahead of this rank's waits for the mailbox depth");
+  memset(out, 0, sizeof *out);
+  for (int r = 0; r < x->lay.world; ++r) out->peer[r] = x->peer[r];
+  out->out = d_out_all;
+  out->status = x->status;
+  out->post_off = x->lay.buffer_of(e) + (unsigned long long)first_row * 3ull;
+  out->wait_off = w ? x->lay.buffer_of(w) : 0;
+  out->timeout_ticks = x->timeout_ticks;
+  out->post_tag = (unsigned)e;
+  out->wait_tag = (unsigned)w;
+  out->world = x->lay.world;
+  out->rank = x->rank;
+  out->cols = 3;
+  out->total_granules = (int)x->lay.buffer_granules();
+  out->wait_blocks = w ? (int)((x->lay.buffer_granules() + 1023) / 1024) : 0;
+  if (out->wait_blocks > 64) out->wait_blocks = 64;
+  return HSM_OK;
+}
+
+void hsm_host::exchange_fused_commit(hsm_exchange* x, const hsm::ExchangeFused& f) {
+  std::lock_guard<std::mutex> lk(x->mu);
+  x->posted += 1;
+  if (f.wait_blocks > 0) x->waited += 1;
+}
+
+extern "C" {
+
 int hsm_exchange_epochs(const hsm_exchange* x, unsigned long long* posted, unsigned long long* waited) {
   if (!x) return hsm_host::fail(HSM_ERR_INVALID, "null exchange");
   if (posted) *posted = x->posted;

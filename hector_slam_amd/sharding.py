@@ -168,6 +168,19 @@ class DirectRowGather:
         if lands:
             self.landed = w
 
+    def match_and_launch(self, matcher, batch, d_begin, d_pts, d_offsets, shared_n, d_out_cov=0, stream=None) -> None:
+        """the matcher launch of this batch AND its exchange step in one call (hsm_match_batch_device_gather): the poses go into
+        next_local(); where the matcher form can, the launch posts them itself and unpacks the batch `lag` back in its tail"""
+        s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+        e = self.launched + 1
+        w = e - self.lag
+        lands = w >= 1 and w > self.landed
+        matcher.match_batch_device_gather(batch, d_begin, d_pts, d_offsets, shared_n, self.local.data_ptr(), d_out_cov, self.x, self.first_row,
+                                          self.lag, self.out[w % 2].data_ptr() if lands else 0, s)
+        self.launched = e
+        if lands:
+            self.landed = w
+
     def drain(self, stream=None) -> None:
         """wait (on the stream) for every posted batch"""
         s = (stream if stream is not None else torch.cuda.current_stream()).cuda_stream

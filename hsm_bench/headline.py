@@ -120,7 +120,12 @@ def headline(args):
             gatherer = None
         run.gather_mode = mode
 
+        fused = mode == "direct" and os.environ.get("HSM_BENCH_UNFUSED_EXCHANGE") != "1"
+
         def step():
+            if fused:  # ONE call: the matcher launch carries the exchange step (hsm_match_batch_device_gather)
+                gatherer.match_and_launch(matcher, B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS, d_cov.data_ptr(), stream)
+                return
             pose_buf = gatherer.next_local() if gatherer else d_pose
             matcher.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS,
                                        pose_buf.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
@@ -179,7 +184,8 @@ def headline(args):
             if mode == "direct":
                 torch.cuda.synchronize()
                 gatherer.check()  # a wait that timed out fails the run here
-                run.ranks.update({"gather": "direct: hsm_exchange post + lagged wait, ONE per batched match, no collective on the data path",
+                run.ranks.update({"gather": "direct: hsm_exchange post + lagged wait, ONE per batched match, no collective on the data path; "
+                                            + ("carried by the matcher launch itself (epilogue posts, tail workgroups unpack)" if fused else "one small kernel behind every matcher launch"),
                                   "gathers_total": gatherer.launched, "collectives_total": gatherer.collectives,
                                   "mailbox_memory": gatherer.x.memory_kind()})
             elif gatherer:
@@ -308,8 +314,8 @@ def headline(args):
         # beside the contract line (one gather per batched match), labelled: the bucketed RCCL collective of round 5, a collective per
         # match, and no exchange at all -- same launches, same timing bracket (a leg that fails leaves its error, not the line)
         gather_legs = {}
-        for name, gm, bucket in (("no_gather", "none", None), ("rccl_bucketed", "rccl", args.gather_bucket), ("rccl_per_match", "rccl", 1),
-                                 ("direct_per_match", "direct", None)):
+        for name, gm, bucket in (("no_gather", "none", None), ("direct_separate_launch", "direct_unfused", None),
+                                 ("rccl_bucketed", "rccl", args.gather_bucket), ("rccl_per_match", "rccl", 1), ("direct_per_match", "direct", None)):
             if gm == headline_gather and (bucket is None or bucket == args.gather_bucket):
                 continue
             if gm == "rccl" and os.environ.get("HSM_BENCH_SHARE_GPU") == "1" and name == "rccl_per_match":
@@ -318,6 +324,9 @@ def headline(args):
             try:
                 if bucket is not None:
                     args.gather_bucket = bucket
+                if gm == "direct_unfused":  # the same exchange as its own small kernel behind every matcher launch
+                    os.environ["HSM_BENCH_UNFUSED_EXCHANGE"] = "1"
+                    gm = "direct"
                 dtl, kl, _ = run(matcher, d_in, args.steps, 3, gather=gm, repeats=min(args.repeats, 3))
                 gather_legs[name] = {"value": total * its * args.steps / dtl, "ms_per_step": dtl / args.steps * 1e3, "kernel_ms": kl,
                                      **({"matches_per_collective": bucket} if bucket else {})}
@@ -325,6 +334,7 @@ def headline(args):
                 gather_legs[name] = {"error": str(e)[:200]}
             finally:
                 args.gather_bucket = keep
+                os.environ.pop("HSM_BENCH_UNFUSED_EXCHANGE", None)
         d_pose.copy_(torch.from_numpy(gpu_pose))
     sustained = None
     if rank == 0 and world == 1 and not multi and args.sustain_s > 0 and args.leg is None:

@@ -266,6 +266,14 @@ int hsm_exchange_post(hsm_exchange* x, const float* d_rows, int first_row, int n
 int hsm_exchange_wait(hsm_exchange* x, float* d_out_all, void* stream);
 int hsm_exchange_post_wait(hsm_exchange* x, const float* d_rows, int first_row, int n_rows, int lag, float* d_out_all,
                            void* stream);
+/* hsm_match_batch_device + one exchange step of its poses (post this rank's `batch` rows at `first_row`, wait for the epoch `lag`
+ * matches back into d_out_all or NULL) as ONE call: where the matcher form can, the launch carries the exchange itself -- every
+ * wavefront posts its pose from the kernel's epilogue and a few extra workgroups at the end of the grid unpack -- so nothing at all
+ * runs between two matcher launches; otherwise the stand-alone exchange kernel is queued behind the matcher.  Same epochs, same
+ * mailbox contents either way (hsm_exchange_wait drains what is still in flight). */
+int hsm_match_batch_device_gather(hsm_ctx* h, int batch, const float* d_begin_world, const float* d_pts_xy,
+                                  const int* d_scan_offsets, int shared_n, float* d_out_pose, float* d_out_cov,
+                                  hsm_exchange* x, int first_row, int lag, float* d_out_all, void* stream);
 int hsm_exchange_epochs(const hsm_exchange* x, unsigned long long* posted, unsigned long long* waited);
 int hsm_exchange_status(hsm_exchange* x);
 /* "uncached" or "fine-grained": the kind of device memory the mailbox got */

@@ -215,3 +215,48 @@ def test_direct_gather_behind_the_matcher(pyramid_scene):
     gat.close()
     g.close()
     assert want.shape == (B, 3)
+
+
+@pytest.mark.parametrize("B", [16, 4096, 5000])
+def test_matcher_launch_that_carries_the_exchange(B):
+    """hsm_match_batch_device_gather: the exact-order batch forms post every scan's pose from the kernel's epilogue and unpack the batch
+    before in extra workgroups at the end of the grid -- no launch of their own for the exchange.  Gathered poses == the matcher's
+    poses, bit for bit, batch after batch, for the chain-wavefront form (16 scans), the headline form (4096) and a launch that
+    splits off its part-filled last generation (5000: two launches post, one unpacks); the stand-alone kernel gives the same"""
+    import torch
+    from hector_slam_amd import capi, sharding, synth
+    sc = synth.make_scene(n_beams=1081, map_size=512, levels=3, resolution=0.05, n_build=40, n_query=16, room=(20.0, 15.0), seed=99)
+    g = capi.MapRepMultiMap(sc.resolution, sc.map_size, sc.map_size, sc.levels, device=0)
+    g.setUpdateFactorFree(0.4)
+    g.setUpdateFactorOccupied(0.9)
+    g.build_map(sc.build_poses, sc.build_scans)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, len(sc.query_scans), B)
+    pts, offs = synth.pack_scans([sc.query_scans[i] for i in idx])
+    dev = torch.device("cuda", 0)
+    d_pts, d_offs = torch.from_numpy(pts).to(dev), torch.from_numpy(offs).to(dev)
+    gat = sharding.DirectRowGather(B, 3, dev, lag=1)
+    plain = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+    seen = []
+    for k in range(6):
+        init = sc.query_init[idx].copy()
+        init[:, :2] += rng.uniform(-0.03, 0.03, (B, 2)).astype(np.float32)
+        d_init = torch.from_numpy(init).to(dev)
+        g.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 1081, plain.data_ptr(), 0, stream.cuda_stream)
+        seen.append(plain.cpu().numpy().copy())
+        if k % 3 == 2:  # every third batch through the stand-alone kernel: the two forms share the epochs
+            g.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 1081, gat.next_local().data_ptr(), 0, stream.cuda_stream)
+            gat.launch(stream)
+        else:
+            gat.match_and_launch(g, B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 1081, 0, stream)
+            assert g.last_launch_config()["kernel"].startswith("gn_match_exact_cached_kernel"), g.last_launch_config()
+        assert np.array_equal(bits(gat.next_local().cpu().numpy()), bits(seen[-1])), k  # the local rows are the matcher's
+        if gat.landed:
+            assert np.array_equal(bits(gat.out[gat.landed % 2].cpu().numpy()), bits(seen[gat.landed - 1])), (k, gat.landed)
+    assert np.array_equal(bits(gat.last_result().cpu().numpy()), bits(seen[-1]))
+    torch.cuda.synchronize()
+    gat.check()
+    assert gat.x.epochs() == (6, 6)
+    gat.close()
+    g.close()
