@@ -145,8 +145,9 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
   static_assert(sizeof(sm.stage) < 65536, "stage rows are addressed through M0[15:0]");
   // a launch that takes part in the pose exchange (MatchParams::xp): the workgroups behind the matcher's own wait for an earlier
   // epoch and unpack it -- no registers, no LDS, no barrier of the matcher's are touched
-  const int match_blocks = P.xp.world > 0 ? P.xp.match_blocks : (int)gridDim.x;
-  if ((int)blockIdx.x >= match_blocks) {
+  // (the four-producer forms only: the chain-wavefront forms sit exactly on the register budget their placement on a CU needs)
+  const int match_blocks = (!CW && P.xp.world > 0) ? P.xp.match_blocks : (int)gridDim.x;
+  if (!CW && (int)blockIdx.x >= match_blocks) {
     exchange_wait_unpack(P.xp, (int)blockIdx.x - match_blocks);
     return;
   }
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
   __syncthreads();
   const int nmax = nmax_s;  // workgroup-uniform
   if (nmax == 0) {          // nothing but empty scans
-    if (active && P.xp.world > 0) exchange_post_pose(P.xp, scan, b0, b1, b2);
+    if (!CW && active && P.xp.world > 0) exchange_post_pose(P.xp, scan, b0, b1, b2);
     if (active && lane == 0) {
       P.out_pose[3 * scan + 0] = b0;
       P.out_pose[3 * scan + 1] = b1;
@@ -703,7 +704,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
 #ifdef HSM_XTIMELINE_WG
   if (P.clock_probe != nullptr && wave == 0 && lane == 0) P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 1] = wall_clock64();
 #endif
-  if (active && P.xp.world > 0) exchange_post_pose(P.xp, scan, n == 0 ? b0 : pw0, n == 0 ? b1 : pw1, n == 0 ? b2 : pw2);
+  if (!CW && active && P.xp.world > 0) exchange_post_pose(P.xp, scan, n == 0 ? b0 : pw0, n == 0 ? b1 : pw1, n == 0 ? b2 : pw2);
   if (active && lane == 0) {
     const bool empty = n == 0;
     P.out_pose[3 * scan + 0] = empty ? b0 : pw0;

@@ -16,7 +16,8 @@ template <int NS, int BPL, int BPC = BPL, bool CW = false>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   int grid = (P.batch + NS - 1) / NS;
   const int block = 64 * (NS + (CW ? 1 : 0));
-  if (P.xp.world > 0) {  // this launch carries the pose exchange: every scan posts its pose, the workgroups behind the matcher's own unpack
+  if (CW) P.xp.world = 0;  // (the chain-wavefront forms do not carry it: the caller queues the stand-alone exchange kernel)
+  if (P.xp.world > 0) {    // this launch carries the pose exchange: every scan posts its pose, the workgroups behind the matcher's own unpack
     P.xp.match_blocks = grid;
     grid += P.xp.wait_blocks;
     h->fused_exchange_done = true;

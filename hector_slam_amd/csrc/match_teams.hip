@@ -69,10 +69,10 @@ int launch_match_exact(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t 
       B.out_pose = P.out_pose + 3 * (size_t)A.batch;
       if (P.out_cov) B.out_cov = P.out_cov + 9 * (size_t)A.batch;
       B.clock_probe = nullptr;  // (scan 0's probe belongs to the first launch)
-      if (P.xp.world > 0) {     // a launch that carries the pose exchange: both parts post their own rows, the second one unpacks
-        A.xp.wait_blocks = 0;
-        B.xp.post_off += 3ull * (unsigned long long)A.batch;
-      }
+      // (a launch that carries the pose exchange: the part-filled last generation runs in a chain-wavefront form, which does not --
+      // so the whole step is left to the stand-alone exchange kernel behind both launches)
+      A.xp.world = 0;
+      B.xp.world = 0;
       if (int rc = launch_match_exact_cached_forms(h, A, max_n, stream)) return rc;
       const int grid_a = h->last_cfg[3];
       if (int rc = launch_match_exact_cached_forms(h, B, max_n, stream)) return rc;

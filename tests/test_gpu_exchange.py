@@ -221,8 +221,9 @@ def test_direct_gather_behind_the_matcher(pyramid_scene):
 def test_matcher_launch_that_carries_the_exchange(B):
     """hsm_match_batch_device_gather: the exact-order batch forms post every scan's pose from the kernel's epilogue and unpack the batch
     before in extra workgroups at the end of the grid -- no launch of their own for the exchange.  Gathered poses == the matcher's
-    poses, bit for bit, batch after batch, for the chain-wavefront form (16 scans), the headline form (4096) and a launch that
-    splits off its part-filled last generation (5000: two launches post, one unpacks); the stand-alone kernel gives the same"""
+    poses, bit for bit, batch after batch, for the headline form (4096 scans: the launch carries the exchange), the chain-wavefront
+    form (16 scans) and a launch that splits off its part-filled last generation (5000) -- those two leave the step to the
+    stand-alone kernel behind them, through the same call; mixing both kinds of step shares the epochs"""
     import torch
     from hector_slam_amd import capi, sharding, synth
     sc = synth.make_scene(n_beams=1081, map_size=512, levels=3, resolution=0.05, n_build=40, n_query=16, room=(20.0, 15.0), seed=99)
