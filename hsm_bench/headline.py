@@ -388,7 +388,7 @@ def headline(args):
         cpu_thread.join()
     pmc = (pmc_all or {}).get(kernel_name)
     rf = roofline_block(kernel_name, kern_ms, bytes_per_launch, N_BEAMS, its, B, pmc, pmc_err, clock_hz,
-                        sclk_hz=headline_sclk, committed_profile="r05")
+                        sclk_hz=headline_sclk, committed_profile="r06")
     if cfg.get("parity_effective") == "exact":
         rf["what_binds"] = ("VALU instruction issue plus the serial chain jobs of the reference's summation order (gn_match_exact.h): one "
                             "workgroup barrier per 64-beam round, a 64-deep dependent fp32 chain behind it; texels and endpoints "
