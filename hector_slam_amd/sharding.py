@@ -208,6 +208,47 @@ class DirectRowGather:
         self.x.close()
 
 
+def make_row_gather(total_rows: int, rows_per_rank: int, cols: int, device, lag: int = 1, fallback_bucket: int = 1, group=None):
+    """The gather a sharded run should use on THIS machine: the device-side exchange (DirectRowGather) if every rank can set it up
+    AND a self-test epoch of known rows arrives intact on every rank; else a torch.distributed all-gather (BucketedRowGather) --
+    decided collectively, so that all ranks take the same transport.  Returns (gatherer, "direct" | "rccl", note).  The self-test is
+    what stands between a topology this code has not seen (IPC mapping of uncached memory refused, no peer path between two
+    devices, stores that do not become visible to a polling kernel) and a run that hangs or gathers garbage: such a machine gets the
+    collective, and the note says why."""
+    ok, note, g = True, "", None
+    try:
+        g = DirectRowGather(total_rows, cols, device, lag=lag, group=group)
+        probe = torch.arange(g.rows * cols, dtype=torch.float32, device=g.local.device).reshape(g.rows, cols) + 1000.0 * (g.rank + 1)
+        g.next_local().copy_(probe)
+        g.launch()
+        g.drain()
+        torch.cuda.synchronize()
+        g.check()
+        got = g.out[g.landed % 2]
+        for r in range(g.world):
+            b, e = shard_bounds(total_rows, r, g.world)
+            want = torch.arange((e - b) * cols, dtype=torch.float32, device=got.device).reshape(e - b, cols) + 1000.0 * (r + 1)
+            if not torch.equal(got[b:e], want):
+                ok, note = False, f"self-test: the rows of rank {r} did not arrive intact on rank {g.rank}"
+                break
+    except Exception as exc:  # set-up or self-test failed on this rank
+        ok, note = False, f"{type(exc).__name__}: {str(exc)[:200]}"
+    if dist.is_available() and dist.is_initialized():
+        flags = [None] * dist.get_world_size(group)
+        dist.all_gather_object(flags, (ok, note), group=group)
+        bad = [(r, n) for r, (o, n) in enumerate(flags) if not o]
+        if bad:
+            ok, note = False, "; ".join(f"rank {r}: {n}" for r, n in bad[:3])
+    if ok:
+        return g, "direct", ""
+    if g is not None:
+        try:
+            g.close()
+        except Exception:
+            pass
+    return BucketedRowGather(rows_per_rank, cols, device, bucket=fallback_bucket, group=group), "rccl", "device-side exchange unavailable (" + note + ")"
+
+
 class BucketedRowGather:
     """The same gather, BUCKETED: the rows of ``bucket`` consecutive batches travel in ONE all-gather.
 

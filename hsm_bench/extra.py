@@ -373,7 +373,13 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
     d_cov = torch.zeros((B, 9), dtype=torch.float32, device=dev)
 
     # N > 1: ONE gather per batched match through the device-side exchange (--gather direct, the default), as the headline path
-    direct = sharding.DirectRowGather(B * nranks, 3, dev, lag=1) if nranks > 1 and args.gather == "direct" else None
+    direct, gather_note = None, ""
+    if nranks > 1 and args.gather == "direct":  # (collective decision + self-test; a machine that cannot run it gets the collective)
+        g0, kind, gather_note = sharding.make_row_gather(B * nranks, B, 3, dev, lag=1, fallback_bucket=args.gather_bucket)
+        if kind == "direct":
+            direct = g0
+        else:
+            args.gather = "rccl"
 
     def timed(steps, warmup):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -421,7 +427,8 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         if nranks > 1:
             timed.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
             timed.ranks["gather"] = ("direct: hsm_exchange, one per batched match, no collective on the data path" if direct is not None else
-                                     f"{args.gather}" + (f", {args.gather_bucket} matches per collective" if args.gather == "rccl" else ""))
+                                     f"{args.gather}" + (f", {args.gather_bucket} matches per collective" if args.gather == "rccl" else "") +
+                                     (f" -- FALLBACK: {gather_note[:200]}" if gather_note else ""))
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())

@@ -91,7 +91,8 @@ def headline(args):
     def direct_gatherer():
         """one exchange per process (its set-up is a collective over the process group): reused by every timed run"""
         if "g" not in _direct:
-            _direct["g"] = sharding.DirectRowGather(total, 3, dev, lag=1)
+            # (collective decision + self-test: a machine on which the exchange cannot be set up gets the RCCL gather, labelled)
+            _direct["g"], _direct["kind"], _direct["note"] = sharding.make_row_gather(total, B, 3, dev, lag=1, fallback_bucket=args.gather_bucket)
         return _direct["g"]
 
     def run(matcher, d_init, steps, warmup, gather=True, repeats=1):
@@ -114,6 +115,9 @@ def headline(args):
             # ONE gather per batched match, no collective: the exchange kernel behind every matcher launch posts this rank's
             # [B,3] rows into every rank's mailbox and unpacks the batch before (lag 1); drained inside the timed region
             gatherer = direct_gatherer()
+            if _direct["kind"] != "direct":  # this machine cannot run the exchange: the collective, and the line says so
+                mode = "rccl"
+                run.gather_note = _direct["note"]
         elif mode == "rccl":
             gatherer = sharding.BucketedRowGather(B, 3, dev, bucket=args.gather_bucket)
         else:
@@ -318,6 +322,8 @@ def headline(args):
                                  ("rccl_bucketed", "rccl", args.gather_bucket), ("rccl_per_match", "rccl", 1), ("direct_per_match", "direct", None)):
             if gm == headline_gather and (bucket is None or bucket == args.gather_bucket):
                 continue
+            if gm.startswith("direct") and _direct.get("kind") == "rccl":
+                continue  # (this machine could not set the exchange up: the headline already is the collective)
             if gm == "rccl" and os.environ.get("HSM_BENCH_SHARE_GPU") == "1" and name == "rccl_per_match":
                 continue  # (gloo stands in for RCCL there: one figure of it is enough)
             keep = args.gather_bucket
@@ -417,6 +423,8 @@ def headline(args):
         out["config"]["gather"] = {"direct": "ONE gather per batched match: device-side exchange (hsm_exchange_*), waits lag one match behind, drained inside the timed region",
                                    "rccl": f"torch.distributed all-gather, {args.gather_bucket} matches per collective",
                                    "none": "no exchange"}[headline_gather]
+        if _direct.get("note"):
+            out["config"]["gather"] += " -- FALLBACK: " + _direct["note"][:300]
         out["gather_legs"] = gather_legs
         if args.all_configs and not args.no_group and os.environ.get("HSM_BENCH_SHARE_GPU") != "1":
             # the C++ single-process group over the same devices, RCCL gather and peer gather (child of rank 0)

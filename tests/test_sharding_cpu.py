@@ -312,3 +312,39 @@ def test_group_child_handoff_does_not_hang():
         p.join(timeout=60)
     assert [r[1] for r in res] == [True, True], res
     assert all(0.5 < r[2] < 30 for r in res), res  # rank 1 waited for the child, nobody waited for a timeout
+
+
+def _worker_fallback(rank, world, port, q):
+    """make_row_gather where the device-side exchange cannot be set up (no HIP device here): every rank must settle on the
+    collective -- collectively -- say why, and still gather correctly"""
+    sys.path.insert(0, ROOT)
+    from hector_slam_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = 5
+        g, kind, note = sharding.make_row_gather(world * rows, rows, 3, "cpu", lag=1, fallback_bucket=2)
+        ok = kind == "rccl" and isinstance(g, sharding.BucketedRowGather) and "unavailable" in note and "rank 0" in note
+        for k in range(3):
+            g.next_local().copy_(torch.full((rows, 3), float(10 * k + rank)))
+            g.launch()
+        out = g.last_result()
+        exp = torch.cat([torch.full((rows, 3), float(20 + r)) for r in range(world)])
+        q.put((rank, bool(ok and torch.equal(out, exp)), note[:120]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_selection_falls_back_to_the_collective_on_every_rank():
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: the exchange sets up (tests/test_gpu_exchange.py covers it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fallback, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True], res
