@@ -326,4 +326,271 @@ __global__ void __launch_bounds__(1024) gn_match_spec_kernel(const MatchParams P
   }
 }
 
+// ---- the same idea for ONE scan of the node's size (<= 2048 beams), everything on chip (round 6) ------------------------------------
+// The ROS node's matchData is a single 1081-beam scan: 14 GN steps x 1081 dependent additions x 8.5 cycles = 54 of the 87 us the
+// exact team form takes.  Here the products of a step never leave the CU: 16 wavefronts produce them into LDS (endpoints resident in
+// registers across all levels and steps, read ONCE -- straight from pinned host memory -- like the team form's), then wavefront c
+// = chain c: lane L loads ITS segment (m <= 32 consecutive products, spec::plan with G = 1) into registers, sums it for the
+// candidate carries (fp32 prefix over the lanes), runs the literal loop from its candidate with the shift summary, and the frontier
+// loop stitches: the boundary offsets e_L = f_{L-1} - c_L are prefix-summed ONCE per step (fp64, exact or flagged), so a pass of the
+// loop is a handful of per-lane operations, one ballot, and -- for the first segment that does not accept -- m dependent additions
+// fed by v_readlane from the owner lane's registers.  No global memory behind the texel gather.
+constexpr int kSpec1MaxBeams = 2048;
+constexpr int kSpec1Row = 64 * 33;  // floats per chain in LDS: 64 lanes x (m + 1), m <= 32 (odd stride: conflict-free column reads)
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(1024) gn_match_spec1_kernel(const MatchParams P) {
+  __shared__ float prod[9 * kSpec1Row];
+  __shared__ float totals[9];
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int scan = (int)blockIdx.x;
+  int beg = 0, n = P.shared_n;
+  if (P.offsets) {
+    beg = P.offsets[scan];
+    n = P.offsets[scan + 1] - beg;
+  }
+  float pw0, pw1, pw2;
+  if (P.begin_world) {
+    pw0 = P.begin_world[3 * scan + 0];
+    pw1 = P.begin_world[3 * scan + 1];
+    pw2 = P.begin_world[3 * scan + 2];
+  } else {
+    pw0 = P.begin_inline[0];
+    pw1 = P.begin_inline[1];
+    pw2 = P.begin_inline[2];
+  }
+  if (n == 0 || n > kSpec1MaxBeams) {  // empty: ScanMatcher.h:68,189; too long: the host never sends it here -- refuse loudly
+    if (tid == 0) {
+      const float nan = __uint_as_float(0x7fc00000u);
+      P.out_pose[3 * scan + 0] = n == 0 ? pw0 : nan;
+      P.out_pose[3 * scan + 1] = n == 0 ? pw1 : nan;
+      P.out_pose[3 * scan + 2] = n == 0 ? pw2 : nan;
+      if (scan == 0) publish_done(P);
+    }
+    return;
+  }
+  const spec::Plan pl = spec::plan(n);  // G == 1 for n <= 2048
+  const int m = pl.m, lanes = pl.lanes, ms = m + 1;
+  const float2* __restrict__ pts = P.pts + beg;
+  // this lane's (up to two) beams: endpoint, and where its products go -- fixed for the whole match
+  float2 q0 = make_float2(1.0e30f, 1.0e30f), q1 = q0;
+  int off0 = -1, off1 = -1;
+  {
+    const int i0 = tid, i1 = tid + 1024;
+    if (i0 < n) {
+      q0 = pts[i0];
+      const int L = i0 / m;
+      off0 = L * ms + (i0 - L * m);
+    }
+    if (i1 < n) {
+      q1 = pts[i1];
+      const int L = i1 / m;
+      off1 = L * ms + (i1 - L * m);
+    }
+  }
+  // the padding of the last segment: +0 products, written once (no beam ever lands there)
+  for (int i = n + tid; i < lanes * m; i += 1024) {
+    const int L = i / m, o = L * ms + (i - L * m);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) prod[c * kSpec1Row + o] = 0.0f;
+  }
+  Acc9 acc;
+  acc.zero();
+  int step = 0;
+  for (int l = P.first_level; l >= P.last_level; --l) {
+    const LevelView& L = P.lv[l];
+    float ex, ey, eth;
+    affine_apply(L.mapTworld, pw0, pw1, ex, ey);
+    eth = pw2;
+    const float ps = L.pt_scale;
+    const int gn_steps = L.gn_steps;
+    const LevelRegs R = level_regs<LAYOUT>(L);
+    for (int it = 0; it < gn_steps; ++it) {
+      float sinRot, cosRot;
+      sincos_f32(eth, sinRot, cosRot);
+      const f2 e2 = step_origin(ex, ey), cs = f2{cosRot, sinRot}, sc = f2{sinRot, cosRot};
+      const bool probe = P.clock_probe != nullptr && tid == 0;
+      unsigned long long ts[8];
+      int iters = 0;
+      if (probe) ts[0] = __builtin_readcyclecounter();
+      // ---- production: the nine products of this lane's beams into LDS ---------------------------------------------------
+      if (off0 >= 0) {
+        BeamRot rot;
+        const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{q0.x * ps, q0.y * ps}, rot);
+        float pr[9];
+        beam_products(b, rot, pr);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) prod[c * kSpec1Row + off0] = pr[c];
+      }
+      if (off1 >= 0) {
+        BeamRot rot;
+        const BeamSample b = beam_fetch<LAYOUT>(R, e2, cs, sc, f2{q1.x * ps, q1.y * ps}, rot);
+        float pr[9];
+        beam_products(b, rot, pr);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) prod[c * kSpec1Row + off1] = pr[c];
+      }
+      __syncthreads();
+      if (probe) ts[1] = __builtin_readcyclecounter();
+      if (wave < 9) {
+        const int c = wave;
+        const bool live = lane < lanes;
+        // ---- this lane's segment into registers; its fp32 sum for the candidate carries --------------------------------------
+        float x[32];
+        const float* src = prod + c * kSpec1Row + lane * ms;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = (live && k < m) ? src[k] : 0.0f;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) s0 += x[k], s1 += x[k + 1], s2 += x[k + 2], s3 += x[k + 3];
+        float incl = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float up = __shfl_up(incl, o);
+          if (lane >= o) incl += up;
+        }
+        float cand = __shfl_up(incl, 1);
+        if (lane == 0) cand = 0.0f;  // the chain's own start: +0, the true carry
+        if (probe) ts[2] = __builtin_readcyclecounter();
+        // ---- the literal run from the candidate with its shift summary ---------------------------------------------------------
+        float run = cand;
+        spec::SegSummary S;
+        S.reset(run);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          if (k < m) {  // (wave-uniform)
+            const float before = run;
+            run = before + x[k];
+            spec::seg_step(S, before, x[k], run);
+          }
+        }
+        const float fin = run;
+        const spec::SegShifts sh = spec::seg_shifts(S);
+        const float inv = sh.unit != 0.0f ? 1.0f / sh.unit : 0.0f;  // a power of two: exact
+        // ---- boundary offsets e_L = f_{L-1} - c_L, prefix-summed once: E_L (fp64), and how many boundaries / additions up to L
+        // were not exact (a segment behind one of those, counted from the frontier, is re-run)
+        if (probe) ts[3] = __builtin_readcyclecounter();
+        bool e_exact = true;
+        float e_in = 0.0f;
+        {
+          const float pf = __shfl_up(fin, 1);
+          if (lane > 0) e_in = spec::seg_delta(pf, cand, &e_exact);
+        }
+        double E = (double)e_in;
+        int nbad = e_exact ? 0 : 1;  // -> boundaries up to this lane whose offset is not exact (counted from the frontier below)
+        int pois = 0;                // -> an addition of the scan itself was not exact: this lane's E is not to be used at all
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double uE = __shfl_up(E, o);
+          const int ub = __shfl_up(nbad, o);
+          const int up = __shfl_up(pois, o);
+          if (lane >= o) {
+            const double sum = E + uE;
+            const double bb = sum - E;
+            const double err = (E - (sum - bb)) + (uE - bb);
+            nbad += ub;
+            pois |= up | (err != 0.0 ? 1 : 0);
+            E = sum;
+          }
+        }
+        // ---- the frontier loop ---------------------------------------------------------------------------------------------------
+        if (probe) ts[4] = __builtin_readcyclecounter();
+        int F = 0;
+        float t = 0.0f;
+        float total = 0.0f;
+        for (;;) {
+          ++iters;
+          if (F >= lanes) {
+            total = t;
+            break;
+          }
+          bool d0_exact;
+          const float d0 = spec::seg_delta(t, spec_readlane(cand, F), &d0_exact);
+          const double EF = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(E), F), __builtin_amdgcn_readlane(__double2loint(E), F));
+          const int bF = __builtin_amdgcn_readlane(nbad, F);
+          const int pF = __builtin_amdgcn_readlane(pois, F);
+          // shift of lane L >= F under the hypothesis that everything from F on accepts: d0 + (E_L - E_F), every operation checked
+          double v;
+          bool okv = d0_exact && nbad == bF && pois == 0 && pF == 0;
+          {
+            const double a = E, b = -EF;
+            const double r = a + b;
+            const double bb = r - a;
+            const double err = (a - (r - bb)) + (b - bb);
+            okv = okv && err == 0.0;
+            const double a2 = r, b2 = (double)d0;
+            v = a2 + b2;
+            const double bb2 = v - a2;
+            const double err2 = (a2 - (v - bb2)) + (b2 - bb2);
+            okv = okv && err2 == 0.0;
+          }
+          const float d = (float)v;
+          const bool d_ok = okv && (double)d == v;
+          bool ok = d_ok && d == 0.0f;
+          if (d_ok && !ok && inv != 0.0f && d >= sh.lo && d <= sh.hi) {
+            const float qa = spec::u2f(spec::f2u(d * inv) & 0x7fffffffu);
+            ok = qa >= 8388608.0f ? qa < 3.0e38f : ((qa + 8388608.0f) - 8388608.0f) == qa;
+          }
+          const bool pending = lane >= F && lane < lanes;
+          const unsigned long long failing = __builtin_amdgcn_ballot_w64(pending && !ok);
+          const float shifted_end = fin + d;  // this segment's true end value if it (and everything before it) accepted
+          if (failing == 0ull) {
+            total = spec_readlane(shifted_end, lanes - 1);
+            break;
+          }
+          const int X = (int)__builtin_ctzll(failing);
+          float rr = X == F ? t : spec_readlane(shifted_end, X - 1);
+          // re-run segment X literally: its products sit in lane X's registers
+#pragma unroll
+          for (int k = 0; k < 32; ++k)
+            if (k < m) rr += spec_readlane(x[k], X);
+          t = rr;
+          F = X + 1;
+        }
+        if (lane == 0) totals[c] = total;
+        if (probe) ts[5] = __builtin_readcyclecounter();
+      }
+      __syncthreads();
+      if (probe) {
+        ts[6] = __builtin_readcyclecounter();
+        for (int kk = 0; kk < 7; ++kk) P.clock_probe[kk] = ts[kk];
+        P.clock_probe[7] = (unsigned long long)iters;
+      }
+      acc.d01 = f2{totals[0], totals[1]}; acc.d2 = totals[2];
+      acc.hd = f2{totals[3], totals[4]}; acc.h22 = totals[5];
+      acc.h01 = totals[6]; acc.hr = f2{totals[7], totals[8]};
+      gn_solve_and_step(acc, ex, ey, eth);
+      if (P.trace) {  // kernel-uniform; only the single-scan hook path sets it
+        if (scan == 0 && tid == 0) {
+          float* tr = P.trace + 12 * step;
+          tr[0] = ex; tr[1] = ey; tr[2] = eth;
+          tr[3] = acc.hd.x; tr[4] = acc.h01; tr[5] = acc.hr.x;
+          tr[6] = acc.h01; tr[7] = acc.hd.y; tr[8] = acc.hr.y;
+          tr[9] = acc.hr.x; tr[10] = acc.hr.y; tr[11] = acc.h22;
+        }
+        ++step;
+      }
+      // (the next step's production rewrites prod[] behind the barrier above: the chain wavefronts have had their segments in
+      // registers since before the frontier loop; totals[] is rewritten behind the next production barrier)
+    }
+    eth = normalize_angle(eth);
+    affine_apply(L.worldTmap, ex, ey, pw0, pw1);
+    pw2 = eth;
+  }
+  if (tid == 0) {
+    P.out_pose[3 * scan + 0] = pw0;
+    P.out_pose[3 * scan + 1] = pw1;
+    P.out_pose[3 * scan + 2] = pw2;
+    if (P.out_cov) {  // covMatrix = H of the last evaluation (ScanMatcher.h:184), column major
+      float* cc = P.out_cov + 9 * scan;
+      cc[0] = acc.hd.x; cc[1] = acc.h01; cc[2] = acc.hr.x;
+      cc[3] = acc.h01; cc[4] = acc.hd.y; cc[5] = acc.hr.y;
+      cc[6] = acc.hr.x; cc[7] = acc.hr.y; cc[8] = acc.h22;
+    }
+    if (scan == 0) publish_done(P);
+  }
+}
+
 }  // namespace hsm

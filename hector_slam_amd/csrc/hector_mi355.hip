@@ -348,6 +348,23 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
       (max_n <= 17 * 64 || (P.batch > h->compute_units && !(h->exact_dense && max_n >= h->exact_dense_min))))
     wps = 1;
   if (exact && wps > 1 && h->wps_override == 0 && h->exact_dense && max_n >= h->exact_dense_min) return launch_match_exact_dense(h, P, max_n, stream);
+  // one scan of the node's size through hsm_match, reference order: the on-chip speculative-carry form (gn_match_spec.h)
+  if (exact && wps > 1 && h->wps_override == 0 && h->exact_spec1 && P.batch == 1 && !P.begin_world && P.n_bound > 0 && max_n <= P.n_bound &&
+      max_n <= kSpec1MaxBeams) {
+    if (h->layout == kLayoutPlane)
+      hipLaunchKernelGGL((gn_match_spec1_kernel<kLayoutPlane>), dim3(1), dim3(1024), 0, stream, P);
+    else
+      hipLaunchKernelGGL((gn_match_spec1_kernel<kLayoutQuad>), dim3(1), dim3(1024), 0, stream, P);
+    HIP_TRY(hipGetLastError());
+    h->last_cfg[0] = h->layout;
+    h->last_cfg[1] = 16;
+    h->last_cfg[2] = 1024;
+    h->last_cfg[3] = 1;
+    h->last_cfg[4] = 0;
+    h->last_cfg[5] = 0;
+    h->last_kernel = "gn_match_spec1_kernel";
+    return HSM_OK;
+  }
   return launch_match_by_width(h, P, max_n, stream, exact, wps);
 }
 
@@ -762,6 +779,7 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
   if (const char* env = getenv("HSM_EXACT_CACHED")) h->exact_cached = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE")) h->exact_dense = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_SPEC")) h->exact_spec = atoi(env) != 0;
+  if (const char* env = getenv("HSM_EXACT_SPEC1")) h->exact_spec1 = atoi(env) != 0;
   if (const char* env = getenv("HSM_EXACT_DENSE_MIN")) h->exact_dense_min = atoi(env);
   if (const char* env = getenv("HSM_EXACT_CHAIN_WAVE")) h->exact_chain_wave = atoi(env);
   if (const char* env = getenv("HSM_EXACT_SPLIT_TAIL")) h->exact_split_tail = atoi(env);

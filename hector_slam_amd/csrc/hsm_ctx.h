@@ -178,6 +178,7 @@ struct hsm_ctx {
   int coop_mute_block = 0;      // hsm_debug_set_coop_mute (test hook)
   bool exact_spec = false;       // env HSM_EXACT_SPEC=1: one-workgroup-per-scan launches in exact order take the speculative-carry form (gn_match_spec.h:
                                  // the same bits; measured SLOWER than the literal chains on one CU -- DESIGN.md 8 -- hence opt-in)
+  bool exact_spec1 = false;      // env HSM_EXACT_SPEC1=1: ONE scan of up to 2048 beams (hsm_match) in exact order takes the on-chip speculative-carry form
   float* d_spec_scratch = nullptr;   // gn_match_spec_kernel: products of every beam, [batch][stride] float4s
   size_t spec_scratch_cap = 0;       // float4s
   SpecStats* d_spec_stats = nullptr; // hsm_debug_spec_stats

@@ -383,6 +383,58 @@ def test_speculative_carry_form_on_short_scans_and_many_poses(capi, oracle_mod, 
     g.close()
 
 
+@pytest.mark.parametrize("layout", ["quad", "plane"])
+def test_single_scan_on_chip_speculative_form(capi, oracle_mod, pyramid_scene, kind, layout, monkeypatch):
+    """HSM_EXACT_SPEC1=1: ONE scan of the node's size through hsm_match in the reference's order, the nine chains cut into (up to)
+    64 segments that live in the chain wavefronts' registers (gn_match_spec1_kernel): pose, covariance and every hook-trace record
+    bit-identical to the reference and to the team form, for lengths from 321 to 2048 beams (segment lengths 8 .. 32, ragged last
+    segments), near and far starts, single-level matches"""
+    import ctypes as C
+    from hector_slam_amd import synth
+    sc = pyramid_scene
+    o = make_oracle(oracle_mod, kind, sc)
+    lay = capi.LAYOUT_QUAD if layout == "quad" else capi.LAYOUT_PLANE
+    team = exact_gpu(capi, sc, o, layout=lay)
+    monkeypatch.setenv("HSM_EXACT_SPEC1", "1")
+    g = exact_gpu(capi, sc, o, layout=lay)
+    lib = capi.load_library()
+    s = float(np.float32(1.0) / np.float32(sc.resolution))
+    rng = np.random.default_rng(11)
+    for n_beams in (321, 512, 513, 720, 1080, 1081, 1082, 1500, 2047, 2048):
+        q = n_beams % len(sc.query_scans)
+        pts = synth.make_scan(sc.world, sc.query_truth[q], n_beams, s, rng, pad_to_full=True)
+        assert pts.shape[0] == n_beams
+        for k in range(2):
+            init = sc.query_init[q].copy()
+            init[:2] += rng.uniform(-0.08, 0.08, 2).astype(np.float32) * np.float32(k)
+            pg, cg = g.matchData(init, pts)
+            assert g.last_launch_config()["kernel"] == "gn_match_spec1_kernel", (n_beams, g.last_launch_config())
+            po, co = o.match(init, pts)
+            assert same(pg, po) and same(cg, co), (n_beams, k, "vs the reference")
+            pt, ct = team.matchData(init, pts)
+            assert same(pg, pt) and same(cg, ct), (n_beams, k, "vs the team form")
+        a = np.ascontiguousarray(pts, np.float32)
+        tr = {}
+        for name, ctx in (("spec1", g), ("team", team)):
+            pose, cov, trace, nst = np.zeros(3, np.float32), np.zeros(9, np.float32), np.zeros(14 * 12, np.float32), C.c_int(0)
+            capi._check(lib.hsm_match_trace(ctx._h, sc.query_init[q], a.ctypes.data, a.shape[0], np.zeros(2, np.float32), pose, cov, trace, 14,
+                                            C.byref(nst)), "hsm_match_trace")
+            assert nst.value == 14
+            tr[name] = (pose, cov, trace)
+        assert all(same(x, y) for x, y in zip(tr["spec1"], tr["team"])), n_beams
+    # every query scan of the scene, and a single-level match
+    for q in range(len(sc.query_scans)):
+        pg, cg = g.matchData(sc.query_init[q], sc.query_scans[q])
+        po, co = o.match(sc.query_init[q], sc.query_scans[q])
+        assert same(pg, po) and same(cg, co), q
+    lvl_pts = sc.query_scans[0] * np.float32(0.5)
+    pl, cl = g.match_level(1, sc.query_init[0], lvl_pts, 7)
+    pol, col = o.match_level(1, sc.query_init[0], lvl_pts, 7)
+    assert same(pl, pol) and same(cl, col)
+    g.close()
+    team.close()
+
+
 def test_slam_loop_from_empty_map_bit_identical(capi, oracle_mod, pyramid_scene, kind):
     """HectorSlamProcessor::update from an EMPTY map, 30 scans: identical poses at every step, hence identical update
     decisions and bit-identical maps on all levels at the end -- the whole SLAM state, not just one match"""
