@@ -219,6 +219,23 @@ def test_batch_of_more_than_one_generation_splits_off_its_tail(capi, oracle_mod)
     record(test="split_tail", batch=5000, checker=KIND, bit_identical_to_reference=int(same.sum()))
 
 
+def test_batch_of_scans_longer_than_the_cached_rows(capi, oracle_mod):
+    """4096 scans of up to 1400 beams: seventeen rows per lane are cached / staged, the beams beyond them stream from memory in
+    extra rounds behind the balanced schedule's last barrier (gn_match_exact.h) -- every pose and covariance equal to the reference's"""
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1400, map_size=2048, levels=3, resolution=0.05, n_build=60, n_query=4096, room=(40.0, 30.0), seed=77)
+    g, o = build_pair(capi, oracle_mod, sc)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    assert int(np.diff(offs).max()) > 17 * 64
+    pose, cov = g.match_batch(sc.query_init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["kernel"].startswith("gn_match_exact_cached_kernel") and cfg["block"] == 256 and cfg["grid"] == 1024, cfg
+    cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
+    same = (bits(pose) == bits(cpu)).all(1)
+    assert same.all(), f"{(~same).sum()} of 4096 poses differ from the reference ({KIND})"
+    record(test="long_scans_batch", batch=4096, checker=KIND, bit_identical_to_reference=int(same.sum()), kernel=cfg)
+
+
 def test_config4_share_4096map_pyramid(capi, oracle_mod):
     """configs[3], one GPU's share: 4096 of the 32768 scans, 3-level 4096/2048/1024 pyramid.  0.05 m cells, the
     room scaled to 160 m x 120 m and a 120 m sensor so that the 204.8 m map is actually used.
