@@ -102,6 +102,15 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
   } while (0)
 #endif
 
+#ifndef HSM_XPACE
+#define HSM_XPACE 0
+#endif
+#ifndef HSM_XPACE_FIRST
+#define HSM_XPACE_FIRST 1530
+#endif
+#ifndef HSM_XPACE_BAND
+#define HSM_XPACE_BAND 50
+#endif
 #ifndef HSM_XWGPRIO  // issue priority of a workgroup's producers by its dispatch order on the CU (blockIdx >> 8): the hardware arbitrates
 #define HSM_XWGPRIO 3  // by priority, then AGE, so the workgroup dispatched last to a CU loses every tie and ends last (profiles/r06).
 #endif                 // 0 = off; 1 = priority = order; 2 = (order + GN step) & 3: every workgroup is favoured in some steps; 3 = min(order, 2)
@@ -226,6 +235,12 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     }
     return;
   }
+#if !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
+  // hsm_set_clock_probe: workgroup 0 stamps the shader-clock counter and the 100 MHz wall clock when it starts and when it ends
+  // (both counters are scalar reads; the stamps wait in SGPRs and are stored where the texel cache no longer holds the VGPRs)
+  // (not in the chain-wavefront forms: their 80 VGPRs have no room for the stores)
+  const unsigned long long probe_t0 = CW ? 0ull : (unsigned long long)__builtin_readcyclecounter(), probe_w0 = CW ? 0ull : wall_clock64();
+#endif
 #ifdef HSM_XTIMELINE_WG  // (variant builds: start / end wall clock (100 MHz) and XCC id of every workgroup, [block][4] behind the other stamps)
   if (P.clock_probe != nullptr && wave == 0 && lane == 0) {
     P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 0] = wall_clock64();
@@ -499,7 +514,15 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
         }
       };
       const int wg_order = (int)((blockIdx.x >> 8) & 3u);
-      const int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
+      int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
+#if HSM_XPACE > 0 && !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
+      if (!CW && !kFirst) {  // experiment: producers' priority from the workgroup's lateness against a pace (cycles per round)
+        const int t = (int)((unsigned long long)__builtin_readcyclecounter() - probe_t0);
+        const int late = t - rounds * (HSM_XPACE_FIRST + (step_no - 1) * HSM_XPACE);
+        wg_prio = late > rounds * HSM_XPACE_BAND ? 2 : late > -rounds * HSM_XPACE_BAND ? 1 : 0;
+        wg_prio = __builtin_amdgcn_readfirstlane(wg_prio);
+      }
+#endif
       if (HSM_XWGPRIO != 0 && !CW) set_prio_uniform(wg_prio);
       // round k is staged: meet, then (one wavefront) run the chain jobs that are complete with it
       const int my_rounds =
@@ -697,6 +720,13 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     affine_apply(L.worldTmap, ex, ey, pw0, pw1);
     pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
   }
+#if !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
+  if (!CW && P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0) {
+    P.clock_probe[0] = probe_t0, P.clock_probe[1] = probe_w0;
+    P.clock_probe[2] = (unsigned long long)__builtin_readcyclecounter();
+    P.clock_probe[3] = wall_clock64();
+  }
+#endif
 #ifdef HSM_XTIMELINE_STEPS
   if (P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0 && step_no < 32)
     P.clock_probe[(size_t)4 * 31 * 4 + step_no] = (unsigned long long)__builtin_readcyclecounter();

@@ -99,6 +99,10 @@ def compact_line(out: dict, details_path) -> str:
         con = rf.get("contract") or {}
         if con.get("frac") is not None:
             r["contract_8d"] = {"bound": "hbm", "achieved": con.get("achieved"), "peak": con.get("peak"), "unit": con.get("unit"), "frac": con["frac"]}
+        cm = rf.get("clock_measured") or {}
+        if cm.get("sclk_hz"):  # the shader clock the kernel actually ran at (read inside the kernel); `frac` stays priced at 2.4 GHz
+            r["sclk_hz"] = cm["sclk_hz"]
+            r["frac_at_measured_clock"] = cm.get("frac_at_measured_clock")
         if rf.get("counter_source"):
             r["counter_source"] = _short(rf["counter_source"], 120)
         line["roofline"] = r

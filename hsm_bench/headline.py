@@ -203,7 +203,7 @@ def headline(args):
         st = probe.cpu().numpy().astype(np.uint64)
         matcher.set_clock_probe(0)
         run.sclk_hz = None
-        if st[1] and st[3] > st[1]:  # (only the quad-layout texel-cache form carries the probe)
+        if st[1] and st[3] > st[1]:  # (the texel-cache forms carry the probe: workgroup 0's first wavefront)
             run.sclk_hz = float(st[2] - st[0]) / float(st[3] - st[1]) * 100e6
         return dt, kern_ms, its
 
