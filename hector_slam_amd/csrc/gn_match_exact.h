@@ -121,7 +121,9 @@ __device__ __forceinline__ void set_prio_uniform(int p) {  // s_setprio takes an
   else __builtin_amdgcn_s_setprio(3);
 }
 
-template <int NS, int BPL, int BPC = BPL, bool CW = false>
+// PROBE: the instantiation hsm_set_clock_probe switches a launch to (the four stamps cost this kernel 0.4 us -- four more live
+// SGPRs -- so launches without a probe do not carry the code: profiles/r06/README.md 2)
+template <int NS, int BPL, int BPC = BPL, bool CW = false, bool PROBE = false>
 __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <= 96 ? 5 : 4) gn_match_exact_cached_kernel(const MatchParams P) {
   static_assert(BPC >= 1 && BPC <= BPL, "cached rows are a prefix of the rows");
   constexpr int NC = 9 * NS;  // chains per workgroup
@@ -235,12 +237,11 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     }
     return;
   }
-#if !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
   // hsm_set_clock_probe: workgroup 0 stamps the shader-clock counter and the 100 MHz wall clock when it starts and when it ends
-  // (both counters are scalar reads; the stamps wait in SGPRs and are stored where the texel cache no longer holds the VGPRs)
-  // (not in the chain-wavefront forms: their 80 VGPRs have no room for the stores)
-  const unsigned long long probe_t0 = CW ? 0ull : (unsigned long long)__builtin_readcyclecounter(), probe_w0 = CW ? 0ull : wall_clock64();
-#endif
+  // (both are scalar reads; the start stamps wait in SGPRs and go out with the end stamps, where the texel cache no longer holds
+  // the VGPRs)
+  const unsigned long long probe_t0 = PROBE || HSM_XPACE > 0 ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+  const unsigned long long probe_w0 = PROBE ? wall_clock64() : 0ull;
 #ifdef HSM_XTIMELINE_WG  // (variant builds: start / end wall clock (100 MHz) and XCC id of every workgroup, [block][4] behind the other stamps)
   if (P.clock_probe != nullptr && wave == 0 && lane == 0) {
     P.clock_probe[1024 + 4 * (size_t)blockIdx.x + 0] = wall_clock64();
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
       };
       const int wg_order = (int)((blockIdx.x >> 8) & 3u);
       int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
-#if HSM_XPACE > 0 && !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
+#if HSM_XPACE > 0
       if (!CW && !kFirst) {  // experiment: producers' priority from the workgroup's lateness against a pace (cycles per round)
         const int t = (int)((unsigned long long)__builtin_readcyclecounter() - probe_t0);
         const int late = t - rounds * (HSM_XPACE_FIRST + (step_no - 1) * HSM_XPACE);
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     pw0 = uniform_f32(pw0), pw1 = uniform_f32(pw1), pw2 = uniform_f32(eth);
   }
 #if !defined(HSM_XTIMELINE) && !defined(HSM_XTIMELINE_STEPS) && !defined(HSM_XTIMELINE_WG)
-  if (!CW && P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0) {
+  if (PROBE && P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0) {
     P.clock_probe[0] = probe_t0, P.clock_probe[1] = probe_w0;
     P.clock_probe[2] = (unsigned long long)__builtin_readcyclecounter();
     P.clock_probe[3] = wall_clock64();

@@ -1,5 +1,5 @@
 // match_exact_cached.hip -- launches of the exact-order texel-cache batch forms (gn_match_exact.h): the headline kernel of
-// configs[2] / configs[3] and its chain-wavefront forms.  A translation unit of its own: these ten instantiations are a third
+// configs[2] / configs[3] and its chain-wavefront forms.  A translation unit of its own: these twelve instantiations are a third
 // of the library's compile time, and the kernel is the one that gets edited.
 #include "gn_match_exact.h"
 #include "hsm_ctx.h"
@@ -12,7 +12,7 @@ namespace {
 // beams-per-lane register budget: the smallest instantiated BPL that holds max_n beams in the
 // team's VGPRs (0 = stream the endpoints from memory every GN step)
 // HSM_PARITY_EXACT: the exact-order form of the general kernel (endpoints streamed, no texel cache)
-template <int NS, int BPL, int BPC = BPL, bool CW = false>
+template <int NS, int BPL, int BPC = BPL, bool CW = false, bool PROBE = false>
 int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   int grid = (P.batch + NS - 1) / NS;
   const int block = 64 * (NS + (CW ? 1 : 0));
@@ -28,7 +28,7 @@ int launch_match_exact_cached(hsm_ctx* h, MatchParams P, hipStream_t stream) {
   // gathers take, so the load balancing the chunks buy the fast form is not needed and the compacter L2 footprint wins.
   // env HSM_XCD_CHUNK_EXACT=n restores chunks of n workgroups.
   P.xcd_chunk = h->xcd_chunk_exact > 0 ? (h->xcd_chunk_exact * 4 / NS > 0 ? h->xcd_chunk_exact * 4 / NS : 1) : 0;
-  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, CW>), dim3(grid), dim3(block), 0, stream, P);
+  hipLaunchKernelGGL((gn_match_exact_cached_kernel<NS, BPL, BPC, CW, PROBE>), dim3(grid), dim3(block), 0, stream, P);
   HIP_TRY(hipGetLastError());
   h->last_kernel = CW ? "gn_match_exact_cached_kernel (chain wavefront)" : "gn_match_exact_cached_kernel";
   h->last_cfg[0] = h->layout;
@@ -69,6 +69,8 @@ int launch_match_exact_cached_forms(hsm_ctx* h, const MatchParams& P, int max_n,
   // four workgroups per CU: the balanced schedule (13 cached rows) where level 0 fits the L2s, else round 3's (15 cached rows: the
   // gathers of a map that misses the L2 cost more than the schedule gains)
   if (HSM_XBPC_MAIN != HSM_XBPC && h->levels[0].cells() > ((size_t)1 << 23)) return launch_match_exact_cached<4, 17, HSM_XBPC>(h, P, stream);
+  // (hsm_set_clock_probe: the headline form has an instantiation that carries the stamps)
+  if (P.clock_probe != nullptr) return launch_match_exact_cached<4, 17, HSM_XBPC_MAIN, false, true>(h, P, stream);
   return launch_match_exact_cached<4, 17, HSM_XBPC_MAIN>(h, P, stream);
 }
 

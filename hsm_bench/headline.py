@@ -95,7 +95,7 @@ def headline(args):
             _direct["g"], _direct["kind"], _direct["note"] = sharding.make_row_gather(total, B, 3, dev, lag=1, fallback_bucket=args.gather_bucket)
         return _direct["g"]
 
-    def run(matcher, d_init, steps, warmup, gather=True, repeats=1):
+    def run(matcher, d_init, steps, warmup, gather=True, repeats=1, probe_after=False):
         """`repeats` timed regions of exactly `steps` launches each, every one bracketed by barrier + synchronize on both sides;
         returns the MEDIAN region (dt, kernel ms per launch) and keeps all of them in run.regions -- boxes settle at 2.0 or
         2.1 GHz, and one 20-step region is a 1 ms sample"""
@@ -136,10 +136,11 @@ def headline(args):
             if gatherer:
                 gatherer.launch()
 
-        # clock probe (hsm_set_clock_probe): the wave of scan 0 stamps {shader-clock counter, 100 MHz wall clock} at its
-        # first GN step and at its end; read after the timed loop = the clock the LAST timed launch ran at
+        # clock probe (hsm_set_clock_probe): workgroup 0 stamps {shader-clock counter, 100 MHz wall clock} at its start and at its
+        # end.  On for the W warm-up launches only -- the stamps cost the reference-order kernel 0.4 us per launch (its probed
+        # instantiation holds four more SGPRs) --, so what is read after the loop is the clock of the LAST WARM-UP launch, the one
+        # right in front of the first timed region; the timed launches carry no probe code
         probe = torch.zeros(4, dtype=torch.int64, device=dev)
-        matcher.set_clock_probe(probe.data_ptr())
         # the engine clock needs ~25 ms of load to settle (first 200-launch region of a cold run: 65 us per launch, second 61,
         # then 58.5 -- profiles/r04/README.md): untimed launches until it has, then the W warm-up steps of the contract
         # (kernel launches only -- no collective: the loop is time-based, so ranks run different numbers of iterations)
@@ -150,8 +151,10 @@ def headline(args):
                     matcher.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS,
                                                d_pose.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
+        matcher.set_clock_probe(probe.data_ptr())
         for _ in range(warmup):
             step()
+        matcher.set_clock_probe(0)
         if gatherer:
             gatherer.flush()
         regions = []
@@ -200,8 +203,14 @@ def headline(args):
         run.regions = {"repeats": len(regions), "steps_each": steps, "prewarm_ms": args.prewarm_ms, "ms_per_step": [r[0] / steps * 1e3 for r in regions],
                        "kernel_ms": [r[1] for r in regions], "reported": "median region",
                        "min_ms_per_step": min(r[0] for r in regions) / steps * 1e3, "max_ms_per_step": max(r[0] for r in regions) / steps * 1e3}
+        if probe_after:  # (the sustained leg: the clock at the END of its one long region -- three probed launches right behind it)
+            matcher.set_clock_probe(probe.data_ptr())
+            for _ in range(3):
+                matcher.match_batch_device(B, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), N_BEAMS,
+                                           d_pose.data_ptr(), d_cov.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            matcher.set_clock_probe(0)
         st = probe.cpu().numpy().astype(np.uint64)
-        matcher.set_clock_probe(0)
         run.sclk_hz = None
         if st[1] and st[3] > st[1]:  # (the texel-cache forms carry the probe: workgroup 0's first wavefront)
             run.sclk_hz = float(st[2] - st[0]) / float(st[3] - st[1]) * 100e6
@@ -349,7 +358,7 @@ def headline(args):
         n_s = max(args.steps, int(args.sustain_s / max(kern_ms * 1e-3, 1e-6)))
         hold = args.prewarm_ms
         args.prewarm_ms = 0.0
-        dts, ks, _ = run(matcher, d_in, n_s, 0, gather="none", repeats=1)
+        dts, ks, _ = run(matcher, d_in, n_s, 0, gather="none", repeats=1, probe_after=True)
         args.prewarm_ms = hold
         sustained = {"seconds": dts, "launches": n_s, "ms_per_step": dts / n_s * 1e3, "kernel_ms": ks, "value": B * its * n_s / dts,
                      "sclk_hz": getattr(run, "sclk_hz", None)}

@@ -200,5 +200,5 @@ def roofline_block(kernel_name, kern_ms, bytes_per_launch, beams, its, batch, pm
         rf["clock_measured"] = {"sclk_hz": sclk_hz, "peak_at_measured_clock": 1024 * sclk_hz / 2 / 1e9,
                                 "frac_at_measured_clock": rf["achieved"] / (1024 * sclk_hz / 2 / 1e9),
                                 "source": "s_memtime vs the 100 MHz wall clock over the lifetime of the first wavefront of workgroup 0 in the last "
-                                          "timed launch (hsm_set_clock_probe)"}
+                                          "warm-up launch before the timed regions (hsm_set_clock_probe; timed launches carry no probe)"}
     return rf

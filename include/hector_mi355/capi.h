@@ -414,9 +414,9 @@ int hsm_debug_expf(hsm_ctx* h, int n, const float* x, float* out_exp, float* out
 int hsm_device_info(const hsm_ctx* h, int info[4]);
 
 /* Measurement aid (no reference counterpart): d_stamps4 = device pointer to four 64-bit words, or NULL to switch it
- * off.  While set, every batched match by a texel-cache form (tree summation: the wavefront of scan 0; reference-order
- * summation: the first wavefront of workgroup 0, chain-wavefront instantiations excepted) stores {shader-clock counter
- * (s_memtime), 100 MHz wall clock} as taken at its start [0,1] and at its end [2,3]:
+ * off.  While set, a batched match by a texel-cache form (tree summation: the wavefront of scan 0; reference-order
+ * summation: the first wavefront of workgroup 0 of the 4096-scan form, which launches a probed instantiation that is 0.4 us
+ * slower) stores {shader-clock counter (s_memtime), 100 MHz wall clock} as taken at its start [0,1] and at its end [2,3]:
  * (s[2]-s[0]) / (s[3]-s[1]) * 100 MHz = the clock the kernel actually ran at (bench.py prices the VALU roof at it next
  * to the nominal 2.4 GHz).  The caller owns the memory. */
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4);

@@ -36,6 +36,23 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+# files whose tests put their contexts in the OPT-IN tree-summation mode (HSM_PARITY=fast, bar: north_star's 1e-4); every other
+# gpu-marked file runs the library default (the reference's order of the additions, bit-identical poses)
+FAST_MODE_FILES = ("test_gpu_parity.py",)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """so that "N passed" is not read as N tests of the default mode: say how the passed gpu tests split"""
+    passed = terminalreporter.stats.get("passed", [])
+    gpu = [r for r in passed if "gpu" in getattr(r, "keywords", {})]
+    if not gpu:
+        return
+    fast = [r for r in gpu if os.path.basename(r.nodeid.split("::")[0]) in FAST_MODE_FILES]
+    terminalreporter.write_line(f"gpu tests passed: {len(gpu)} = {len(gpu) - len(fast)} in the library's default mode (reference-order summation, "
+                                f"bit-exact bars) + {len(fast)} in {', '.join(FAST_MODE_FILES)} (opt-in HSM_PARITY=fast forms, 1e-4 bars; "
+                                f"some of them switch modes themselves)")
+
+
 def oracle_kinds():
     """CPU checkers to parametrise over: the restatement always, the reference-compiled one where its prebuilt
     library is present (the build container and, via the snapshot, the GPU box)."""

@@ -236,6 +236,35 @@ def test_batch_of_scans_longer_than_the_cached_rows(capi, oracle_mod):
     record(test="long_scans_batch", batch=4096, checker=KIND, bit_identical_to_reference=int(same.sum()), kernel=cfg)
 
 
+def test_clock_probe_in_the_reference_order_batch_kernel(capi, oracle_mod):
+    """hsm_set_clock_probe on a batch of 4096 full-length scans in the default mode: the launch takes the instantiation of the
+    headline kernel that carries the stamps (PROBE, gn_match_exact.h) -- same poses and covariances bit for bit, and the ratio
+    of the two counters is a clock an MI355X can run at; without a probe the launch carries no stamp code"""
+    import torch
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1081, map_size=1024, levels=1, resolution=0.05, n_build=60, n_query=4096, room=(40.0, 30.0), seed=5)
+    g, o = build_pair(capi, oracle_mod, sc, oracle_build=False)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    p0, c0 = g.match_batch(sc.query_init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["kernel"].startswith("gn_match_exact_cached_kernel") and cfg["grid"] == 1024, cfg
+    stamps = torch.zeros(4, dtype=torch.int64, device="cuda")
+    g.set_clock_probe(stamps.data_ptr())
+    p1, c1 = g.match_batch(sc.query_init, pts, offs)
+    torch.cuda.synchronize()
+    g.set_clock_probe(0)
+    st = stamps.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(bits(p0), bits(p1)) and np.array_equal(bits(c0), bits(c1))
+    assert st[3] > st[1] and st[2] > st[0], st
+    ghz = float(st[2] - st[0]) / float(st[3] - st[1]) * 0.1
+    assert 0.8 < ghz < 3.0, ghz
+    stamps.zero_()
+    g.match_batch(sc.query_init, pts, offs)
+    torch.cuda.synchronize()
+    assert not stamps.cpu().numpy().any()  # switched off: nothing is written
+    record(test="clock_probe_exact", ghz=ghz)
+
+
 def test_config4_share_4096map_pyramid(capi, oracle_mod):
     """configs[3], one GPU's share: 4096 of the 32768 scans, 3-level 4096/2048/1024 pyramid.  0.05 m cells, the
     room scaled to 160 m x 120 m and a 120 m sensor so that the 204.8 m map is actually used.
