@@ -794,6 +794,9 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
   const int wit = wave - team * WPS;
   const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + team);  // wave-uniform
   if (scan >= P.batch) return;  // whole team exits together
+#ifdef HSM_TEAM_TIMELINE
+  if (EXACT && P.clock_probe != nullptr && scan == 0 && threadIdx.x == 0) P.clock_probe[4] = wall_clock64();
+#endif
 
   int beg = 0, n = P.shared_n;
   if (P.offsets) {
@@ -870,6 +873,10 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
       for (int k = 0; k < NREG; ++k) pt[k] *= f2{ratio, ratio};
     }
     for (int it = 0; it < gn_steps; ++it) {
+#ifdef HSM_TEAM_TIMELINE  // (variant builds, tools/study/team_phase_probe.py: cycles of a GN step's phases, summed over the steps)
+      const unsigned long long tt0 = __builtin_readcyclecounter();
+      unsigned long long tt1 = tt0, tt2 = tt0;
+#endif
       float sinRot, cosRot;
       sincos_f32(eth, sinRot, cosRot);
       acc.zero();
@@ -955,7 +962,13 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
               beam_products(b[g], r[g], pr);
               exact_stage<kXRowLen>(pr, st, g * T + tid_in_team);
             }
+#ifdef HSM_TEAM_TIMELINE
+            tt1 = __builtin_readcyclecounter();
+#endif
             run = exact_chain<kXRowLen, (T > 64)>(st, tid_in_team, run, min(kXRowLen, n - base0));
+#ifdef HSM_TEAM_TIMELINE
+            tt2 = __builtin_readcyclecounter();
+#endif
           } else {
 #pragma unroll
             for (int g = 0; g < kXGroup; ++g) {
@@ -995,6 +1008,17 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
         buf ^= 1;
       }
       gn_solve_and_step(acc, ex, ey, eth);
+#ifdef HSM_TEAM_TIMELINE
+      if (EXACT && P.clock_probe != nullptr && scan == 0 && tid_in_team == 0) {
+        const unsigned long long tt3 = __builtin_readcyclecounter();
+        const bool first = l == P.first_level && it == 0;
+        if (first) P.clock_probe[8] = P.clock_probe[9] = P.clock_probe[10] = P.clock_probe[11] = 0, P.clock_probe[12] = tt0, P.clock_probe[13] = wall_clock64();
+        const int sno = (int)P.clock_probe[11];
+        P.clock_probe[8] += tt1 - tt0, P.clock_probe[9] += tt2 - tt1, P.clock_probe[10] += tt3 - tt2, P.clock_probe[11] += 1;
+        if (sno < 16) P.clock_probe[16 + sno] = tt1 - tt0, P.clock_probe[32 + sno] = tt2 - tt1, P.clock_probe[48 + sno] = tt3 - tt2;
+        P.clock_probe[14] = tt3, P.clock_probe[15] = wall_clock64();
+      }
+#endif
       if (P.trace) {  // kernel-uniform; only the single-scan hook path sets it
         if (scan == 0 && lane == 0 && wit == 0) {
           float* t = P.trace + 12 * step;
@@ -1020,6 +1044,9 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
       c[3] = acc.h01; c[4] = acc.hd.y; c[5] = acc.hr.y;
       c[6] = acc.hr.x; c[7] = acc.hr.y; c[8] = acc.h22;
     }
+#ifdef HSM_TEAM_TIMELINE
+    if (EXACT && P.clock_probe != nullptr && scan == 0) P.clock_probe[5] = wall_clock64();
+#endif
     if (scan == 0) publish_done(P);
   }
 }
