@@ -784,8 +784,12 @@ __global__ void __launch_bounds__(64 * WPS * SPB, ((EXACT && SPB == 1 && (WPS ==
   __shared__ __attribute__((aligned(16))) float red[2][9][WPS < 4 ? 4 : WPS];
   // exact order: [team][term][beam]; single-scan teams of up to four wavefronts stage a whole GROUP of rounds (kXGroup x T beams,
   // 46 KB at four wavefronts) and sum it in one go, the others round by round
-  constexpr int kXGroup = kExactGroupRounds;
-  constexpr int kXStaged = (EXACT && SPB == 1 && T <= 256) ? kXGroup : 1;  // rounds staged together
+#ifndef HSM_XTEAM8  // experiment: an eight-wavefront team stages its THREE rounds (1536 beams, 55 KB) together as well
+#define HSM_XTEAM8 0
+#endif
+  constexpr bool kTeam8 = HSM_XTEAM8 != 0 && EXACT && SPB == 1 && T == 512;
+  constexpr int kXGroup = kTeam8 ? 3 : kExactGroupRounds;
+  constexpr int kXStaged = (EXACT && SPB == 1 && (T <= 256 || kTeam8)) ? kXGroup : 1;  // rounds staged together
   constexpr int kXRowLen = kXStaged * T;
   __shared__ float stage[EXACT ? SPB * 9 * (kXRowLen + kExactPad) : 1];
   const int lane = threadIdx.x & 63;
