@@ -236,6 +236,27 @@ def test_batch_of_scans_longer_than_the_cached_rows(capi, oracle_mod):
     record(test="long_scans_batch", batch=4096, checker=KIND, bit_identical_to_reference=int(same.sum()), kernel=cfg)
 
 
+@pytest.mark.parametrize("beams,rows", [(300, 5), (560, 9), (720, 13)])
+def test_full_batch_of_short_scans_takes_the_short_row_forms(capi, oracle_mod, beams, rows):
+    """4096 ragged scans of at most 300 / 560 / 720 beams, four workgroups per CU: the 5- / 9- / 13-row instantiations of the headline
+    kernel on the balanced run-ahead schedule (every row cached) -- every pose and covariance equal to the reference's"""
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=beams, map_size=1024, levels=3, resolution=0.05, n_build=60, n_query=4096, room=(40.0, 30.0), seed=beams)
+    g, o = build_pair(capi, oracle_mod, sc)
+    rng = np.random.default_rng(beams)
+    scans = [sq[: max(0, sq.shape[0] - int(rng.integers(0, 64)))] if q % 5 else sq for q, sq in enumerate(sc.query_scans)]
+    scans[17] = scans[17][:0]  # an empty scan passes its start pose through
+    pts, offs = synth.pack_scans(scans)
+    pose, cov = g.match_batch(sc.query_init, pts, offs)
+    cfg = g.last_launch_config()
+    assert cfg["kernel"] == "gn_match_exact_cached_kernel" and cfg["block"] == 256 and cfg["grid"] == 1024 and cfg["beams_per_lane"] == rows, cfg
+    cpu = oracle_match_all(oracle_mod, sc, sc.query_init, pts, offs)
+    same = (bits(pose) == bits(cpu)).all(1)
+    assert same.all(), f"{(~same).sum()} of 4096 poses differ from the reference ({KIND})"
+    assert np.array_equal(bits(pose[17]), bits(sc.query_init[17]))
+    record(test="short_scans_batch", beams=beams, rows=rows, checker=KIND, bit_identical_to_reference=int(same.sum()))
+
+
 def test_clock_probe_in_the_reference_order_batch_kernel(capi, oracle_mod):
     """hsm_set_clock_probe on a batch of 4096 full-length scans in the default mode: the launch takes the instantiation of the
     headline kernel that carries the stamps (PROBE, gn_match_exact.h) -- same poses and covariances bit for bit, and the ratio
