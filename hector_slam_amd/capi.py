@@ -29,6 +29,7 @@ HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
 PARITY_FAST, PARITY_EXACT, PARITY_RELAXED, PARITY_AUTO = 0, 1, 2, 3
 GATHER_AUTO, GATHER_PEER, GATHER_RCCL, GATHER_DIRECT = 0, 1, 2, 3
+ORDER_GIVEN, ORDER_MORTON = 0, 1
 EXCHANGE_HANDLE_BYTES = 64
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -57,6 +58,10 @@ SIGNATURES = {
     "hsm_set_parity": (_i, [_vp, _i]),
     "hsm_parity": (_i, [_vp]),
     "hsm_last_launch_parity": (_i, [_vp]),
+    "hsm_set_batch_order": (_i, [_vp, _i]),
+    "hsm_set_batch_order_refresh": (_i, [_vp, _i]),
+    "hsm_batch_order": (_i, [_vp]),
+    "hsm_last_launch_sorted": (_i, [_vp]),
     "hsm_match": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p]),
     "hsm_match_trace": (_i, [_vp, _f32p, _vp, _i, _f32p, _f32p, _f32p, _f32p, _i, C.POINTER(_i)]),
     "hsm_match_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -260,6 +265,20 @@ class MapRepMultiMap:
 
     def parity(self) -> int:
         return self._lib.hsm_parity(self._h)
+
+    def set_batch_order(self, order: int):
+        """ORDER_GIVEN (default) / ORDER_MORTON: how a batch is laid out on the device (hsm_set_batch_order)"""
+        _check(self._lib.hsm_set_batch_order(self._h, order), "hsm_set_batch_order")
+
+    def set_batch_order_refresh(self, launches: int):
+        """a stream's permutation serves that many launches of the same batch size before it is computed again (default 8)"""
+        _check(self._lib.hsm_set_batch_order_refresh(self._h, launches), "hsm_set_batch_order_refresh")
+
+    def batch_order(self) -> int:
+        return self._lib.hsm_batch_order(self._h)
+
+    def last_launch_sorted(self) -> bool:
+        return bool(self._lib.hsm_last_launch_sorted(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

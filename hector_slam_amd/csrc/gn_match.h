@@ -125,6 +125,8 @@ struct MatchParams {
   unsigned spec_stride;    // float4s per scan
   SpecStats* spec_stats;   // nullptr, or counters the stitching pass adds to (hsm_debug_spec_stats)
   int n_bound;             // HOST ONLY: 0 = scan lengths live on the device only (max_n is a hint), else no scan is longer than this
+  const int* perm;         // nullptr, or [batch]: launch slot -> scan index (hsm_set_batch_order: the batch in Morton order of its start
+                           // poses; results still land at the scan's own index).  Read by the texel-cache batch forms only
   ExchangeFused xp;        // world > 0: this launch posts its poses into an exchange and unpacks an earlier epoch (forms that support
                            // it say so by setting hsm_ctx::fused_exchange_done; the others leave both to a launch of pose_exchange.hip)
 };
@@ -1304,11 +1306,13 @@ __global__ void __launch_bounds__(64 * SPB * WPS, WPS > 1 ? 5 : 4) gn_match_cach
   const int wit = __builtin_amdgcn_readfirstlane(wave % WPS);  // wave in team
   int red_buf = 0;
   // wave-uniform: kept in an SGPR (and with it the pose / covariance addresses, which live across the whole kernel)
-  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave / WPS);
+  const int slot = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, (int)gridDim.x, P.xcd_chunk) * SPB + wave / WPS);
 #if defined(HSM_EXPERIMENTS) && defined(HSM_EXP_TIMESTAMPS)
   const unsigned long long ts_entry = wall_clock64();
 #endif
-  if (scan >= P.batch) return;
+  if (slot >= P.batch) return;
+  // (MatchParams::perm: the batch in Morton order of its start poses -- neighbours in the launch are neighbours in the map)
+  const int scan = P.perm != nullptr ? __builtin_amdgcn_readfirstlane(P.perm[slot]) : slot;
 
   int beg = 0, n = P.shared_n;
   if (P.offsets) {

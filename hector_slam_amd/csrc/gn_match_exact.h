@@ -164,9 +164,12 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int scan = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, match_blocks, P.xcd_chunk) * NS + wave);
+  const int slot = __builtin_amdgcn_readfirstlane(xcd_block((int)blockIdx.x, match_blocks, P.xcd_chunk) * NS + wave);
+  // (MatchParams::perm: the batch in Morton order of its start poses -- neighbours in the launch are neighbours in the map; a slot
+  // beyond the batch keeps an index beyond it)
+  const int scan = (P.perm != nullptr && slot < P.batch) ? __builtin_amdgcn_readfirstlane(P.perm[slot]) : slot;
   const bool chain_wave = CW && wave == NS;   // wave-uniform
-  const bool active = scan < P.batch && !chain_wave;  // inactive wavefronts (batch tail) run along with an empty scan: barriers, jobs
+  const bool active = slot < P.batch && !chain_wave;  // inactive wavefronts (batch tail) run along with an empty scan: barriers, jobs
   int beg = 0, n = 0;
   float pw0 = 0.0f, pw1 = 0.0f, pw2 = 0.0f;
   if (active) {

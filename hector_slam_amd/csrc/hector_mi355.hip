@@ -272,6 +272,7 @@ int launch_match_mode(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t s
 // mutex) -- and is recorded for hsm_last_launch_parity().
 int launch_match(hsm_ctx* h, const MatchParams& P, int max_n, hipStream_t stream) {
   const bool exact = h->exact || auto_wants_exact(h, P);
+  h->last_sorted = false;  // (the forms that take a permuted batch set it: ensure_batch_perm)
   const int rc = launch_match_mode(h, P, max_n, stream, exact);
   h->last_parity = exact ? HSM_PARITY_EXACT : (h->relaxed ? HSM_PARITY_RELAXED : HSM_PARITY_FAST);
   return rc;
@@ -773,6 +774,16 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     h->relaxed = is_relaxed;
     h->auto_parity = is_auto;
   }
+  if (const char* env = getenv("HSM_BATCH_ORDER")) {
+    if (strcmp(env, "given") == 0) h->batch_order = HSM_ORDER_GIVEN;
+    else if (strcmp(env, "morton") == 0) h->batch_order = HSM_ORDER_MORTON;
+    else {
+      delete h;
+      return fail(HSM_ERR_INVALID, "hsm_create: HSM_BATCH_ORDER must be given or morton");
+    }
+  }
+  if (const char* env = getenv("HSM_BATCH_ORDER_MIN")) h->batch_order_min = atoi(env);
+  if (const char* env = getenv("HSM_BATCH_ORDER_REFRESH")) h->batch_order_refresh = atoi(env) > 0 ? atoi(env) : 1;
   if (const char* env = getenv("HSM_MERGED_MARK_MAX")) h->merged_mark_max = atoi(env);
   if (const char* env = getenv("HSM_SCATTER_TEXELS_MAX")) h->scatter_texels_max = atoi(env);
   if (const char* env = getenv("HSM_DENSE_BITS")) h->dense_bits = atoi(env) != 0;
@@ -873,6 +884,7 @@ void hsm_destroy(hsm_ctx* h) {
   for (Level& L : h->levels) free_level(L, log);
   TEARDOWN(log, hipFree(h->d_scan));
   TEARDOWN(log, hipFree(h->d_spec_scratch));
+  for (hsm_ctx::PermBuf& b : h->perm_bufs) TEARDOWN(log, hipFree(b.d));
   TEARDOWN(log, hipFree(h->d_spec_stats));
   TEARDOWN(log, hipFree(h->d_beam_recs));
   TEARDOWN(log, hipFree(h->d_retained));
@@ -953,6 +965,25 @@ int hsm_parity(const hsm_ctx* h) {
 }
 
 int hsm_last_launch_parity(const hsm_ctx* h) { return h ? h->last_parity : HSM_PARITY_FAST; }
+
+int hsm_set_batch_order(hsm_ctx* h, int order) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (order != HSM_ORDER_GIVEN && order != HSM_ORDER_MORTON) return fail(HSM_ERR_INVALID, "hsm_set_batch_order: unknown order");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->batch_order = order;
+  for (hsm_ctx::PermBuf& b : h->perm_bufs) b.batch = 0;
+  return HSM_OK;
+}
+int hsm_set_batch_order_refresh(hsm_ctx* h, int launches) {
+  if (!h) return fail(HSM_ERR_INVALID, "null context");
+  if (launches < 1) return fail(HSM_ERR_INVALID, "hsm_set_batch_order_refresh: at least 1");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->batch_order_refresh = launches;
+  for (hsm_ctx::PermBuf& b : h->perm_bufs) b.batch = 0;  // (the next launch computes a fresh one)
+  return HSM_OK;
+}
+int hsm_batch_order(const hsm_ctx* h) { return h ? h->batch_order : HSM_ORDER_GIVEN; }
+int hsm_last_launch_sorted(const hsm_ctx* h) { return h && h->last_sorted ? 1 : 0; }
 
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");

@@ -179,6 +179,22 @@ struct hsm_ctx {
   bool exact_spec = false;       // env HSM_EXACT_SPEC=1: one-workgroup-per-scan launches in exact order take the speculative-carry form (gn_match_spec.h:
                                  // the same bits; measured SLOWER than the literal chains on one CU -- DESIGN.md 8 -- hence opt-in)
   bool exact_spec1 = false;      // env HSM_EXACT_SPEC1=1: ONE scan of up to 2048 beams (hsm_match) in exact order takes the on-chip speculative-carry form
+  // hsm_set_batch_order: launch order of a batch (texel-cache batch forms).  One permutation buffer per stream that has launched
+  // a sorted batch (launches on one stream are ordered; a ninth stream keeps the caller's order)
+  int batch_order = 0;           // HSM_ORDER_GIVEN
+  int batch_order_min = 1024;    // env HSM_BATCH_ORDER_MIN: smaller batches keep the caller's order
+  int batch_order_refresh = 8;   // hsm_set_batch_order_refresh / env HSM_BATCH_ORDER_REFRESH: a stream's permutation serves that many
+                                 // launches of the same batch size before it is computed again (ANY permutation gives the same
+                                 // results; an old one only groups the scans by where they were)
+  struct PermBuf {
+    hipStream_t s;
+    int* d;
+    size_t cap;
+    int batch;  // the batch size the permutation in `d` was computed for (0: none)
+    int used;   // launches it has served
+  };
+  std::vector<PermBuf> perm_bufs;
+  bool last_sorted = false;
   float* d_spec_scratch = nullptr;   // gn_match_spec_kernel: products of every beam, [batch][stride] float4s
   size_t spec_scratch_cap = 0;       // float4s
   SpecStats* d_spec_stats = nullptr; // hsm_debug_spec_stats
@@ -204,6 +220,8 @@ namespace hsm_host {
 int launch_match_exact_cached_forms(hsm_ctx* h, const hsm::MatchParams& P, int max_n, hipStream_t stream);
 // match_teams.hip: `wps` wavefronts per scan (1, 2, 4, 8, 16), either summation order; the one-wavefront exact form goes on to
 // launch_match_exact_cached_forms where that applies
+// MatchParams::perm for this launch where hsm_set_batch_order asks for it (a sort kernel on `stream` in front of the matcher)
+int ensure_batch_perm(hsm_ctx* h, hsm::MatchParams& P, hipStream_t stream);
 int launch_match_by_width(hsm_ctx* h, const hsm::MatchParams& P, int max_n, hipStream_t stream, bool exact, int wps);
 
 }  // namespace hsm_host

@@ -231,6 +231,8 @@ def test_matcher_launch_that_carries_the_exchange(B):
     g.setUpdateFactorFree(0.4)
     g.setUpdateFactorOccupied(0.9)
     g.build_map(sc.build_poses, sc.build_scans)
+    if B == 4096:  # (... and through a permuted batch: the epilogue posts a scan's pose to the scan's own row)
+        g.set_batch_order(capi.ORDER_MORTON)
     rng = np.random.default_rng(3)
     idx = rng.integers(0, len(sc.query_scans), B)
     pts, offs = synth.pack_scans([sc.query_scans[i] for i in idx])

@@ -257,6 +257,73 @@ def test_full_batch_of_short_scans_takes_the_short_row_forms(capi, oracle_mod, b
     record(test="short_scans_batch", beams=beams, rows=rows, checker=KIND, bit_identical_to_reference=int(same.sum()))
 
 
+@pytest.mark.parametrize("B", [1500, 4096, 5000])
+def test_batch_in_morton_order_gives_the_same_bits(capi, oracle_mod, B):
+    """hsm_set_batch_order(HSM_ORDER_MORTON): a one-workgroup counting sort in front of the matcher lays a randomly ordered batch out
+    by the map tile of its start poses and the matcher takes its scans through that permutation -- every pose and covariance lands
+    at the scan's own index with the bits of the caller's order: the chain-wavefront form (1500 scans), the headline form (4096),
+    a launch that splits off its part-filled last generation (5000), the fast tree form; ragged scans, an empty one; the default
+    is the caller's order"""
+    import torch
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1081, map_size=1024, levels=3, resolution=0.05, n_build=60, n_query=512, room=(40.0, 30.0), seed=9)
+    g, o = build_pair(capi, oracle_mod, sc, oracle_build=False)
+    rng = np.random.default_rng(B)
+    idx = rng.integers(0, 512, B)
+    scans = [sc.query_scans[i][: 1081 - int(rng.integers(0, 300))] for i in idx]
+    scans[5] = scans[5][:0]
+    init = sc.query_init[idx] + rng.uniform(-0.05, 0.05, (B, 3)).astype(np.float32) * np.float32([1, 1, 0.2])
+    pts, offs = synth.pack_scans(scans)
+    assert g.batch_order() == capi.ORDER_GIVEN
+    for mode in (capi.PARITY_AUTO, capi.PARITY_FAST):
+        g.set_parity(mode)
+        g.set_batch_order(capi.ORDER_GIVEN)
+        p0, c0 = g.match_batch(init, pts, offs)
+        assert not g.last_launch_sorted()
+        k0 = g.last_launch_config()["kernel"]
+        g.set_batch_order(capi.ORDER_MORTON)
+        far = init.copy()
+        far[:, :2] += np.float32(3.0)  # (results of another basin into the result buffers: a slot the permutation missed would show)
+        g.match_batch(far, pts, offs)
+        p1, c1 = g.match_batch(init, pts, offs)
+        cached = g.last_launch_config()["texel_cache"]  # (the tree mode runs 1500 scans on teams of wavefronts: the caller's order)
+        assert g.last_launch_sorted() == bool(cached) and g.last_launch_config()["kernel"] == k0, g.last_launch_config()
+        assert cached or (mode == capi.PARITY_FAST and B == 1500)
+        live = np.arange(B) != 5  # (an empty scan leaves its covariance untouched: whatever the output buffer held)
+        assert np.array_equal(bits(p0), bits(p1)) and np.array_equal(bits(c0[live]), bits(c1[live])), mode
+    assert np.array_equal(bits(p1[5]), bits(init[5]))  # the empty scan's start pose passes through, at its own index
+    # shared scan (pose hypotheses of ONE scan), sorted
+    g.set_parity(capi.PARITY_AUTO)
+    g.set_batch_order(capi.ORDER_GIVEN)
+    h0, _ = g.match_batch(init, sc.query_scans[3], None)
+    g.set_batch_order(capi.ORDER_MORTON)
+    h1, _ = g.match_batch(init, sc.query_scans[3], None)
+    assert g.last_launch_sorted() and np.array_equal(bits(h0), bits(h1))
+    # the permutation serves eight launches by default; computed for every launch it gives the same bits again
+    g.set_batch_order_refresh(1)
+    h2, _ = g.match_batch(init, sc.query_scans[3], None)
+    h3, _ = g.match_batch(init, sc.query_scans[3], None)
+    assert g.last_launch_sorted() and np.array_equal(bits(h0), bits(h2)) and np.array_equal(bits(h0), bits(h3))
+    with pytest.raises(capi.HsmError):
+        g.set_batch_order_refresh(0)
+    # a small batch keeps the caller's order; a single scan is not a batch
+    g.match_batch(init[:64], *synth.pack_scans(scans[:64]))
+    assert not g.last_launch_sorted()
+    with pytest.raises(capi.HsmError):
+        g.set_batch_order(7)
+    g.close()
+
+
+def test_batch_order_environment_word(capi, monkeypatch):
+    monkeypatch.setenv("HSM_BATCH_ORDER", "morton")
+    g = capi.MapRepMultiMap(0.05, 256, 256, 1)
+    assert g.batch_order() == capi.ORDER_MORTON
+    g.close()
+    monkeypatch.setenv("HSM_BATCH_ORDER", "sorted")
+    with pytest.raises(capi.HsmError):
+        capi.MapRepMultiMap(0.05, 256, 256, 1)
+
+
 def test_clock_probe_in_the_reference_order_batch_kernel(capi, oracle_mod):
     """hsm_set_clock_probe on a batch of 4096 full-length scans in the default mode: the launch takes the instantiation of the
     headline kernel that carries the stamps (PROBE, gn_match_exact.h) -- same poses and covariances bit for bit, and the ratio
