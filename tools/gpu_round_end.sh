@@ -51,6 +51,10 @@ echo "== free-running soak, default mode, 30000 steps"; S=$(date +%s)
 timeout 900 python tests/tools/soak.py 30000 --default --free-run > "$OUT/soak_default_free_run_30000.json" 2> /dev/null; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-400 "$OUT/soak_default_free_run_30000.json"
 echo "== dense soak (16384 beams, 2048^2), 1500 steps"; S=$(date +%s)
 timeout 900 python tests/tools/soak_dense.py 1500 --beams 16384 --size 2048 --check 500 > "$OUT/soak_dense_16384beams_2048map_1500.json" 2> /dev/null; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-300 "$OUT/soak_dense_16384beams_2048map_1500.json"
+echo "== batch order: the headline batch and the 4096^2 pyramid in trajectory / random order, as given and through HSM_ORDER_MORTON"; S=$(date +%s)
+timeout 600 python tools/study/batch_order_locality.py 2> /dev/null | grep -v amdgpu.ids > "$OUT/batch_order_locality.txt"; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-150 "$OUT/batch_order_locality.txt"
+echo "== exchange cost by world size (one device)"; S=$(date +%s)
+timeout 600 python tools/study/exchange_world_cost.py 2> /dev/null | grep -v amdgpu.ids > "$OUT/exchange_cost_by_world_size_one_device.txt"; echo "rc=$? ($(( $(date +%s) - S )) s)"; cut -c1-200 "$OUT/exchange_cost_by_world_size_one_device.txt"
 echo "== ThreadSanitizer over the facade"; bash tools/tsan_facade.sh 2>&1 | tail -4; cp gpurun_out/tsan/tsan_stdout.txt "$OUT/sanitizer_tsan_facade.txt" 2>/dev/null
 echo "== default-mode batches by size (chain-wavefront form up to 3072 scans)"; S=$(date +%s)
 for L in 1 3; do timeout 300 python tools/batch_size_sweep.py --levels $L --variants "default;HSM_EXACT_CHAIN_WAVE=0" > "$OUT/batch_size_sweep_l$L.jsonl" 2> /dev/null; done; echo "rc=$? ($(( $(date +%s) - S )) s)"
