@@ -306,6 +306,15 @@ def test_batch_in_morton_order_gives_the_same_bits(capi, oracle_mod, B):
     assert g.last_launch_sorted() and np.array_equal(bits(h0), bits(h2)) and np.array_equal(bits(h0), bits(h3))
     with pytest.raises(capi.HsmError):
         g.set_batch_order_refresh(0)
+    if B == 4096:  # more scans than one pass of the sort kernel holds (8192): 20 000 hypotheses of one scan
+        hyp = np.tile(init, (5, 1))[:20000] + rng.uniform(-0.2, 0.2, (20000, 3)).astype(np.float32) * np.float32([1, 1, 0.1])
+        g.set_batch_order(capi.ORDER_GIVEN)
+        a0, _ = g.match_batch(hyp, sc.query_scans[7], None)
+        g.set_batch_order(capi.ORDER_MORTON)
+        g.match_batch(hyp + np.float32(1.0), sc.query_scans[7], None)
+        g.set_batch_order_refresh(1)
+        a1, _ = g.match_batch(hyp, sc.query_scans[7], None)
+        assert g.last_launch_sorted() and np.array_equal(bits(a0), bits(a1))
     # a small batch keeps the caller's order; a single scan is not a batch
     g.match_batch(init[:64], *synth.pack_scans(scans[:64]))
     assert not g.last_launch_sorted()
