@@ -199,6 +199,12 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     }
     return;
   }
+#if defined(HSM_XSTAGGER) && HSM_XSTAGGER > 0  // experiment: the k-th workgroup dispatched to a CU starts k x HSM_XSTAGGER x 64 cycles late
+  if (!CW) {                                  // (the endpoint streams of a CU's four workgroups then do not all hit the HBM at once)
+    const int late = (int)((blockIdx.x >> 8) & 3u) * HSM_XSTAGGER;
+    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   // rounds per GN step: the BPL cached rows (all of them: shorter scans pad with +-0 contributions), plus streamed
   // rounds for scans longer than the host's length hint
   const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
