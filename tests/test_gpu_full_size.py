@@ -333,6 +333,42 @@ def test_batch_order_environment_word(capi, monkeypatch):
         capi.MapRepMultiMap(0.05, 256, 256, 1)
 
 
+def test_batched_matches_can_be_captured_in_a_hip_graph(capi, oracle_mod):
+    """hsm_match_batch_device on a caller's stream is kernel launches only: a loop of batched matches can be captured into a hipGraph
+    (torch.cuda.CUDAGraph on ROCm) and replayed -- same poses bit for bit, in the default mode and in Morton order (whose sort kernel
+    and permutation buffer belong to the stream: allocated by the warm-up launch, not during the capture)"""
+    import torch
+    from hector_slam_amd import synth
+    sc = synth.make_scene(n_beams=1081, map_size=1024, levels=3, resolution=0.05, n_build=60, n_query=4096, room=(40.0, 30.0), seed=21)
+    g, o = build_pair(capi, oracle_mod, sc, oracle_build=False)
+    g.synchronize()
+    dev = torch.device("cuda", 0)
+    pts, offs = synth.pack_scans(sc.query_scans)
+    d_pts, d_offs, d_init = torch.from_numpy(pts).to(dev), torch.from_numpy(offs).to(dev), torch.from_numpy(sc.query_init).to(dev)
+    d_pose = torch.zeros((4096, 3), dtype=torch.float32, device=dev)
+    s = torch.cuda.Stream()
+
+    def launch():
+        g.match_batch_device(4096, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 1081, d_pose.data_ptr(), 0, s.cuda_stream)
+    for order in (capi.ORDER_GIVEN, capi.ORDER_MORTON):
+        g.set_batch_order(order)
+        g.set_batch_order_refresh(2)
+        launch()
+        torch.cuda.synchronize()
+        ref = d_pose.cpu().numpy().copy()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            for _ in range(5):
+                launch()
+        for _ in range(3):
+            d_pose.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(d_pose.cpu().numpy()), bits(ref)), order
+    g.close()
+
+
 def test_clock_probe_in_the_reference_order_batch_kernel(capi, oracle_mod):
     """hsm_set_clock_probe on a batch of 4096 full-length scans in the default mode: the launch takes the instantiation of the
     headline kernel that carries the stamps (PROBE, gn_match_exact.h) -- same poses and covariances bit for bit, and the ratio
