@@ -141,11 +141,33 @@ class DirectRowGather:
         self.first_row, end = shard_bounds(total_rows, self.rank, self.world)
         self.rows = end - self.first_row
         dev = torch.device(device)
-        self.x = capi.PoseExchange(self.rank, self.world, total_rows, cols, depth=2 + 2 * lag, device=dev.index if dev.index is not None else -1)
+        # Set-up is collective: every rank takes part in BOTH object gathers whatever happened to it locally -- a rank whose mailbox
+        # could not be created or connected says so instead of leaving the others inside a collective it never joins -- and a
+        # failure anywhere is raised on every rank (make_row_gather then falls back on all of them together).
+        self.x, err = None, None
+        try:
+            self.x = capi.PoseExchange(self.rank, self.world, total_rows, cols, depth=2 + 2 * lag, device=dev.index if dev.index is not None else -1)
+        except Exception as exc:
+            err = f"{type(exc).__name__}: {str(exc)[:160]}"
         if self.world > 1:
             handles = [None] * self.world
-            dist.all_gather_object(handles, self.x.handle(), group=group)
-            self.x.connect(handles)
+            dist.all_gather_object(handles, (self.x.handle() if self.x is not None else None, err), group=group)
+            bad = [(r, e) for r, (hd, e) in enumerate(handles) if hd is None]
+            if not bad:
+                try:
+                    self.x.connect([hd for hd, _ in handles])
+                except Exception as exc:
+                    err = f"{type(exc).__name__}: {str(exc)[:160]}"
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err if not bad else (err or "a peer has no mailbox"), group=group)
+            bad = bad or [(r, e) for r, e in enumerate(oks) if e]
+            if bad:
+                if self.x is not None:
+                    self.x.close()
+                    self.x = None
+                raise RuntimeError("device-side exchange set-up failed: " + "; ".join(f"rank {r}: {e}" for r, e in bad[:3]))
+        elif err:
+            raise RuntimeError("device-side exchange set-up failed: " + err)
         self.local = torch.zeros((max(self.rows, 1), cols), dtype=dtype, device=dev)[: self.rows]
         self.out = [torch.zeros((total_rows, cols), dtype=dtype, device=dev) for _ in range(2)]
         self.launched = 0   # epochs posted
@@ -205,7 +227,8 @@ class DirectRowGather:
         self.x.check()
 
     def close(self) -> None:
-        self.x.close()
+        if self.x is not None:
+            self.x.close()
 
 
 def make_row_gather(total_rows: int, rows_per_rank: int, cols: int, device, lag: int = 1, fallback_bucket: int = 1, group=None):

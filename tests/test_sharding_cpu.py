@@ -335,6 +335,55 @@ def _worker_fallback(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_fallback_one_rank(rank, world, port, q):
+    """... and when only ONE rank cannot set its mailbox up (rank 0 gets a stand-in that 'works', rank 1 has no device): the set-up
+    is collective, so rank 0 must not wait inside a handle exchange rank 1 never joins -- both settle on the collective"""
+    sys.path.insert(0, ROOT)
+    from hector_slam_amd import capi, sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 0:
+            class Stub:
+                def __init__(self, *a, **k):
+                    self.closed = False
+
+                def handle(self):
+                    return b"x" * 64
+
+                def connect(self, handles):
+                    raise AssertionError("must not connect: a peer has no mailbox")
+
+                def close(self):
+                    self.closed = True
+            capi.PoseExchange = Stub
+        rows = 4
+        g, kind, note = sharding.make_row_gather(world * rows, rows, 3, "cpu", lag=1, fallback_bucket=1)
+        ok = kind == "rccl" and isinstance(g, sharding.BucketedRowGather) and "rank 1" in note
+        g.next_local().copy_(torch.full((rows, 3), float(7 + rank)))
+        g.launch()
+        out = g.last_result()
+        exp = torch.cat([torch.full((rows, 3), float(7 + r)) for r in range(world)])
+        q.put((rank, bool(ok and torch.equal(out, exp)), note[:160]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_selection_falls_back_together_when_one_rank_has_no_mailbox():
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: the exchange sets up (tests/test_gpu_exchange.py covers it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fallback_one_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True], res
+
+
 def test_gather_selection_falls_back_to_the_collective_on_every_rank():
     if torch.cuda.is_available():
         pytest.skip("a HIP device is present: the exchange sets up (tests/test_gpu_exchange.py covers it)")
