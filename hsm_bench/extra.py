@@ -422,8 +422,17 @@ def extra_workload(name: str, args, local_rank: int, rank: int = 0, nranks: int 
         if gatherer:
             allp = gatherer.last_result()
             d_pose.copy_(allp[rank * B:(rank + 1) * B])
-            if direct is not None:
-                direct.check()
+            if direct is not None:  # (a lost epoch is raised on every rank together: one rank leaving alone would hang the others)
+                bad, why = 0, ""
+                try:
+                    direct.check()
+                except Exception as exc:
+                    bad, why = 1, str(exc)[:200]
+                tb = torch.tensor([bad], dtype=torch.int32, device=dev)
+                if nranks > 1:
+                    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                if int(tb.item()):
+                    raise RuntimeError("device-side gather lost an epoch: " + (why or "on a peer"))
         if nranks > 1:
             timed.ranks = multi_rank_record(dt, ev0.elapsed_time(ev1) / steps, dev, allp if gatherer else None)
             timed.ranks["gather"] = ("direct: hsm_exchange, one per batched match, no collective on the data path" if direct is not None else
