@@ -338,6 +338,7 @@ def headline(args):
         # the exchange passed its self-test and then lost an epoch under load: every rank is here (see run), the line is measured
         # with the collective instead and says so
         _direct["kind"], _direct["note"] = "rccl", f"device-side exchange failed during the timed run ({exc})"
+        _direct["g"] = sharding.BucketedRowGather(B, 3, dev, bucket=args.gather_bucket)
         dt, kern_ms, its = run(matcher, d_in, args.steps, args.warmup, gather=args.gather, repeats=args.repeats)
     regions = getattr(run, "regions", None)
     headline_sclk = getattr(run, "sclk_hz", None)
