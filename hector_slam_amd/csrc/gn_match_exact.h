@@ -102,15 +102,6 @@ constexpr int kXRows = 9;  // staged rows per scan and round: the nine products 
   } while (0)
 #endif
 
-#ifndef HSM_XPACE
-#define HSM_XPACE 0
-#endif
-#ifndef HSM_XPACE_FIRST
-#define HSM_XPACE_FIRST 1530
-#endif
-#ifndef HSM_XPACE_BAND
-#define HSM_XPACE_BAND 50
-#endif
 #ifndef HSM_XWGPRIO  // issue priority of a workgroup's producers by its dispatch order on the CU (blockIdx >> 8): the hardware arbitrates
 #define HSM_XWGPRIO 3  // by priority, then AGE, so the workgroup dispatched last to a CU loses every tie and ends last (profiles/r06).
 #endif                 // 0 = off; 1 = priority = order; 2 = (order + GN step) & 3: every workgroup is favoured in some steps; 3 = min(order, 2)
@@ -199,12 +190,6 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
     }
     return;
   }
-#if defined(HSM_XSTAGGER) && HSM_XSTAGGER > 0  // experiment: the k-th workgroup dispatched to a CU starts k x HSM_XSTAGGER x 64 cycles late
-  if (!CW) {                                  // (the endpoint streams of a CU's four workgroups then do not all hit the HBM at once)
-    const int late = (int)((blockIdx.x >> 8) & 3u) * HSM_XSTAGGER;
-    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
   // rounds per GN step: the BPL cached rows (all of them: shorter scans pad with +-0 contributions), plus streamed
   // rounds for scans longer than the host's length hint
   const int rounds = BPL + (nmax > 64 * BPL ? (nmax - 64 * BPL + 63) >> 6 : 0);
@@ -249,7 +234,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
   // hsm_set_clock_probe: workgroup 0 stamps the shader-clock counter and the 100 MHz wall clock when it starts and when it ends
   // (both are scalar reads; the start stamps wait in SGPRs and go out with the end stamps, where the texel cache no longer holds
   // the VGPRs)
-  const unsigned long long probe_t0 = PROBE || HSM_XPACE > 0 ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+  const unsigned long long probe_t0 = PROBE ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
   const unsigned long long probe_w0 = PROBE ? wall_clock64() : 0ull;
 #ifdef HSM_XTIMELINE_WG  // (variant builds: start / end wall clock (100 MHz) and XCC id of every workgroup, [block][4] behind the other stamps)
   if (P.clock_probe != nullptr && wave == 0 && lane == 0) {
@@ -524,15 +509,7 @@ __global__ void __launch_bounds__(64 * (NS + (CW ? 1 : 0)), CW && 5 * BPC + 50 <
         }
       };
       const int wg_order = (int)((blockIdx.x >> 8) & 3u);
-      int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
-#if HSM_XPACE > 0
-      if (!CW && !kFirst) {  // experiment: producers' priority from the workgroup's lateness against a pace (cycles per round)
-        const int t = (int)((unsigned long long)__builtin_readcyclecounter() - probe_t0);
-        const int late = t - rounds * (HSM_XPACE_FIRST + (step_no - 1) * HSM_XPACE);
-        wg_prio = late > rounds * HSM_XPACE_BAND ? 2 : late > -rounds * HSM_XPACE_BAND ? 1 : 0;
-        wg_prio = __builtin_amdgcn_readfirstlane(wg_prio);
-      }
-#endif
+      const int wg_prio = HSM_XWGPRIO == 1 ? wg_order : HSM_XWGPRIO == 2 ? ((wg_order + step_no) & 3) : HSM_XWGPRIO == 3 ? min(wg_order, 2) : 0;
       if (HSM_XWGPRIO != 0 && !CW) set_prio_uniform(wg_prio);
       // round k is staged: meet, then (one wavefront) run the chain jobs that are complete with it
       const int my_rounds =
