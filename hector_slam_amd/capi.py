@@ -29,7 +29,7 @@ HSM_OK = 0
 LAYOUT_AUTO, LAYOUT_QUAD, LAYOUT_PLANE = 0, 1, 2
 PARITY_FAST, PARITY_EXACT, PARITY_RELAXED, PARITY_AUTO = 0, 1, 2, 3
 GATHER_AUTO, GATHER_PEER, GATHER_RCCL, GATHER_DIRECT = 0, 1, 2, 3
-ORDER_GIVEN, ORDER_MORTON = 0, 1
+ORDER_GIVEN, ORDER_MORTON, ORDER_AUTO = 0, 1, 2
 EXCHANGE_HANDLE_BYTES = 64
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -267,11 +267,11 @@ class MapRepMultiMap:
         return self._lib.hsm_parity(self._h)
 
     def set_batch_order(self, order: int):
-        """ORDER_GIVEN (default) / ORDER_MORTON: how a batch is laid out on the device (hsm_set_batch_order)"""
+        """ORDER_AUTO (default) / ORDER_GIVEN / ORDER_MORTON: how a batch is laid out on the device (hsm_set_batch_order)"""
         _check(self._lib.hsm_set_batch_order(self._h, order), "hsm_set_batch_order")
 
     def set_batch_order_refresh(self, launches: int):
-        """a stream's permutation serves that many launches of the same batch size before it is computed again (default 8)"""
+        """a stream's permutation serves that many launches of the same batch size before it is computed again (default 16)"""
         _check(self._lib.hsm_set_batch_order_refresh(self._h, launches), "hsm_set_batch_order_refresh")
 
     def batch_order(self) -> int:

@@ -775,11 +775,12 @@ int hsm_create(float map_resolution, int size_x, int size_y, unsigned levels, fl
     h->auto_parity = is_auto;
   }
   if (const char* env = getenv("HSM_BATCH_ORDER")) {
-    if (strcmp(env, "given") == 0) h->batch_order = HSM_ORDER_GIVEN;
+    if (strcmp(env, "auto") == 0) h->batch_order = HSM_ORDER_AUTO;
+    else if (strcmp(env, "given") == 0) h->batch_order = HSM_ORDER_GIVEN;
     else if (strcmp(env, "morton") == 0) h->batch_order = HSM_ORDER_MORTON;
     else {
       delete h;
-      return fail(HSM_ERR_INVALID, "hsm_create: HSM_BATCH_ORDER must be given or morton");
+      return fail(HSM_ERR_INVALID, "hsm_create: HSM_BATCH_ORDER must be one of auto, given, morton");
     }
   }
   if (const char* env = getenv("HSM_BATCH_ORDER_MIN")) h->batch_order_min = atoi(env);
@@ -968,7 +969,7 @@ int hsm_last_launch_parity(const hsm_ctx* h) { return h ? h->last_parity : HSM_P
 
 int hsm_set_batch_order(hsm_ctx* h, int order) {
   if (!h) return fail(HSM_ERR_INVALID, "null context");
-  if (order != HSM_ORDER_GIVEN && order != HSM_ORDER_MORTON) return fail(HSM_ERR_INVALID, "hsm_set_batch_order: unknown order");
+  if (order != HSM_ORDER_GIVEN && order != HSM_ORDER_MORTON && order != HSM_ORDER_AUTO) return fail(HSM_ERR_INVALID, "hsm_set_batch_order: unknown order");
   std::lock_guard<std::mutex> lk(h->mu);
   h->batch_order = order;
   for (hsm_ctx::PermBuf& b : h->perm_bufs) b.batch = 0;
@@ -982,7 +983,7 @@ int hsm_set_batch_order_refresh(hsm_ctx* h, int launches) {
   for (hsm_ctx::PermBuf& b : h->perm_bufs) b.batch = 0;  // (the next launch computes a fresh one)
   return HSM_OK;
 }
-int hsm_batch_order(const hsm_ctx* h) { return h ? h->batch_order : HSM_ORDER_GIVEN; }
+int hsm_batch_order(const hsm_ctx* h) { return h ? h->batch_order : HSM_ORDER_AUTO; }
 int hsm_last_launch_sorted(const hsm_ctx* h) { return h && h->last_sorted ? 1 : 0; }
 
 int hsm_set_clock_probe(hsm_ctx* h, unsigned long long* d_stamps4) {

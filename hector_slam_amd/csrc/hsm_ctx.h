@@ -181,9 +181,9 @@ struct hsm_ctx {
   bool exact_spec1 = false;      // env HSM_EXACT_SPEC1=1: ONE scan of up to 2048 beams (hsm_match) in exact order takes the on-chip speculative-carry form
   // hsm_set_batch_order: launch order of a batch (texel-cache batch forms).  One permutation buffer per stream that has launched
   // a sorted batch (launches on one stream are ordered; a ninth stream keeps the caller's order)
-  int batch_order = 0;           // HSM_ORDER_GIVEN
+  int batch_order = 2;           // HSM_ORDER_AUTO
   int batch_order_min = 1024;    // env HSM_BATCH_ORDER_MIN: smaller batches keep the caller's order
-  int batch_order_refresh = 8;   // hsm_set_batch_order_refresh / env HSM_BATCH_ORDER_REFRESH: a stream's permutation serves that many
+  int batch_order_refresh = 16;  // hsm_set_batch_order_refresh / env HSM_BATCH_ORDER_REFRESH: a stream's permutation serves that many
                                  // launches of the same batch size before it is computed again (ANY permutation gives the same
                                  // results; an old one only groups the scans by where they were)
   struct PermBuf {

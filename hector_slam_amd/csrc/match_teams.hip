@@ -41,13 +41,17 @@ __device__ __forceinline__ int bin_take(int* bins, int key, bool valid, int lane
   return pos;
 }
 
+// detect != 0 (HSM_ORDER_AUTO): a batch that follows the map already -- its tile changes between neighbours number no more than a
+// few times its distinct tiles -- keeps its own order (the identity permutation): the order inside a tile would only get worse.
 __global__ void __launch_bounds__(1024) batch_order_kernel(Affine2 mapTworld, int tile_shift, const float* __restrict__ begin_world, int batch,
-                                                           int* __restrict__ perm) {
+                                                           int* __restrict__ perm, int detect) {
   constexpr int KPT = 8;  // scans per thread and pass: their start poses are loaded together, not one dependent round trip each
   __shared__ int bins[4096];
   __shared__ int part[1024];
+  __shared__ int changes, tiles;
   const int tid = (int)threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 4096; i += 1024) bins[i] = 0;
+  if (tid == 0) changes = 0, tiles = 0;
   __syncthreads();
   auto keys_of = [&](int first, int (&key)[KPT]) {
     float x[KPT], y[KPT];
@@ -71,10 +75,27 @@ __global__ void __launch_bounds__(1024) batch_order_kernel(Affine2 mapTworld, in
   for (int first = 0; first < batch; first += 1024 * KPT) {
     keys_of(first, key);
 #pragma unroll
-    for (int u = 0; u < KPT; ++u) bin_take(bins, key[u], first + u * 1024 + tid < batch, lane);
+    for (int u = 0; u < KPT; ++u) {
+      const bool valid = first + u * 1024 + tid < batch;
+      bin_take(bins, key[u], valid, lane);
+      if (detect) {  // neighbours in the batch are neighbours in the wavefront (the first lane's left neighbour is not looked at)
+        const int left = __shfl_up(key[u], 1);
+        const unsigned long long m = __ballot(valid && lane > 0 && key[u] != left);
+        if (lane == 0 && m != 0ull) atomicAdd(&changes, (int)__popcll(m));
+      }
+    }
   }
   __syncthreads();
   const int c0 = bins[4 * tid], c1 = bins[4 * tid + 1], c2 = bins[4 * tid + 2], c3 = bins[4 * tid + 3];
+  if (detect) {
+    const int wave_tiles = (int)(__popcll(__ballot(c0 != 0)) + __popcll(__ballot(c1 != 0)) + __popcll(__ballot(c2 != 0)) + __popcll(__ballot(c3 != 0)));
+    if (lane == 0 && wave_tiles) atomicAdd(&tiles, wave_tiles);
+    __syncthreads();
+    if (changes <= 4 * tiles + 16) {  // (workgroup-uniform)
+      for (int i = tid; i < batch; i += 1024) perm[i] = i;
+      return;
+    }
+  }
   // exclusive scan of the 1024 partial counts: inside the wavefront by DPP-free shuffles, then over the 16 wavefront totals
   const int mine = c0 + c1 + c2 + c3;
   int inc = mine;
@@ -109,7 +130,8 @@ namespace hsm_host {
 
 int ensure_batch_perm(hsm_ctx* h, MatchParams& P, hipStream_t stream) {
   if (P.perm != nullptr || P.begin_world == nullptr || P.batch < h->batch_order_min) return HSM_OK;
-  if (h->batch_order != HSM_ORDER_MORTON) return HSM_OK;
+  const bool automatic = h->batch_order == HSM_ORDER_AUTO;
+  if (h->batch_order != HSM_ORDER_MORTON && !(automatic && h->levels[0].cells() > ((size_t)1 << 23))) return HSM_OK;
   hsm_ctx::PermBuf* pb = nullptr;
   for (hsm_ctx::PermBuf& b : h->perm_bufs)
     if (b.s == stream) pb = &b;
@@ -135,7 +157,7 @@ int ensure_batch_perm(hsm_ctx* h, MatchParams& P, hipStream_t stream) {
   const Level& L0 = h->levels[0];
   int shift = 0;
   while ((64 << shift) < (L0.sx > L0.sy ? L0.sx : L0.sy)) ++shift;
-  hipLaunchKernelGGL(batch_order_kernel, dim3(1), dim3(1024), 0, stream, P.lv[0].mapTworld, shift, P.begin_world, P.batch, pb->d);
+  hipLaunchKernelGGL(batch_order_kernel, dim3(1), dim3(1024), 0, stream, P.lv[0].mapTworld, shift, P.begin_world, P.batch, pb->d, automatic ? 1 : 0);
   HIP_TRY(hipGetLastError());
   pb->batch = P.batch, pb->used = 1;
   P.perm = pb->d;

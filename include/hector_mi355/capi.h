@@ -112,19 +112,23 @@ int hsm_last_launch_parity(const hsm_ctx* h);
 /* no reference counterpart (the reference matches one scan at a time): the order in which a BATCH is laid out on the device.
  * Scans that are neighbours in a launch run on one XCD at the same time and share the texel lines they touch in its L2; a batch
  * whose order does not follow the map (particles of several modes, several robots) loses that -- 61 instead of 58 us on the
- * 2048^2 map, 177 instead of 145 us on the 4096^2 pyramid (profiles/r06).  HSM_ORDER_MORTON (opt-in; env
- * HSM_BATCH_ORDER=morton): a one-workgroup counting sort in front of the matcher orders batches of at least 1024 scans by the
- * Morton code of the 64 x 64 map tile their start poses lie in, and the matcher takes its scans through that permutation; every
- * result still lands at the scan's own index and is bit-identical.  The sort is a 9 us kernel, so a stream's permutation serves
- * hsm_set_batch_order_refresh launches of the same batch size (default 8; env HSM_BATCH_ORDER_REFRESH) before it is computed
- * again: ANY permutation gives the same results, an old one only groups the scans by where they were a few launches ago.
- * Worth it on maps that outgrow the L2s when the batch is not in map order already.  HSM_ORDER_GIVEN (default): the caller's
- * order.  Applies to the texel-cache batch forms (every batch of the quad layout). */
-enum { HSM_ORDER_GIVEN = 0, HSM_ORDER_MORTON = 1 };
+ * 2048^2 map, 178 instead of 145 us on the 4096^2 pyramid (profiles/r06).
+ *   HSM_ORDER_MORTON: a one-workgroup counting sort in front of the matcher orders batches of at least 1024 scans by the Morton
+ *     code of the 64 x 64 map tile their start poses lie in, and the matcher takes its scans through that permutation; every
+ *     result still lands at the scan's own index and is bit-identical.  The sort is a 9 us kernel, so a stream's permutation
+ *     serves hsm_set_batch_order_refresh launches of the same batch size (default 16; env HSM_BATCH_ORDER_REFRESH) before it is
+ *     computed again: ANY permutation gives the same results, an old one only groups the scans by where they were a few
+ *     launches ago.
+ *   HSM_ORDER_AUTO (default; env HSM_BATCH_ORDER=auto|given|morton): that, on maps of more than 2^23 cells (the ones that outgrow
+ *     the L2s), and only for a batch that does not follow the map already -- the sort kernel counts the tile changes between
+ *     neighbouring scans and leaves a batch that has few of them in its own order.  Costs such a batch ~1 us per launch.
+ *   HSM_ORDER_GIVEN: always the caller's order.
+ * Applies to the texel-cache batch forms (every batch of the quad layout). */
+enum { HSM_ORDER_GIVEN = 0, HSM_ORDER_MORTON = 1, HSM_ORDER_AUTO = 2 };
 int hsm_set_batch_order(hsm_ctx* h, int order);
 int hsm_set_batch_order_refresh(hsm_ctx* h, int launches);
 int hsm_batch_order(const hsm_ctx* h);
-/* 1 if the last batched match ran in Morton order, else 0 */
+/* 1 if the last batched match took its scans through a permutation (Morton order, or the identity AUTO left a batch in), else 0 */
 int hsm_last_launch_sorted(const hsm_ctx* h);
 
 /* ---- the hot path -----------------------------------------------------------

@@ -274,7 +274,7 @@ def test_batch_in_morton_order_gives_the_same_bits(capi, oracle_mod, B):
     scans[5] = scans[5][:0]
     init = sc.query_init[idx] + rng.uniform(-0.05, 0.05, (B, 3)).astype(np.float32) * np.float32([1, 1, 0.2])
     pts, offs = synth.pack_scans(scans)
-    assert g.batch_order() == capi.ORDER_GIVEN
+    assert g.batch_order() == capi.ORDER_AUTO  # (on a map of 2^20 cells: the caller's order)
     for mode in (capi.PARITY_AUTO, capi.PARITY_FAST):
         g.set_parity(mode)
         g.set_batch_order(capi.ORDER_GIVEN)
@@ -324,10 +324,11 @@ def test_batch_in_morton_order_gives_the_same_bits(capi, oracle_mod, B):
 
 
 def test_batch_order_environment_word(capi, monkeypatch):
-    monkeypatch.setenv("HSM_BATCH_ORDER", "morton")
-    g = capi.MapRepMultiMap(0.05, 256, 256, 1)
-    assert g.batch_order() == capi.ORDER_MORTON
-    g.close()
+    for word, order in (("morton", capi.ORDER_MORTON), ("given", capi.ORDER_GIVEN), ("auto", capi.ORDER_AUTO)):
+        monkeypatch.setenv("HSM_BATCH_ORDER", word)
+        g = capi.MapRepMultiMap(0.05, 256, 256, 1)
+        assert g.batch_order() == order
+        g.close()
     monkeypatch.setenv("HSM_BATCH_ORDER", "sorted")
     with pytest.raises(capi.HsmError):
         capi.MapRepMultiMap(0.05, 256, 256, 1)
@@ -417,6 +418,20 @@ def test_config4_share_4096map_pyramid(capi, oracle_mod):
     # the rest (worst measured 0.07 m)
     batch_properties(capi, oracle_mod, sc, g, sc.query_init, sc.query_scans, np.random.default_rng(6),
                      fast_within_tol=0.99, fast_max_m=0.1)
+    # HSM_ORDER_AUTO (the default) on a map of this size: the batch goes through the sort kernel's permutation -- the identity for
+    # this batch, which follows the trajectory; a Morton order for the same batch shuffled -- and every pose keeps its bits
+    pts, offs = synth.pack_scans(sc.query_scans)
+    assert g.batch_order() == capi.ORDER_AUTO
+    p_auto, _ = g.match_batch(sc.query_init, pts, offs)
+    assert g.last_launch_sorted()
+    g.set_batch_order(capi.ORDER_GIVEN)
+    p_given, _ = g.match_batch(sc.query_init, pts, offs)
+    assert not g.last_launch_sorted() and np.array_equal(bits(p_auto), bits(p_given))
+    perm = np.random.default_rng(8).permutation(len(sc.query_scans))
+    pts_r, offs_r = synth.pack_scans([sc.query_scans[i] for i in perm])
+    g.set_batch_order(capi.ORDER_AUTO)
+    p_r, _ = g.match_batch(sc.query_init[perm], pts_r, offs_r)
+    assert g.last_launch_sorted() and np.array_equal(bits(p_r), bits(p_given[perm]))
 
 
 def config5_loop(capi, oracle_mod, steps, seed=31, **ctx_kw):

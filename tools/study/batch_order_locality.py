@@ -20,6 +20,7 @@ for name, kw in (("2048^2, 1 level", dict(map_size=2048, levels=1, room=(40.0, 3
     rp = rng.permutation(B)
     for order_name, perm, order in (("trajectory order", np.arange(B), capi.ORDER_GIVEN), ("random order", rp, capi.ORDER_GIVEN),
                                     ("random order, HSM_ORDER_MORTON", rp, capi.ORDER_MORTON), ("trajectory order, HSM_ORDER_MORTON", np.arange(B), capi.ORDER_MORTON),
+                                    ("random order, HSM_ORDER_AUTO (the default)", rp, capi.ORDER_AUTO), ("trajectory order, HSM_ORDER_AUTO (the default)", np.arange(B), capi.ORDER_AUTO),
                                     ("trajectory order again", np.arange(B), capi.ORDER_GIVEN)):
         g.set_batch_order(order)
         scans = [sc.query_scans[i] for i in perm]
