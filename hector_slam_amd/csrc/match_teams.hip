@@ -141,6 +141,9 @@ int ensure_batch_perm(hsm_ctx* h, MatchParams& P, hipStream_t stream) {
     pb = &h->perm_bufs.back();
   }
   if (pb->cap < (size_t)P.batch) {
+    // (no allocation while the caller captures this stream into a graph: such a launch keeps the caller's order)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return HSM_OK;
     if (pb->d) HIP_TRY(hipFree(pb->d));  // (hipFree waits for the device: no launch still reads it)
     pb->d = nullptr, pb->cap = 0, pb->batch = 0;
     const size_t cap = ((size_t)P.batch + 4095) / 4096 * 4096;

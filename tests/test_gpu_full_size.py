@@ -367,6 +367,20 @@ def test_batched_matches_can_be_captured_in_a_hip_graph(capi, oracle_mod):
             graph.replay()
             torch.cuda.synchronize()
             assert np.array_equal(bits(d_pose.cpu().numpy()), bits(ref)), order
+    # a stream whose FIRST sorted launch happens inside a capture: no permutation buffer exists yet and none is allocated while
+    # capturing -- those launches keep the caller's order; same bits
+    s2 = torch.cuda.Stream()
+    g.set_batch_order(capi.ORDER_MORTON)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=s2):
+        for _ in range(2):
+            g.match_batch_device(4096, d_init.data_ptr(), d_pts.data_ptr(), d_offs.data_ptr(), 1081, d_pose.data_ptr(), 0, s2.cuda_stream)
+    assert not g.last_launch_sorted()
+    d_pose.zero_()
+    torch.cuda.synchronize()
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d_pose.cpu().numpy()), bits(ref))
     g.close()
 
 
